@@ -1,0 +1,39 @@
+"""MI355X-native engine for CellRegMap's per-variant score-test path.
+
+Exports the names of the reference package (cellregmap/__init__.py:1-20).
+"""
+from enum import Enum
+
+from ._engine import (
+    CellRegMap,
+    GenotypePanel,
+    estimate_betas,
+    get_L_values,
+    lrt_pvalues,
+    run_association,
+    run_association_fast,
+    run_interaction,
+)
+
+
+class Term(Enum):
+    """cellregmap/_types.py:1-8."""
+
+    FIXED = 1
+    RANDOM = 2
+
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "__version__",
+    "CellRegMap",
+    "GenotypePanel",
+    "run_association",
+    "run_association_fast",
+    "run_interaction",
+    "estimate_betas",
+    "get_L_values",
+    "lrt_pvalues",
+    "Term",
+]

@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's scan API on top of libcrm_hip.so.
+
+Same names, argument meaning, defaults, positional quirks and error behaviour as
+``cellregmap/_cellregmap.py`` (reference file:line cited per method); everything
+numerical happens in the HIP library through the C-ABI of ``include/crm_hip.h``.
+There is no CPU path here: without the library or without a GPU, calls raise.
+"""
+import ctypes
+import hashlib
+import weakref
+from collections import OrderedDict
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+_RHO_GRID = np.linspace(0, 1, 11)
+_SQRT_EPS = float(np.sqrt(np.finfo(float).eps))
+
+_contexts = {}
+
+
+def _context(device=0):
+    """One library context (device + stream + workspace) per device, created lazily."""
+    if device not in _contexts:
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(lib.crm_ctx_create(int(device), ctypes.byref(h)))
+        _contexts[device] = h
+    return _contexts[device]
+
+
+def _economic_svd(X):
+    """Thin SVD with singular values < sqrt(eps) dropped (numpy_sugar.economic_svd,
+    used at _cellregmap.py:540)."""
+    U, s, Vt = np.linalg.svd(np.asarray(X, float), full_matrices=False)
+    ok = s >= _SQRT_EPS
+    return U[:, ok], s[ok], Vt[ok, :]
+
+
+def get_L_values(hK, E):
+    """L_i = diag((U S)[:, i]) hK with U, S from the economic SVD of E
+    (_cellregmap.py:533-545); sum_i L_i L_i' = K o EE' (proof.md)."""
+    U, S, _ = _economic_svd(E)
+    us = U * S
+    hK = np.asarray(hK, float)
+    return [us[:, [i]] * hK for i in range(us.shape[1])]
+
+
+class _Background:
+    """Owner of a ``crm_background`` handle (device-resident Q0/S0 per rho)."""
+
+    def __init__(self, handle, rho, device):
+        self.handle = handle
+        self.rho = np.asarray(rho, float)
+        self.device = device
+        self._fin = weakref.finalize(self, _lib.load().crm_background_destroy, handle)
+
+    def rank(self, i):
+        return _lib.load().crm_background_rank(self.handle, i)
+
+    def read(self, i, n):
+        r = self.rank(i)
+        Q0 = np.empty((n, r))
+        S0 = np.empty(r)
+        _lib.check(_lib.load().crm_background_read(self.handle, i, _lib.ptr(Q0), _lib.ptr(S0)))
+        return Q0, S0
+
+
+_bg_cache = OrderedDict()
+BACKGROUND_CACHE_SIZE = 2
+
+
+def _digest(*arrays):
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        if a is None:
+            h.update(b"-")
+        else:
+            h.update(str(a.shape).encode())
+            h.update(np.ascontiguousarray(a).view(np.uint8).data)
+    return h.hexdigest()
+
+
+def _make_background(E1, B, rho, device, rel_tol=0.0, cache=True):
+    """hS(rho) = [sqrt(rho) E1, sqrt(1-rho) B] -> economic eigendecompositions on the device.
+    Re-used across objects with identical (E1, B, rho): the reference redoes the 11
+    decompositions per ``CellRegMap(...)``, i.e. per gene."""
+    lib = _lib.load()
+    key = (device, _digest(E1, B), tuple(np.asarray(rho, float)), rel_tol) if cache else None
+    if cache and key in _bg_cache:
+        _bg_cache.move_to_end(key)
+        return _bg_cache[key]
+    ctx = _context(device)
+    E1c = _lib.f64(E1)
+    Bc = None if B is None else _lib.f64(B)
+    rho = _lib.f64(rho)
+    h = ctypes.c_void_p()
+    _lib.check(lib.crm_background_create(ctx, E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(Bc),
+                                         0 if Bc is None else Bc.shape[1], rho.shape[0], _lib.ptr(rho),
+                                         float(rel_tol), ctypes.byref(h)))
+    bg = _Background(h, rho, device)
+    if cache:
+        _bg_cache[key] = bg
+        while len(_bg_cache) > BACKGROUND_CACHE_SIZE:
+            _bg_cache.popitem(last=False)
+    return bg
+
+
+def background_from_qs(qs_list, rho, device=0):
+    """Background from precomputed ``((Q0,), S0)`` pairs (one per rho), e.g. LAPACK's."""
+    lib = _lib.load()
+    ctx = _context(device)
+    Q0s = [_lib.f64(q[0][0]) for q in qs_list]
+    S0s = [_lib.f64(q[1]) for q in qs_list]
+    n = Q0s[0].shape[0]
+    r = np.asarray([q.shape[1] for q in Q0s], np.int32)
+    rho = _lib.f64(rho)
+    PP = ctypes.c_void_p * len(Q0s)
+    qp = PP(*[q.ctypes.data for q in Q0s])
+    sp = PP(*[s.ctypes.data for s in S0s])
+    h = ctypes.c_void_p()
+    _lib.check(lib.crm_background_create_qs(ctx, n, len(Q0s), _lib.ptr(rho), _lib.ptr(r), qp, sp,
+                                            ctypes.byref(h)))
+    return _Background(h, rho, device)
+
+
+class GenotypePanel:
+    """A genotype matrix (n x p) resident in HBM; build once, scan many genes against it."""
+
+    def __init__(self, G, device=0):
+        lib = _lib.load()
+        G = np.asarray(G, float)
+        assert G.ndim == 2
+        if not G.flags.c_contiguous:
+            G = np.ascontiguousarray(G)
+        self.shape = G.shape
+        self.device = device
+        h = ctypes.c_void_p()
+        _lib.check(lib.crm_panel_create(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
+                                        ctypes.byref(h)))
+        self.handle = h
+        self._fin = weakref.finalize(self, lib.crm_panel_destroy, h)
+
+
+class CellRegMap:
+    """Mixed model with genetic effect heterogeneity -- MI355X engine.
+
+    Drop-in for ``cellregmap.CellRegMap`` (_cellregmap.py:23-440) on the score-test path:
+    the constructor (:63-131) builds the rho grid of background covariances as economic
+    eigendecompositions -- here on the device -- and ``scan_interaction`` (:317-440) runs the
+    per-variant null fits, score statistic and Davies p-value in batched HIP kernels.
+
+    Extra keyword-only arguments (not in the reference): ``device`` (GPU ordinal),
+    ``background`` (a prebuilt background to share across genes).
+    """
+
+    def __init__(self, y, E, W=None, Ls=None, E1=None, hK=None, *, device=0, background=None):
+        # coercions and checks exactly as _cellregmap.py:64-91
+        self._y = np.asarray(y, float).flatten()
+        self._E0 = np.asarray(E, float)
+        Ls = [] if Ls is None else Ls
+        if W is not None:
+            self._W = np.asarray(W, float)
+        else:
+            self._W = np.ones((self._y.shape[0], 1))
+        if E1 is not None:
+            self._E1 = np.asarray(E1, float)
+        else:
+            self._E1 = np.asarray(E, float)
+        self._Ls = list(np.asarray(L, float) for L in Ls)
+
+        assert self._W.ndim == 2
+        assert self._E0.ndim == 2
+        assert self._E1.ndim == 2
+        assert self._y.shape[0] == self._W.shape[0]
+        assert self._y.shape[0] == self._E0.shape[0]
+        assert self._y.shape[0] == self._E1.shape[0]
+        for L in Ls:
+            assert self._y.shape[0] == L.shape[0]
+            assert L.ndim == 2
+
+        self._device = device
+        # background modes of _cellregmap.py:101-131
+        if len(Ls) == 0:
+            if hK is None:
+                self._rho1 = [1.0]
+                B = None
+            else:
+                self._rho1 = _RHO_GRID
+                B = np.asarray(hK, float)
+        else:
+            self._rho1 = _RHO_GRID
+            B = np.concatenate(self._Ls, axis=1)
+        if background is not None:
+            self._bg = background
+        else:
+            self._bg = _make_background(self._E1, B, self._rho1, device)
+        self._gene = None
+        self._gene_fin = None
+
+    @property
+    def n_samples(self):
+        return self._y.shape[0]
+
+    # -- device objects --------------------------------------------------------------------
+    def _fixed_effect_basis(self):
+        """W, or an orthogonal basis of its column space when W is rank deficient (the
+        reference's LMM and PMat only depend on span(W): economic_svd / lstsq)."""
+        W = self._W
+        if W.shape[1] == 0:
+            raise ValueError("W has no columns")
+        U, s, _ = _economic_svd(W)
+        if s.shape[0] == W.shape[1]:
+            return W
+        return U * s
+
+    def _bind_gene(self):
+        if self._gene is not None:
+            return self._gene
+        lib = _lib.load()
+        if not np.all(np.isfinite(self._y)):
+            raise ValueError("There are non-finite values in the outcome.")
+        if not np.all(np.isfinite(self._W)):
+            raise ValueError("There are non-finite values in the covariates matrix.")
+        Wb = _lib.f64(self._fixed_effect_basis())
+        y = _lib.f64(self._y)
+        E0 = _lib.f64(self._E0)
+        h = ctypes.c_void_p()
+        _lib.check(lib.crm_gene_create(self._bg.handle, _lib.ptr(y), _lib.ptr(Wb), Wb.shape[1], _lib.ptr(E0),
+                                       E0.shape[1], ctypes.byref(h)))
+        self._gene = h
+        self._gene_fin = weakref.finalize(self, lib.crm_gene_destroy, h)
+        return h
+
+    # -- interaction scan (_cellregmap.py:317-440) ----------------------------------------------
+    def scan_interaction(self, G, idx_E: Optional[any] = None, idx_G: Optional[any] = None,
+                         return_stats: bool = False):
+        """Per-variant GxC score test.  ``G`` is n x p (array-like) or a ``GenotypePanel``.
+
+        Returns ``(pvalues, info)`` with ``info = {rho1, e2, g2, eps2}`` as the reference
+        (:439-440); with ``return_stats=True`` additionally a dict holding Q, the eigenvalues
+        of F, F itself and the null-fit scalars (for parity tests)."""
+        lib = _lib.load()
+        panel = G if isinstance(G, GenotypePanel) else GenotypePanel(np.asarray(G, float), self._device)
+        n, p = panel.shape
+        if n != self.n_samples:
+            raise ValueError(f"G has {n} rows, expected {self.n_samples}")
+        if not isinstance(G, GenotypePanel) and not np.all(np.isfinite(np.asarray(G, float))):
+            raise ValueError("There are non-finite values in the covariates matrix.")
+        gene = self._bind_gene()
+        k0 = self._E0.shape[1]
+
+        def _perm(idx):
+            if idx is None:
+                return None
+            idx = np.asarray(idx)
+            if idx.dtype == bool:
+                idx = np.flatnonzero(idx)
+            idx = np.ascontiguousarray(idx, dtype=np.int64)
+            if idx.shape != (n,):
+                raise ValueError("permutation index must have one entry per sample")
+            idx = np.where(idx < 0, idx + n, idx)
+            return np.ascontiguousarray(idx, dtype=np.int32)
+
+        iE, iG = _perm(idx_E), _perm(idx_G)
+        out = {k: np.empty(p) for k in ("pv", "rho1", "e2", "g2", "eps2")}
+        extra = {}
+        if return_stats:
+            extra = {"Q": np.empty(p), "lml": np.empty(p), "delta": np.empty(p), "scale": np.empty(p),
+                     "lambda": np.empty((p, k0)), "F": np.empty((p, k0, k0))}
+        _lib.check(lib.crm_scan_interaction(
+            gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),
+            _lib.ptr(out["pv"]), _lib.ptr(out["rho1"]), _lib.ptr(out["e2"]), _lib.ptr(out["g2"]),
+            _lib.ptr(out["eps2"]), _lib.ptr(extra.get("Q")), _lib.ptr(extra.get("lml")),
+            _lib.ptr(extra.get("delta")), _lib.ptr(extra.get("scale")), _lib.ptr(extra.get("lambda")),
+            _lib.ptr(extra.get("F"))))
+        info = {key: out[key] for key in ("rho1", "e2", "g2", "eps2")}
+        if return_stats:
+            return out["pv"], info, extra
+        return out["pv"], info
+
+    # -- association scans (_cellregmap.py:246-314): not on the device yet ----------------------------
+    def scan_association(self, G):
+        raise NotImplementedError(
+            "scan_association (LRT, _cellregmap.py:246-281) is not built yet in the MI355X engine")
+
+    def scan_association_fast(self, G):
+        raise NotImplementedError(
+            "scan_association_fast (_cellregmap.py:284-314) is not built yet in the MI355X engine")
+
+    def predict_interaction(self, G, MAF):
+        raise NotImplementedError("effect-size estimation is outside the score-test path")
+
+    def estimate_aggregate_environment(self, g):
+        raise NotImplementedError("effect-size estimation is outside the score-test path")
+
+
+def lrt_pvalues(null_lml, alt_lmls, dof=1):
+    """Likelihood-ratio p-values with the reference's clips (_cellregmap.py:443-469)."""
+    from scipy.stats import chi2
+
+    tiny = float(np.finfo(float).eps)
+    super_tiny = float(np.finfo(float).tiny)
+    lrs = np.clip(-2 * null_lml + 2 * np.asarray(alt_lmls, float), super_tiny, np.inf)
+    pv = chi2(df=dof).sf(lrs)
+    return np.clip(pv, super_tiny, 1 - tiny)
+
+
+def run_interaction(y, E, G, W=None, E1=None, E2=None, hK=None, idx_G=None, *, device=0):
+    """Interaction test (_cellregmap.py:547-587).
+
+    As in the reference, ``idx_G`` is forwarded positionally and therefore lands in
+    ``scan_interaction``'s ``idx_E`` slot (:586 vs :318): it permutes the rows of the
+    contexts inside the test direction, not the genotypes."""
+    if E1 is None:
+        E1 = E
+    if E2 is None:
+        E2 = E
+    if hK is None:
+        Ls = None
+    else:
+        Ls = get_L_values(hK, E2)
+    crm = CellRegMap(y=y, E=E, W=W, E1=E1, Ls=Ls, device=device)
+    pv = crm.scan_interaction(G, idx_G)
+    return pv
+
+
+def run_association(y, W, E, G, hK=None, *, device=0):
+    """Association test (_cellregmap.py:471-500).  The reference's positional constructor call
+    (:498) binds ``W`` to the contexts slot and ``E`` to the covariates slot; kept as is."""
+    crm = CellRegMap(y, W, E, hK=hK, device=device)
+    pv = crm.scan_association(G)
+    return pv
+
+
+def run_association_fast(y, W, E, G, hK=None, *, device=0):
+    """Fast association test (_cellregmap.py:502-531); same positional binding (:529)."""
+    crm = CellRegMap(y, W, E, hK=hK, device=device)
+    pv = crm.scan_association_fast(G)
+    return pv
+
+
+def estimate_betas(y, W, E, G, maf=None, E1=None, E2=None, hK=None):
+    """Effect sizes (_cellregmap.py:640-682): outside the score-test path."""
+    raise NotImplementedError("estimate_betas is outside the score-test path of this engine")

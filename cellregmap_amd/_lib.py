@@ -1,0 +1,87 @@
+"""ctypes binding of libcrm_hip.so (the C-ABI declared in include/crm_hip.h).
+
+The product path has no CPU fallback: if the library is missing or no MI355X is
+visible, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrm_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_long_p = ctypes.POINTER(ctypes.c_long)
+vp = ctypes.c_void_p
+
+#: every symbol include/crm_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "crm_last_error": (ctypes.c_char_p, []),
+    "crm_version": (ctypes.c_char_p, []),
+    "crm_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
+    "crm_ctx_destroy": (None, [vp]),
+    "crm_ctx_synchronize": (ctypes.c_int, [vp]),
+    "crm_background_create_qs": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp, vp, vp,
+                                                ctypes.POINTER(vp)]),
+    "crm_background_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long,
+                                             ctypes.c_int, vp, ctypes.c_double, ctypes.POINTER(vp)]),
+    "crm_background_destroy": (None, [vp]),
+    "crm_background_rank": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_background_read": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),
+    "crm_gene_create": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(vp)]),
+    "crm_gene_destroy": (None, [vp]),
+    "crm_panel_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long,
+                                        ctypes.POINTER(vp)]),
+    "crm_panel_destroy": (None, [vp]),
+    "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
+    "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
+    "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
+    "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,
+                                         ctypes.c_int]),
+    "crm_test_contract_kr": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            vp, vp, vp, vp]),
+    "crm_test_eigvalsh": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "crm_test_davies": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class CrmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrmError(
+            f"{LIB_PATH} is missing: build it with `python -m cellregmap_amd.build` "
+            "(there is no CPU fallback for this path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().crm_last_error()
+        raise CrmError(f"libcrm_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def f64(a):
+    """C-contiguous float64 view/copy."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(vp)

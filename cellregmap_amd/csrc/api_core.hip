@@ -1,0 +1,236 @@
+// Context, error text, device-buffer helpers and the contraction test hooks of the C-ABI.
+#include <cstdarg>
+
+#include "crm_internal.h"
+
+namespace crm {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+const char* last_error_text() { return g_error.c_str(); }
+
+int DevBuf::ensure(size_t need) {
+    if (need <= bytes) return CRM_OK;
+    if (ptr) {
+        CRM_HIP(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    CRM_HIP(hipMalloc(&ptr, need));
+    bytes = need;
+    return CRM_OK;
+}
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+// Upload a row-major host matrix [rows x cols] (leading dimension ld_src) into a zero-padded
+// device matrix [rows_pad x ld_dst].
+int upload_padded(hipStream_t st, double* dst, long ld_dst, long rows_pad, const double* src,
+                  long ld_src, long rows, long cols) {
+    CRM_HIP(hipMemsetAsync(dst, 0, sizeof(double) * rows_pad * ld_dst, st));
+    if (rows > 0 && cols > 0)
+        CRM_HIP(hipMemcpy2DAsync(dst, ld_dst * sizeof(double), src, ld_src * sizeof(double),
+                                 cols * sizeof(double), rows, hipMemcpyHostToDevice, st));
+    return CRM_OK;
+}
+
+}  // namespace crm
+
+using namespace crm;
+
+extern "C" {
+
+const char* crm_last_error(void) { return last_error_text(); }
+const char* crm_version(void) { return "0.1.0"; }
+
+int crm_ctx_create(int device, crm_ctx** out) {
+    if (!out) return CRM_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    CRM_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        set_error("crm_ctx_create: device %d not present (%d visible)", device, count);
+        return CRM_ERR_ARG;
+    }
+    CRM_HIP(hipSetDevice(device));
+    crm_ctx* c = new crm_ctx();
+    c->device = device;
+    CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRM_HIP(hipEventCreate(&c->ev0));
+    CRM_HIP(hipEventCreate(&c->ev1));
+    *out = c;
+    return CRM_OK;
+}
+
+void crm_ctx_destroy(crm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto* b : c->all_bufs()) b->release();
+    for (auto& e : c->timed) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int crm_ctx_synchronize(crm_ctx* c) {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    return CRM_OK;
+}
+
+int crm_set_block_variants(crm_ctx* c, int variants) {
+    if (!c || variants < 0) return CRM_ERR_ARG;
+    c->block_variants = variants == 0 ? CRM_DEFAULT_BLOCK : (int)round_up(variants, 128);
+    return CRM_OK;
+}
+
+int crm_kernel_timer_reset(crm_ctx* c) {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    c->timed_used = 0;
+    c->kr_flops = 0.0;
+    c->timing = true;
+    return CRM_OK;
+}
+
+int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* kr_flops,
+                          double* total_ms) {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < c->timed_used; i++) {
+        float t = 0.f;
+        CRM_HIP(hipEventElapsedTime(&t, c->timed[i].first, c->timed[i].second));
+        ms += t;
+    }
+    if (kr_ms) *kr_ms = ms;
+    if (kr_launches) *kr_launches = (long)c->timed_used;
+    if (kr_flops) *kr_flops = c->kr_flops;
+    if (total_ms) *total_ms = 0.0;
+    return CRM_OK;
+}
+
+// ---- single-kernel hooks -------------------------------------------------------------
+int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, const double* Y,
+                      double* C, int ksplit) {
+    if (!c || cells <= 0 || M <= 0 || N <= 0 || !X || !Y || !C || ksplit < 1) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    const long cp = round_up(cells, GEMM_BK * (long)ksplit);
+    const long ldx = round_up(M, 128), ldy = round_up(N, 128);
+    DevBuf bx, by, bc, bp;
+    CRM_TRY(bx.ensure(sizeof(double) * cp * ldx));
+    CRM_TRY(by.ensure(sizeof(double) * cp * ldy));
+    const long cstride = (long)M * ldy;
+    CRM_TRY(bc.ensure(sizeof(double) * cstride * ksplit));
+    CRM_TRY(bp.ensure(sizeof(GemmProblem)));
+    CRM_TRY(upload_padded(c->stream, bx.as<double>(), ldx, cp, X, M, cells, M));
+    CRM_TRY(upload_padded(c->stream, by.as<double>(), ldy, cp, Y, N, cells, N));
+    GemmProblem p{};
+    p.X = bx.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
+    p.ldx = ldx; p.ldy = ldy; p.ldc = ldy; p.M = M; p.N = N;
+    CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
+    CRM_TRY(launch_gemm_tn(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, false, 0, ksplit, cstride));
+    CRM_TRY(launch_reduce_splits(c->stream, bc.as<double>(), cstride, ksplit, cstride));
+    CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
+                             M, hipMemcpyDeviceToHost, c->stream));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    bx.release(); by.release(); bc.release(); bp.release();
+    return CRM_OK;
+}
+
+int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const double* G,
+                         const double* E, const double* Y, double* C) {
+    if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !C) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    const long cp = round_up(cells, GEMM_BK);
+    const long ldg = round_up(B, 128) + 128, lde = round_up(k0, 16), ldy = round_up(N, 128);
+    const int M = B * k0;
+    DevBuf bg, be, by, bc, bp;
+    CRM_TRY(bg.ensure(sizeof(double) * cp * ldg));
+    CRM_TRY(be.ensure(sizeof(double) * cp * lde));
+    CRM_TRY(by.ensure(sizeof(double) * cp * ldy));
+    CRM_TRY(bc.ensure(sizeof(double) * (long)M * ldy));
+    CRM_TRY(bp.ensure(sizeof(GemmProblem)));
+    CRM_TRY(upload_padded(c->stream, bg.as<double>(), ldg, cp, G, B, cells, B));
+    CRM_TRY(upload_padded(c->stream, be.as<double>(), lde, cp, E, k0, cells, k0));
+    CRM_TRY(upload_padded(c->stream, by.as<double>(), ldy, cp, Y, N, cells, N));
+    GemmProblem p{};
+    p.X = bg.as<double>(); p.E = be.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
+    p.ldx = ldg; p.lde = lde; p.ldy = ldy; p.ldc = ldy; p.M = M; p.N = N; p.k0 = k0;
+    CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
+    CRM_TRY(launch_gemm_tn(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, true, k0, 1, 0));
+    CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
+                             M, hipMemcpyDeviceToHost, c->stream));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    bg.release(); be.release(); by.release(); bc.release(); bp.release();
+    return CRM_OK;
+}
+
+}  // extern "C"
+
+// ---- eigenvalue / Davies hooks ---------------------------------------------------------------
+#include "nullfit.h"
+
+extern "C" {
+
+int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lambda) {
+    if (!c || count <= 0 || k <= 0 || !F || !lambda) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    DevBuf bF, bQ, bL, bP;
+    CRM_TRY(bF.ensure(sizeof(double) * (size_t)count * k * k));
+    CRM_TRY(bQ.ensure(sizeof(double) * count));
+    CRM_TRY(bL.ensure(sizeof(double) * (size_t)count * k));
+    CRM_TRY(bP.ensure(sizeof(double) * count));
+    CRM_HIP(hipMemcpyAsync(bF.ptr, F, sizeof(double) * (size_t)count * k * k, hipMemcpyHostToDevice, c->stream));
+    CRM_HIP(hipMemsetAsync(bQ.ptr, 0, sizeof(double) * count, c->stream));
+    CRM_TRY(launch_eig_davies(c->stream, bF.as<double>(), bQ.as<double>(), count, k, bL.as<double>(),
+                              bP.as<double>(), nullptr, nullptr, true));
+    CRM_HIP(hipMemcpyAsync(lambda, bL.ptr, sizeof(double) * (size_t)count * k, hipMemcpyDeviceToHost, c->stream));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    bF.release(); bQ.release(); bL.release(); bP.release();
+    return CRM_OK;
+}
+
+int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double* lambda, double* pvalue,
+                    int* ifault, double* liu) {
+    if (!c || count <= 0 || k <= 0 || !Q || !lambda || !pvalue) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    DevBuf bQ, bL, bP, bI, bU;
+    CRM_TRY(bQ.ensure(sizeof(double) * count));
+    CRM_TRY(bL.ensure(sizeof(double) * (size_t)count * k));
+    CRM_TRY(bP.ensure(sizeof(double) * count));
+    CRM_TRY(bI.ensure(sizeof(int) * count));
+    CRM_TRY(bU.ensure(sizeof(double) * count));
+    CRM_HIP(hipMemcpyAsync(bQ.ptr, Q, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+    CRM_HIP(hipMemcpyAsync(bL.ptr, lambda, sizeof(double) * (size_t)count * k, hipMemcpyHostToDevice, c->stream));
+    CRM_TRY(launch_eig_davies(c->stream, nullptr, bQ.as<double>(), count, k, bL.as<double>(), bP.as<double>(),
+                              bI.as<int>(), bU.as<double>(), false));
+    CRM_HIP(hipMemcpyAsync(pvalue, bP.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    if (ifault) CRM_HIP(hipMemcpyAsync(ifault, bI.ptr, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
+    if (liu) CRM_HIP(hipMemcpyAsync(liu, bU.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    bQ.release(); bL.release(); bP.release(); bI.release(); bU.release();
+    return CRM_OK;
+}
+
+}  // extern "C"

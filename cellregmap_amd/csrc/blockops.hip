@@ -1,0 +1,192 @@
+// Streaming helpers around one block of variants: column statistics of G, gathers
+// (permutation hooks idx_E / idx_G of cellregmap/_cellregmap.py:398-413 and the rho*-sorted
+// order the Khatri-Rao contraction consumes), elementwise products feeding the side
+// contractions.  All HBM-bound, coalesced along the variant / column axis.
+#include "nullfit.h"
+
+namespace crm {
+
+namespace {
+
+constexpr int STAT_SPLITS = 64;
+
+// partial[split][q][b]: q = 0 gg, 1 gy, 2.. gW_i.  y and W are columns of one row-major
+// matrix (leading dimension ldw).
+template <int C>
+__global__ __launch_bounds__(256) void variant_stats_kernel(const double* __restrict__ G, long ldg,
+                                                           long cells, int variants,
+                                                           const double* __restrict__ y,
+                                                           const double* __restrict__ W, long ldw,
+                                                           double* __restrict__ partial) {
+    __shared__ double red[4][C + 2][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + tx;
+    const long per = (cells + STAT_SPLITS - 1) / STAT_SPLITS;
+    const long i0 = (long)blockIdx.y * per;
+    const long i1 = i0 + per < cells ? i0 + per : cells;
+    double acc[C + 2];
+#pragma unroll
+    for (int q = 0; q < C + 2; q++) acc[q] = 0.0;
+    if (b < variants) {
+        for (long i = i0 + ty; i < i1; i += 4) {
+            const double g = G[i * ldg + b];
+            acc[0] += g * g;
+            acc[1] += g * y[i * ldw];
+#pragma unroll
+            for (int q = 0; q < C; q++) acc[2 + q] += g * W[i * ldw + q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < C + 2; q++) red[ty][q][tx] = acc[q];
+    __syncthreads();
+    if (ty == 0 && b < variants) {
+#pragma unroll
+        for (int q = 0; q < C + 2; q++) {
+            const double s = ((red[0][q][tx] + red[1][q][tx]) + red[2][q][tx]) + red[3][q][tx];
+            partial[((long)blockIdx.y * (C + 2) + q) * variants + b] = s;
+        }
+    }
+}
+
+__global__ void variant_stats_finish(const double* __restrict__ partial, int variants, int c,
+                                     double* __restrict__ gg, double* __restrict__ gy,
+                                     double* __restrict__ gW, long ld_gW) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= variants) return;
+    for (int q = 0; q < c + 2; q++) {
+        double s = 0.0;
+        for (int k = 0; k < STAT_SPLITS; k++) s += partial[((long)k * (c + 2) + q) * variants + b];
+        if (q == 0) gg[b] = s;
+        else if (q == 1) gy[b] = s;
+        else gW[(long)b * ld_gW + (q - 2)] = s;
+    }
+}
+
+__global__ void gather_block_kernel(const double* __restrict__ src, long ld_src, long cells_pad,
+                                    long cells, const int* __restrict__ row_index,
+                                    const int* __restrict__ col_index, int variants,
+                                    double* __restrict__ dst, long ld_dst, int dst_cols) {
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    const long i = blockIdx.x;
+    if (j >= dst_cols) return;
+    double v = 0.0;
+    if (i < cells && j < variants) {
+        const long si = row_index ? row_index[i] : i;
+        const long sj = col_index ? col_index[j] : j;
+        v = src[si * ld_src + sj];
+    }
+    dst[i * ld_dst + j] = v;
+}
+
+__global__ void square_block_kernel(const double* __restrict__ Gt, const double* __restrict__ G,
+                                    long ldg, long ldg_t, int cols, double* __restrict__ G2,
+                                    double* __restrict__ GG, long ld_out) {
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    const long i = blockIdx.x;
+    if (j >= cols) return;
+    const double t = Gt[i * ldg_t + j];
+    G2[i * ld_out + j] = t * t;
+    if (GG) GG[i * ld_out + j] = t * G[i * ldg + j];
+}
+
+__global__ void context_features_kernel(const double* __restrict__ E, long lde,
+                                        const int* __restrict__ row_index, long cells, int k0,
+                                        const double* __restrict__ y, const double* __restrict__ W,
+                                        long ldw, int c, double* __restrict__ Ep, long ld_ep,
+                                        double* __restrict__ YE, long ld_ye, double* __restrict__ EE,
+                                        long ld_ee) {
+    extern __shared__ double row[];  // k0 entries of the (permuted) context row
+    const long i = blockIdx.x;
+    const bool live = i < cells;
+    const long si = live ? (row_index ? row_index[i] : i) : 0;
+    for (int j = threadIdx.x; j < k0; j += blockDim.x) row[j] = live ? E[si * lde + j] : 0.0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < ld_ep; j += blockDim.x) Ep[i * ld_ep + j] = j < k0 ? row[j] : 0.0;
+    const int nye = k0 * (1 + c);
+    for (int q = threadIdx.x; q < ld_ye; q += blockDim.x) {
+        double v = 0.0;
+        if (q < nye && live) {
+            const int u = q / k0, j = q - u * k0;
+            v = (u == 0 ? y[i * ldw] : W[i * ldw + (u - 1)]) * row[j];
+        }
+        YE[i * ld_ye + q] = v;
+    }
+    // pairs (j, j'), j <= j', row-major over the upper triangle
+    const int npair = k0 * (k0 + 1) / 2;
+    for (int q = threadIdx.x; q < ld_ee; q += blockDim.x) {
+        double v = 0.0;
+        if (q < npair) {
+            // invert q -> (j, j'): rows of the triangle have lengths k0, k0-1, ...
+            int j = 0, rem = q;
+            while (rem >= k0 - j) {
+                rem -= k0 - j;
+                j++;
+            }
+            v = row[j] * row[j + rem];
+        }
+        EE[i * ld_ee + q] = v;
+    }
+}
+
+}  // namespace
+
+int launch_variant_stats(hipStream_t st, const double* G, long ldg, long cells, int variants,
+                         const double* y, const double* W, long ldw, int c, double* partial,
+                         double* gg, double* gy, double* gW, long ld_gW) {
+    if (variants <= 0) return CRM_OK;
+    dim3 grid((variants + 63) / 64, STAT_SPLITS);
+#define CRM_STATS(CC)                                                                          \
+    case CC:                                                                                   \
+        hipLaunchKernelGGL(variant_stats_kernel<CC>, grid, dim3(256), 0, st, G, ldg, cells,    \
+                           variants, y, W, ldw, partial);                                      \
+        break;
+    switch (c) {
+        CRM_STATS(1) CRM_STATS(2) CRM_STATS(3) CRM_STATS(4)
+        CRM_STATS(5) CRM_STATS(6) CRM_STATS(7) CRM_STATS(8)
+        default:
+            set_error("variant statistics: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV);
+            return CRM_ERR_UNSUPPORTED;
+    }
+#undef CRM_STATS
+    CRM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(variant_stats_finish, dim3((variants + 127) / 128), dim3(128), 0, st, partial,
+                       variants, c, gg, gy, gW, ld_gW);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+size_t variant_stats_workspace(int variants, int c) {
+    return sizeof(double) * (size_t)STAT_SPLITS * (c + 2) * variants;
+}
+
+int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
+                        const int* row_index, const int* col_index, int variants, double* dst,
+                        long ld_dst, int dst_cols) {
+    dim3 grid((unsigned)cells_pad, (dst_cols + 255) / 256);
+    hipLaunchKernelGGL(gather_block_kernel, grid, dim3(256), 0, st, src, ld_src, cells_pad, cells,
+                       row_index, col_index, variants, dst, ld_dst, dst_cols);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_square_block(hipStream_t st, const double* Gt, const double* G, long ldg, long ldg_t,
+                        long cells_pad, int cols, double* G2, double* GG, long ld_out) {
+    dim3 grid((unsigned)cells_pad, (cols + 255) / 256);
+    hipLaunchKernelGGL(square_block_kernel, grid, dim3(256), 0, st, Gt, G, ldg, ldg_t, cols, G2, GG,
+                       ld_out);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_context_features(hipStream_t st, const double* E, long lde, const int* row_index,
+                            long cells, long cells_pad, int k0, const double* y, const double* W,
+                            long ldw, int c, double* Ep, long ld_ep, double* YE, long ld_ye,
+                            double* EE, long ld_ee) {
+    hipLaunchKernelGGL(context_features_kernel, dim3((unsigned)cells_pad), dim3(256),
+                       sizeof(double) * k0, st, E, lde, row_index, cells, k0, y, W, ldw, c, Ep, ld_ep,
+                       YE, ld_ye, EE, ld_ee);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+}  // namespace crm

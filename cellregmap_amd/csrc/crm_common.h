@@ -1,0 +1,61 @@
+// Shared declarations for the CellRegMap score-test HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crm_hip.h"
+
+namespace crm {
+
+void set_error(const char* fmt, ...);
+const char* last_error_text();
+
+#define CRM_HIP(call)                                                                 \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            crm::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,              \
+                           hipGetErrorString(e__));                                   \
+            return CRM_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+#define CRM_TRY(call)                    \
+    do {                                 \
+        int rc__ = (call);               \
+        if (rc__ != CRM_OK) return rc__; \
+    } while (0)
+
+inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// ---- contraction kernel (gemm_tn.hip) ------------------------------------------
+// C[z][M x N] = X[z]' * Y[z]  with the contraction over the cell axis (rows of X, Y).
+// Khatri-Rao form: X[i, b*k0 + j] = Gs[i, b] * E[i, j] is formed on the fly.
+struct GemmProblem {
+    const double* X;  // plain: [cells x ldx]; KR: Gs [cells x ldx] (first variant of the group)
+    const double* E;  // KR only: [cells x lde]
+    const double* Y;  // [cells x ldy]
+    double* C;        // [M x ldc]
+    long ldx, lde, ldy, ldc;
+    int M, N;         // logical extents (stores are predicated on them)
+    int k0;           // KR only
+    int pad_;
+};
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 8;
+
+// Launch nz problems (device array `probs`), each over `cells` (multiple of GEMM_BK)
+// rows, optionally split into `ksplit` slices along the cell axis (slice s writes
+// C + s * split_stride; reduce with reduce_splits).
+int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
+                   long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
+int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
+
+}  // namespace crm

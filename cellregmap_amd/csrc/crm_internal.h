@@ -1,0 +1,43 @@
+// Internal object layouts behind the opaque C-ABI handles.
+#pragma once
+#include <utility>
+
+#include "crm_common.h"
+
+namespace crm {
+
+constexpr int CRM_DEFAULT_BLOCK = 1024;  // variants per internal batch
+constexpr int CRM_MAX_RHO = 16;    // rho grid points (the reference uses 1 or 11)
+constexpr int CRM_MAX_COV = 8;    // columns of W the interaction null fit is instantiated for
+constexpr int CRM_MAX_K0 = 128;   // contexts (columns of E0)
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+    template <class T>
+    T* as() const { return static_cast<T*>(ptr); }
+};
+
+int upload_padded(hipStream_t st, double* dst, long ld_dst, long rows_pad, const double* src,
+                  long ld_src, long rows, long cols);
+
+}  // namespace crm
+
+struct crm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int block_variants = crm::CRM_DEFAULT_BLOCK;
+    // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    size_t timed_used = 0;
+    double kr_flops = 0.0;
+    // scan workspace (grown on demand, reused across calls)
+    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext;
+    std::vector<crm::DevBuf*> all_bufs() {
+        return {&ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+    }
+};

@@ -1,0 +1,561 @@
+// Mixture weights and p-value per variant: one wavefront per variant.
+//
+// Reference: chiscore.davies_pvalue(Q, F, True) at cellregmap/_cellregmap.py:333,435
+// -> eigvalsh(F) (lower triangle), SKAT's eigenvalue filter, Davies' AS 155 algorithm
+// (chi2comb, lim = 10000, acc = 1e-6), modified-Liu fall-back.  Same procedure as
+// oracle/davies.py + oracle/qfc.c, re-organised for 64 lanes:
+//   * eigenvalues: cyclic Jacobi in LDS with a round-robin pair schedule (k/2 disjoint
+//     rotations per round; lanes over pairs, then over rows / columns);
+//   * qfc: the scalar search logic (truncation point, cut-offs, step) runs wave-uniform;
+//     every sum over the eigenvalues is lane-parallel + butterfly, and the trapezoid rule
+//     puts one abscissa per lane.
+#include "nullfit.h"
+
+namespace crm {
+
+namespace {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double LN28 = 0.08664339756999316;  // log(2)/8
+constexpr int DAVIES_LIM = 10000;
+constexpr double DAVIES_ACC = 1e-6;
+
+__device__ inline double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline int wsum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline double exp_guard(double x) { return x < -50.0 ? 0.0 : exp(x); }
+
+// log(1+x) when first, else log(1+x) - x; series for small |x| (AS 155 "log1")
+__device__ inline double log1p_variant(double x, bool first) {
+    if (fabs(x) > 0.1) return first ? log(1.0 + x) : (log(1.0 + x) - x);
+    double y = x / (2.0 + x);
+    double term = 2.0 * y * y * y;
+    double k = 3.0;
+    double s = (first ? 2.0 : -x) * y;
+    y = y * y;
+    double s1 = s + term / k;
+    while (s1 != s) {
+        k += 2.0;
+        term *= y;
+        s = s1;
+        s1 = s + term / k;
+    }
+    return s;
+}
+
+// ---- regularised upper incomplete gamma and non-central chi-square survival --------------
+__device__ double igamc(double a, double x) {
+    if (x <= 0.0) return 1.0;
+    const double lg = lgamma(a);
+    if (x < a + 1.0) {
+        // P(a, x) by series
+        double ap = a, sum = 1.0 / a, del = sum;
+        for (int it = 0; it < 2000; it++) {
+            ap += 1.0;
+            del *= x / ap;
+            sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        return 1.0 - sum * exp(-x + a * log(x) - lg);
+    }
+    // continued fraction (modified Lentz)
+    const double tiny = 1e-300;
+    double bq = x + 1.0 - a;
+    double cq = 1.0 / tiny;
+    double dq = 1.0 / bq;
+    double h = dq;
+    for (int i = 1; i < 5000; i++) {
+        const double an = -i * (i - a);
+        bq += 2.0;
+        dq = an * dq + bq;
+        if (fabs(dq) < tiny) dq = tiny;
+        cq = bq + an / cq;
+        if (fabs(cq) < tiny) cq = tiny;
+        dq = 1.0 / dq;
+        const double del = dq * cq;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return exp(-x + a * log(x) - lg) * h;
+}
+
+// P[ ncx2(dof, nc) > x ] as a Poisson mixture of central survival functions
+__device__ double ncx2_sf(double x, double dof, double nc) {
+    if (!(x > 0.0)) return 1.0;
+    const double z = 0.5 * x, lam = 0.5 * nc, a0 = 0.5 * dof;
+    double q = igamc(a0, z);                                // Q(a0 + i, z)
+    double inc = exp(-z + a0 * log(z) - lgamma(a0 + 1.0));  // z^a e^-z / Gamma(a+1)
+    double w = exp(-lam);                                   // Poisson weight
+    double sum = 0.0;
+    for (int i = 0; i < 5000; i++) {
+        const double term = w * q;
+        sum += term;
+        if (i > lam && term <= sum * 1e-17) break;
+        q += inc;
+        inc *= z / (a0 + i + 1.0);
+        w *= lam / (i + 1.0);
+    }
+    return sum < 1.0 ? sum : 1.0;
+}
+
+struct Qf {
+    const double* lb;  // LDS, r positive weights in ascending order
+    int r, lane;
+    double sigsq, lmax, lmin, mean, c;
+    double intl, ersm;
+    int count, lim;
+    bool fail, overflow;
+};
+
+__device__ inline void tick(Qf& q) {
+    q.count++;
+    if (q.count > q.lim) q.overflow = true;
+}
+
+// AS 155 errbd: bound on the tail probability via the mgf (dof 1, no non-centrality)
+__device__ double tail_bound(Qf& q, double u, double& cx) {
+    tick(q);
+    double xconst = u * q.sigsq;
+    double sum1 = u * xconst;
+    u = 2.0 * u;
+    double pc = 0.0, ps = 0.0;
+    for (int j = q.lane; j < q.r; j += 64) {
+        const double lj = q.lb[j];
+        const double x = u * lj, y = 1.0 - x;
+        pc += lj / y;
+        ps += x * x / y + log1p_variant(-x, false);
+    }
+    xconst += wsum(pc);
+    sum1 += wsum(ps);
+    cx = xconst;
+    return exp_guard(-0.5 * sum1);
+}
+
+// AS 155 ctff
+__device__ double cutoff(Qf& q, double accx, double& upn) {
+    double u2 = upn, u1 = 0.0, c1 = q.mean, c2 = 0.0, xconst;
+    const double rb = 2.0 * ((u2 > 0.0) ? q.lmax : q.lmin);
+    double u = u2 / (1.0 + u2 * rb);
+    while (!q.overflow && tail_bound(q, u, c2) > accx) {
+        u1 = u2;
+        c1 = c2;
+        u2 = 2.0 * u2;
+        u = u2 / (1.0 + u2 * rb);
+    }
+    u = (c1 - q.mean) / (c2 - q.mean);
+    while (!q.overflow && u < 0.9) {
+        u = (u1 + u2) / 2.0;
+        if (tail_bound(q, u / (1.0 + u * rb), xconst) > accx) {
+            u1 = u;
+            c1 = xconst;
+        } else {
+            u2 = u;
+            c2 = xconst;
+        }
+        u = (c1 - q.mean) / (c2 - q.mean);
+    }
+    upn = u2;
+    return c2;
+}
+
+// AS 155 truncation
+__device__ double trunc_bound(Qf& q, double u, double tausq) {
+    tick(q);
+    const double sum2 = (q.sigsq + tausq) * u * u;
+    double prod1 = 2.0 * sum2;
+    u = 2.0 * u;
+    double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int s = 0;
+    for (int j = q.lane; j < q.r; j += 64) {
+        const double lj = q.lb[j];
+        const double x = (u * lj) * (u * lj);
+        if (x > 1.0) {
+            p2 += log(x);
+            p3 += log1p_variant(x, true);
+            s += 1;
+        } else {
+            p1 += log1p_variant(x, true);
+        }
+    }
+    prod1 += wsum(p1);
+    double prod2 = wsum(p2), prod3 = wsum(p3);
+    s = wsum_i(s);
+    const double sum1 = 0.0;  // non-centralities are zero on this path
+    prod2 += prod1;
+    prod3 += prod1;
+    double x = exp_guard(-sum1 - 0.25 * prod2) / PI;
+    const double y = exp_guard(-sum1 - 0.25 * prod3) / PI;
+    double err1 = (s == 0) ? 1.0 : x * 2.0 / s;
+    double err2 = (prod3 > 1.0) ? 2.5 * y : 1.0;
+    if (err2 < err1) err1 = err2;
+    x = 0.5 * sum2;
+    err2 = (x <= y) ? 1.0 : y / x;
+    return (err1 < err2) ? err1 : err2;
+}
+
+// AS 155 findu
+__device__ void find_trunc_point(Qf& q, double& utx, double accx) {
+    const double divis[4] = {2.0, 1.4, 1.2, 1.1};
+    double ut = utx, u = ut / 4.0;
+    if (trunc_bound(q, u, 0.0) > accx) {
+        for (u = ut; !q.overflow && trunc_bound(q, u, 0.0) > accx; u = ut) ut *= 4.0;
+    } else {
+        ut = u;
+        for (u = u / 4.0; !q.overflow && trunc_bound(q, u, 0.0) <= accx; u = u / 4.0) ut = u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u = ut / divis[i];
+        if (trunc_bound(q, u, 0.0) <= accx) ut = u;
+    }
+    utx = ut;
+}
+
+// AS 155 integrate: one abscissa per lane
+__device__ void integrate(Qf& q, int nterm, double interv, double tausq, bool mainx) {
+    const double inpi = interv / PI;
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = nterm - q.lane; k >= 0; k -= 64) {
+        const double u = (k + 0.5) * interv;
+        double sum1 = -2.0 * u * q.c;
+        double sum2 = fabs(sum1);
+        double sum3 = -0.5 * q.sigsq * u * u;
+        for (int j = q.r - 1; j >= 0; j--) {
+            const double x = 2.0 * q.lb[j] * u;
+            const double y = x * x;
+            sum3 -= 0.25 * log1p_variant(y, true);
+            const double z = atan(x);
+            sum1 += z;
+            sum2 += fabs(z);
+        }
+        double x = inpi * exp_guard(sum3) / u;
+        if (!mainx) x *= (1.0 - exp_guard(-0.5 * tausq * u * u));
+        a1 += sin(0.5 * sum1) * x;
+        a2 += 0.5 * sum2 * x;
+    }
+    q.intl += wsum(a1);
+    q.ersm += wsum(a2);
+}
+
+// AS 155 cfe.  Weights are positive and ascending, so the |lb|-descending order th[]
+// of the original is simply index r-1-k.
+__device__ double conv_coef(Qf& q, double x) {
+    tick(q);
+    double axl = fabs(x);
+    const double sxl = (x > 0.0) ? 1.0 : -1.0;
+    double sum1 = 0.0;
+    for (int j = q.r - 1; j >= 0; j--) {
+        const int t = q.r - 1 - j;
+        if (q.lb[t] * sxl > 0.0) {
+            const double lj = fabs(q.lb[t]);
+            const double axl1 = axl - lj;
+            const double axl2 = lj / LN28;
+            if (axl1 > axl2) {
+                axl = axl1;
+            } else {
+                if (axl > axl2) axl = axl2;
+                sum1 = (axl - axl1) / lj;
+                sum1 += (double)j;  // one unit per remaining weight
+                break;
+            }
+        }
+    }
+    if (sum1 > 100.0) {
+        q.fail = true;
+        return 1.0;
+    }
+    return pow(2.0, sum1 / 4.0) / (PI * axl * axl);
+}
+
+// P[ sum lb_j chi2_1 < c ];  returns the cdf (or -1 when the search gave up)
+__device__ double qfc_wave(const double* lb, int r, double c, int lane, int& ifault) {
+    Qf q;
+    q.lb = lb; q.r = r; q.lane = lane; q.c = c;
+    q.sigsq = 0.0; q.intl = 0.0; q.ersm = 0.0; q.count = 0; q.lim = DAVIES_LIM;
+    q.fail = false; q.overflow = false;
+    ifault = 0;
+    double acc1 = DAVIES_ACC, xlim = (double)DAVIES_LIM;
+    double sd = 0.0, mean = 0.0;
+    for (int j = lane; j < r; j += 64) {
+        sd += lb[j] * lb[j] * 2.0;
+        mean += lb[j];
+    }
+    sd = wsum(sd);
+    q.mean = wsum(mean);
+    q.lmax = lb[r - 1] > 0.0 ? lb[r - 1] : 0.0;  // ascending order
+    q.lmin = lb[0] < 0.0 ? lb[0] : 0.0;
+    if (sd == 0.0) return (c > 0.0) ? 1.0 : 0.0;
+    if (q.lmin == 0.0 && q.lmax == 0.0) {
+        ifault = 3;
+        return -1.0;
+    }
+    sd = sqrt(sd);
+    const double almx = (q.lmax < -q.lmin) ? -q.lmin : q.lmax;
+    double utx = 16.0 / sd, up = 4.5 / sd, un = -up, tausq, intv = 0.0, xnt = 0.0, xntm;
+    find_trunc_point(q, utx, 0.5 * acc1);
+    if (q.overflow) { ifault = 4; return -1.0; }
+    if (c != 0.0 && almx > 0.07 * sd) {
+        tausq = 0.25 * acc1 / conv_coef(q, c);
+        if (q.fail) {
+            q.fail = false;
+        } else if (trunc_bound(q, utx, tausq) < 0.2 * acc1) {
+            q.sigsq += tausq;
+            find_trunc_point(q, utx, 0.25 * acc1);
+        }
+        if (q.overflow) { ifault = 4; return -1.0; }
+    }
+    acc1 *= 0.5;
+    for (;;) {
+        const double d1 = cutoff(q, acc1, up) - c;
+        if (q.overflow) { ifault = 4; return -1.0; }
+        if (d1 < 0.0) return 1.0;
+        const double d2 = c - cutoff(q, acc1, un);
+        if (q.overflow) { ifault = 4; return -1.0; }
+        if (d2 < 0.0) return 0.0;
+        intv = 2.0 * PI / ((d1 > d2) ? d1 : d2);
+        xnt = utx / intv;
+        xntm = 3.0 / sqrt(acc1);
+        if (xnt <= xntm * 1.5) break;
+        if (xntm > xlim) { ifault = 1; return -1.0; }
+        const int ntm = (int)floor(xntm + 0.5);
+        const double intv1 = utx / ntm;
+        const double x = 2.0 * PI / intv1;
+        if (x <= fabs(c)) break;
+        tausq = 0.33 * acc1 / (1.1 * (conv_coef(q, c - x) + conv_coef(q, c + x)));
+        if (q.overflow) { ifault = 4; return -1.0; }
+        if (q.fail) break;
+        acc1 *= 0.67;
+        integrate(q, ntm, intv1, tausq, false);
+        xlim -= xntm;
+        q.sigsq += tausq;
+        find_trunc_point(q, utx, 0.25 * acc1);
+        if (q.overflow) { ifault = 4; return -1.0; }
+        acc1 *= 0.75;
+    }
+    if (xnt > xlim) { ifault = 1; return -1.0; }
+    const int nt = (int)floor(xnt + 0.5);
+    integrate(q, nt, intv, 0.0, true);
+    const double qfval = 0.5 - q.intl;
+    const double upv = q.ersm, x = upv + DAVIES_ACC / 10.0;
+    const int rats[4] = {1, 2, 4, 8};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (rats[j] * x == rats[j] * upv) ifault = 2;
+    return qfval;
+}
+
+// modified Liu (Lee, Wu & Lin 2012) survival at t for weights lb (dof 1, nc 0)
+__device__ double liu_mod_sf(const double* lb, int r, double t, int lane) {
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0;
+    for (int j = lane; j < r; j += 64) {
+        const double l = lb[j], l2 = l * l;
+        c1 += l;
+        c2 += l2;
+        c3 += l2 * l;
+        c4 += l2 * l2;
+    }
+    c1 = wsum(c1); c2 = wsum(c2); c3 = wsum(c3); c4 = wsum(c4);
+    const double sq = sqrt(c2);
+    const double s1 = c3 / (sq * sq * sq);
+    const double s2 = c4 / (c2 * c2);
+    const double s12 = s1 * s1;
+    double a, delta_x, dof_x;
+    if (s12 > s2) {
+        a = 1.0 / (s1 - sqrt(s12 - s2));
+        delta_x = s1 * a * a * a - a * a;
+        dof_x = a * a - 2.0 * delta_x;
+    } else {
+        delta_x = 0.0;
+        a = 1.0 / sqrt(s2);
+        dof_x = 1.0 / s2;
+    }
+    const double mu_q = c1, sigma_q = sqrt(2.0 * c2);
+    const double mu_x = dof_x + delta_x, sigma_x = sqrt(2.0 * (dof_x + 2.0 * delta_x));
+    const double t_star = (t - mu_q) / sigma_q;
+    const double tfinal = t_star * sigma_x + mu_x;
+    return ncx2_sf(tfinal, dof_x, delta_x > 1e-9 ? delta_x : 1e-9);
+}
+
+// ---- the kernel ------------------------------------------------------------------------------
+// LDS: A [k][ks] (ks = k | 1), ev [k], kept [k], rotation tables
+__global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict__ Fall,
+                                                         const double* __restrict__ Qall, int k,
+                                                         double* __restrict__ lambda_out,
+                                                         double* __restrict__ pv_out,
+                                                         int* __restrict__ ifault_out,
+                                                         double* __restrict__ liu_out, int do_eig) {
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int ks = k | 1;
+    double* A = sm;               // k * ks
+    double* ev = A + (long)k * ks;  // k
+    double* kept = ev + k;        // k
+    double* rc = kept + k;        // k/2+1 cos
+    double* rs = rc + (k / 2 + 1);  // k/2+1 sin
+    int* rp = reinterpret_cast<int*>(rs + (k / 2 + 1));  // pairs p
+    int* rq = rp + (k / 2 + 1);
+
+    bool bad = false;
+    if (do_eig) {
+        const double* __restrict__ F = Fall + (long)b * k * k;
+        for (int e = lane; e < k * k; e += 64) {
+            const int i = e / k, j = e - i * k;
+            const double v = i >= j ? F[(long)i * k + j] : F[(long)j * k + i];  // lower triangle
+            if (!(fabs(v) < INFINITY)) bad = true;
+            A[i * ks + j] = v;
+        }
+        bad = __any(bad);
+        __syncthreads();
+        const int m = k + (k & 1);  // players (a dummy one when k is odd)
+        if (!bad && k > 1) {
+            for (int sweep = 0; sweep < 40; sweep++) {
+                double off = 0.0, dg = 0.0;
+                for (int e = lane; e < k * k; e += 64) {
+                    const int i = e / k, j = e - i * k;
+                    const double v = A[i * ks + j];
+                    if (i == j) dg += v * v; else off += v * v;
+                }
+                off = wsum(off);
+                dg = wsum(dg);
+                if (off <= 1e-33 * (dg + off) || off == 0.0) break;
+                for (int rd = 0; rd < m - 1; rd++) {
+                    // rotation angles, one pair per lane
+                    for (int s = lane; s < m / 2; s += 64) {
+                        int p, qq;
+                        if (s == 0) { p = m - 1; qq = rd; }
+                        else { p = (rd + s) % (m - 1); qq = (rd - s + (m - 1)) % (m - 1); }
+                        double cs = 1.0, sn = 0.0;
+                        if (p < k && qq < k) {
+                            const double apq = A[p * ks + qq];
+                            if (apq != 0.0) {
+                                const double theta = (A[qq * ks + qq] - A[p * ks + p]) / (2.0 * apq);
+                                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                                cs = 1.0 / sqrt(t * t + 1.0);
+                                sn = t * cs;
+                            }
+                        } else {
+                            p = -1;
+                        }
+                        rp[s] = p; rq[s] = qq; rc[s] = cs; rs[s] = sn;
+                    }
+                    __syncthreads();
+                    // A <- A J : lanes over rows
+                    for (int i = lane; i < k; i += 64) {
+                        for (int s = 0; s < m / 2; s++) {
+                            const int p = rp[s], qq = rq[s];
+                            if (p < 0) continue;
+                            const double cs = rc[s], sn = rs[s];
+                            const double aip = A[i * ks + p], aiq = A[i * ks + qq];
+                            A[i * ks + p] = cs * aip - sn * aiq;
+                            A[i * ks + qq] = sn * aip + cs * aiq;
+                        }
+                    }
+                    __syncthreads();
+                    // A <- J' A : lanes over columns
+                    for (int j = lane; j < k; j += 64) {
+                        for (int s = 0; s < m / 2; s++) {
+                            const int p = rp[s], qq = rq[s];
+                            if (p < 0) continue;
+                            const double cs = rc[s], sn = rs[s];
+                            const double apj = A[p * ks + j], aqj = A[qq * ks + j];
+                            A[p * ks + j] = cs * apj - sn * aqj;
+                            A[qq * ks + j] = sn * apj + cs * aqj;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // ascending rank sort of the diagonal
+        for (int i = lane; i < k; i += 64) {
+            const double v = A[i * ks + i];
+            int rank = 0;
+            for (int j = 0; j < k; j++) {
+                const double w = A[j * ks + j];
+                rank += (w < v) || (w == v && j < i);
+            }
+            ev[rank] = v;
+        }
+        __syncthreads();
+        for (int i = lane; i < k; i += 64) lambda_out[(long)b * k + i] = bad ? NAN : ev[i];
+    } else {
+        for (int i = lane; i < k; i += 64) {
+            ev[i] = lambda_out[(long)b * k + i];
+            if (!(fabs(ev[i]) < INFINITY)) bad = true;
+        }
+        bad = __any(bad);
+        __syncthreads();
+    }
+    const double Q = Qall[b];
+    if (bad || !(fabs(Q) < INFINITY)) {
+        if (lane == 0) {
+            pv_out[b] = NAN;
+            if (ifault_out) ifault_out[b] = -1;
+            if (liu_out) liu_out[b] = NAN;
+        }
+        return;
+    }
+    // SKAT Get_Lambda filter: lam > mean(lam[lam >= 0]) / 1e5   (ev ascending)
+    double sp = 0.0;
+    int np = 0;
+    for (int i = lane; i < k; i += 64)
+        if (ev[i] >= 0.0) { sp += ev[i]; np += 1; }
+    sp = wsum(sp);
+    np = wsum_i(np);
+    const double thr = np > 0 ? (sp / np) / 100000.0 : INFINITY;
+    int r = 0;
+    if (lane == 0) {
+        for (int i = 0; i < k; i++)
+            if (ev[i] > thr) kept[r++] = ev[i];
+    }
+    r = __shfl(r, 0, 64);
+    __syncthreads();
+    if (r == 0) {  // "No eigenvalue is bigger than 0": the reference raises here
+        if (lane == 0) {
+            pv_out[b] = NAN;
+            if (ifault_out) ifault_out[b] = -2;
+            if (liu_out) liu_out[b] = NAN;
+        }
+        return;
+    }
+    const double p_liu = liu_mod_sf(kept, r, Q, lane);
+    int ifault = 0;
+    const double cdf = qfc_wave(kept, r, Q, lane, ifault);
+    double p = 1.0 - cdf;
+    if (r == 1) p = p_liu;
+    if (p > 1.0 || p <= 0.0) p = p_liu;
+    if (lane == 0) {
+        pv_out[b] = p;
+        if (ifault_out) ifault_out[b] = ifault;
+        if (liu_out) liu_out[b] = p_liu;
+    }
+}
+
+}  // namespace
+
+int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int count, int k,
+                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig) {
+    if (count <= 0) return CRM_OK;
+    if (k < 1 || k > CRM_MAX_K0) {
+        set_error("eigen/Davies: k0=%d (supported 1..%d)", k, CRM_MAX_K0);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    const int ks = k | 1;
+    size_t lds = sizeof(double) * ((size_t)k * ks + 2 * k + 2 * (k / 2 + 1)) + sizeof(int) * 2 * (k / 2 + 1);
+    lds = (lds + 15) / 16 * 16;
+    hipLaunchKernelGGL(eig_davies_kernel, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
+                       ifault, liu, do_eig ? 1 : 0);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+}  // namespace crm

@@ -1,0 +1,236 @@
+// FP64 MFMA contraction over the cell axis:  C = X' * Y   (gfx950 / CDNA4).
+//
+// Every large product of the score-test path has this one shape -- both operands are
+// row-major [cells x columns] matrices and the sum runs over cells:
+//     T(rho)  = G_block'            * Q0(rho)      (null-fit rotations)
+//     A~      = KR(G_block, E0)'    * Q0(rho*)     (the dominant term, 2*n*r*k0 flop/variant, a10)
+//     side reductions  G'[y o E, W o E],  (G o G)'[E, E (x) E]            (a9, a10)
+// KR(G, E)[i, b*k0 + j] = G[i, b] * E[i, j] (Khatri-Rao columns) is never materialised:
+// the G and E tiles are staged in LDS separately and multiplied while the A fragment of
+// v_mfma_f64_16x16x4_f64 is assembled.
+//
+// Tiling: 128 x 128 output tile per 256-thread workgroup, 4 wavefronts as 2 x 2, each
+// wavefront owns 64 x 64 = 4 x 4 MFMA tiles (16 accumulators of 4 f64 -> 128 registers);
+// cell axis in stages of 8 rows, LDS double-buffered, next stage prefetched into registers
+// while the current one feeds the matrix pipe.  Operand tiles are stored [stage row][column]
+// with a row stride of 144 doubles (= 128 B mod 256 B) so that the four 16-lane groups of a
+// ds_read_b64 fragment read hit disjoint bank halves.
+#include "crm_common.h"
+
+namespace crm {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int LDT = GEMM_BM + 16;  // LDS row stride of a plain operand tile (doubles)
+constexpr int KR_MAX_PREF = 4;      // prefetch registers per thread for the small KR tiles
+
+__host__ __device__ inline int kr_variants_per_tile(int k0) {
+    int nb = GEMM_BM / k0 + 2;
+    return nb > GEMM_BM ? GEMM_BM : nb;
+}
+__host__ __device__ inline int kr_e_stride(int k0) {
+    // smallest stride >= k0 with stride % 32 == 16 (doubles): consecutive rows fall on
+    // opposite halves of the 64 LDS banks
+    int s = (k0 + 15) / 32 * 32 + 16;
+    if (s < k0) s += 32;
+    return s;
+}
+
+template <bool KR>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
+                                                          int mtiles_max, long cells_per_split,
+                                                          long split_stride, int k0) {
+    extern __shared__ __align__(16) double smem[];
+    const GemmProblem P = probs[blockIdx.z];
+    const int mtile = blockIdx.x % mtiles_max;
+    const int ntile = blockIdx.x / mtiles_max;
+    const int m0 = mtile * GEMM_BM;
+    const int n0 = ntile * GEMM_BN;
+    if (m0 >= P.M || n0 >= P.N) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const long cell_begin = (long)blockIdx.y * cells_per_split;
+    const int stages = (int)(cells_per_split / GEMM_BK);
+
+    // ---- LDS carve-up -------------------------------------------------------------
+    const int nb = KR ? kr_variants_per_tile(k0) : 0;
+    const int lde_s = KR ? kr_e_stride(k0) : 0;
+    double* Ys = smem;                                  // [2][BK][LDT]
+    double* Xs = Ys + 2 * GEMM_BK * LDT;                // plain: [2][BK][LDT]
+    double* Gt = Xs;                                    // KR: [2][BK][nb]
+    double* Et = Gt + 2 * GEMM_BK * (KR ? nb : 0);      // KR: [2][BK][lde_s]
+
+    // ---- global -> register prefetch state --------------------------------------------
+    const int ld_row = tid >> 6;        // 0..3 (+4 on the second pass)
+    const int ld_col = (tid & 63) * 2;  // 16-byte pieces
+    v2d ry[2], rx[2];
+    double rg[KR_MAX_PREF], re[KR_MAX_PREF];
+    const int b0 = KR ? (m0 / k0) : 0;
+
+    const double* Yp = P.Y + (cell_begin + ld_row) * P.ldy + n0 + ld_col;
+    const double* Xp = KR ? nullptr : P.X + (cell_begin + ld_row) * P.ldx + m0 + ld_col;
+
+    auto fetch = [&](int s) {
+        const long roff = (long)s * GEMM_BK;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            ry[q] = *reinterpret_cast<const v2d*>(Yp + (roff + 4 * q) * P.ldy);
+            if (!KR) rx[q] = *reinterpret_cast<const v2d*>(Xp + (roff + 4 * q) * P.ldx);
+        }
+        if (KR) {
+#pragma unroll
+            for (int q = 0; q < KR_MAX_PREF; q++) {
+                int e = tid + 256 * q;
+                if (e < GEMM_BK * nb) {
+                    int row = e / nb, col = e - row * nb;
+                    rg[q] = P.X[(cell_begin + roff + row) * P.ldx + b0 + col];
+                }
+                if (e < GEMM_BK * k0) {
+                    int row = e / k0, col = e - row * k0;
+                    re[q] = P.E[(cell_begin + roff + row) * P.lde + col];
+                }
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            *reinterpret_cast<v2d*>(Ys + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = ry[q];
+            if (!KR)
+                *reinterpret_cast<v2d*>(Xs + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = rx[q];
+        }
+        if (KR) {
+#pragma unroll
+            for (int q = 0; q < KR_MAX_PREF; q++) {
+                int e = tid + 256 * q;
+                if (e < GEMM_BK * nb) Gt[buf * GEMM_BK * nb + e] = rg[q];
+                if (e < GEMM_BK * k0) {
+                    int row = e / k0, col = e - row * k0;
+                    Et[(buf * GEMM_BK + row) * lde_s + col] = re[q];
+                }
+            }
+        }
+    };
+
+    // ---- per-lane fragment addressing ----------------------------------------------------
+    int xa[4], xg[4], xe[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        int mloc = wm * 64 + t * 16 + l15;
+        xa[t] = mloc;
+        if (KR) {
+            int m = m0 + mloc;
+            int b = m / k0;
+            int j = m - b * k0;
+            int bl = b - b0;
+            xg[t] = bl < nb ? bl : nb - 1;  // rows past the group's end are never stored
+            xe[t] = j;
+        }
+    }
+    const int yb = wn * 64 + l15;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    for (int s = 0; s < stages; s++) {
+        const int buf = s & 1;
+        if (s + 1 < stages) fetch(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < GEMM_BK / 4; ks++) {
+            const int row = buf * GEMM_BK + ks * 4 + lq;
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                b[t] = Ys[row * LDT + yb + t * 16];
+                if (KR)
+                    a[t] = Gt[row * nb + xg[t]] * Et[row * lde_s + xe[t]];
+                else
+                    a[t] = Xs[row * LDT + xa[t]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < stages) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = lq + 4*reg][col = l15] per 16x16 tile ---------------------------
+    double* Cb = P.C + (long)blockIdx.y * split_stride;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int m = m0 + wm * 64 + i * 16 + lq + 4 * reg;
+            if (m < P.M) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int n = n0 + wn * 64 + j * 16 + l15;
+                    if (n < P.N) Cb[(long)m * P.ldc + n] = acc[i][j][reg];
+                }
+            }
+        }
+    }
+}
+
+__global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksplit, long stride) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = C[i];
+    for (int k = 1; k < ksplit; k++) s += C[i + k * stride];
+    C[i] = s;
+}
+
+int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
+                   long cells, bool khatri_rao, int k0, int ksplit, long split_stride) {
+    if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
+    if (ksplit < 1) ksplit = 1;
+    if (cells % (GEMM_BK * (long)ksplit) != 0) {
+        set_error("contraction: cell count %ld is not a multiple of %d", cells, GEMM_BK * ksplit);
+        return CRM_ERR_ARG;
+    }
+    const int mt = (max_m + GEMM_BM - 1) / GEMM_BM;
+    const int nt = (max_n + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
+    size_t lds = (size_t)2 * GEMM_BK * LDT * sizeof(double);
+    if (khatri_rao) {
+        if (k0 < 1 || k0 > 128) {
+            set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
+            return CRM_ERR_UNSUPPORTED;
+        }
+        lds += (size_t)2 * GEMM_BK * (kr_variants_per_tile(k0) + kr_e_stride(k0)) * sizeof(double);
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), lds, st, probs_dev, mt,
+                           cells / ksplit, split_stride, k0);
+    } else {
+        lds += (size_t)2 * GEMM_BK * LDT * sizeof(double);
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), lds, st, probs_dev, mt,
+                           cells / ksplit, split_stride, 0);
+    }
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride) {
+    if (ksplit <= 1 || count <= 0) return CRM_OK;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                       C, count, ksplit, split_stride);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+}  // namespace crm

@@ -1,0 +1,102 @@
+// Argument records shared by the per-variant kernels and the host orchestration.
+#pragma once
+#include "crm_internal.h"
+
+namespace crm {
+
+// ---- null fits (nullfit.hip) -------------------------------------------------------------
+struct NullFitRho {
+    const double* T;   // [variants x ldT]   rows = Q0(rho)' g
+    const double* ty;  // [r]                Q0(rho)' y
+    const double* tW;  // [c x ldW]          rows = Q0(rho)' W_i
+    const double* S0;  // [r]
+    long ldT, ldW;
+    int r;
+    int pad_;
+};
+
+struct NullFitTrial {  // one (variant, rho) fit
+    double lml, delta, scale;
+    int use_g, nfev;
+};
+
+struct NullFitOut {
+    int rho_index;
+    int use_g;  // 0 when g lies in span(W): X = [W, g] is rank deficient
+    double lml, delta, scale, v0, v1;
+};
+
+struct NullFitArgs {
+    NullFitRho rho[CRM_MAX_RHO];
+    int nrho, c, restricted, pad_;
+    long n;            // cells (unpadded)
+    const double* WW;  // [c x c]
+    const double* Wy;  // [c]
+    double yy;
+    const double* gg;  // [variants]
+    const double* gy;  // [variants]
+    const double* gW;  // [variants x ld_gW]
+    long ld_gW;
+    NullFitTrial* trial;  // [variants x nrho]
+    NullFitOut* out;      // [variants]
+};
+
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants);
+
+// ---- small per-block kernels (blockops.hip) ----------------------------------------------------
+// gg, gy, gW for a block of variants: column reductions of G (cells x ldg), deterministic.
+int launch_variant_stats(hipStream_t st, const double* G, long ldg, long cells, int variants,
+                         const double* y, const double* W, long ldw, int c, double* partial,
+                         double* gg, double* gy, double* gW, long ld_gW);
+size_t variant_stats_workspace(int variants, int c);
+// out[i, b] = src[row(i), col(b)]: optional row permutation (idx_G) and column order (sorted by rho*).
+int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
+                        const int* row_index, const int* col_index, int variants, double* dst,
+                        long ld_dst, int dst_cols);
+// G2 = Gt o Gt, GG = Gt o G
+int launch_square_block(hipStream_t st, const double* Gt, const double* G, long ldg, long ldg_t,
+                        long cells_pad, int cols, double* G2, double* GG, long ld_out);
+// rows of E permuted; YE = [y o E, W_1 o E, ...]; EE = pairwise products E_j E_j' (j <= j')
+int launch_context_features(hipStream_t st, const double* E, long lde, const int* row_index,
+                            long cells, long cells_pad, int k0, const double* y, const double* W,
+                            long ldw, int c, double* Ep, long ld_ep, double* YE, long ld_ye,
+                            double* EE, long ld_ee);
+
+// ---- score statistic assembly (assemble.hip) ------------------------------------------------------
+struct AssembleRho {
+    const double* ty;
+    const double* tW;
+    const double* S0;
+    const double* T;  // [variants x ldT] in block order
+    long ldW, ldT;
+    int r;
+    int pad_;
+};
+
+struct AssembleArgs {
+    AssembleRho rho[CRM_MAX_RHO];
+    const NullFitOut* fit;    // [variants] block order
+    const int* sorted_pos;    // [variants] position of variant b inside the rho*-sorted A~ buffer
+    const double* A;          // [variants*k0 x ldA]  rows (pos*k0 + j) = Q0(rho*)' (gtest o E_j)
+    long ldA;
+    int k0, c;
+    long n;
+    // n-length reductions, block order
+    const double* Z1; long ldZ1;   // [variants x k0*(1+c)]  E' (gt o y), E' (gt o W_i)
+    const double* Z2; long ldZ2;   // [variants x k0]        E' (gt o g)
+    const double* Z3; long ldZ3;   // [variants x k0(k0+1)/2] E' diag(gt^2) E (upper, row-major pairs)
+    const double* WW; const double* Wy; double yy;
+    const double* gg; const double* gy; const double* gW; long ld_gW;
+    double* Q;   // [variants]
+    double* F;   // [variants x k0 x k0]
+};
+
+// Gext: workspace [variants x (k0+c+2)^2]
+int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext);
+
+// ---- eigenvalues + Davies / Liu (davies.hip) -----------------------------------------------------
+// lambda: ascending eigenvalues of the lower triangle of F (count x k x k); pvalue per SKAT rule.
+int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int count, int k,
+                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig);
+
+}  // namespace crm

@@ -1,0 +1,408 @@
+// Batched null-model fits of the interaction scan.
+//
+// Reference: for every variant, `for rho1 in self._rho1: LMM(y, [W, g], QS[rho1],
+// restricted=True).fit(); keep the first strictly larger lml`
+// (cellregmap/_cellregmap.py:345-357), then rho1 / e2 / g2 / eps2 (:366-369).
+//
+// One wavefront per (variant, rho grid point).  A wavefront holds the
+// rotated vectors t_u = Q0(rho)' u  (u in {W columns, g, y}) only as streams from L2:
+// each likelihood evaluation is one pass over the r spectrum entries with lanes striding
+// j, accumulating  sum_j t_u[j] t_v[j] / ((1-d) S0[j] + d)  for all pairs and
+// sum_j log((1-d) S0[j] + d), followed by a 64-lane butterfly so that every lane holds
+// bitwise identical totals.  The scalar logic on top of the totals -- closed-form beta
+// and scale, REML log-likelihood, and the bracket + Brent search over x = logit(d) with
+// rtol = atol = 1e-6 -- is executed redundantly by all lanes (wave-uniform control flow)
+// and follows oracle/brent.py statement by statement.
+#include "crm_internal.h"
+#include "nullfit.h"
+
+namespace crm {
+
+namespace {
+
+constexpr double LOG2PI = 1.8378770664093453;
+constexpr double EPS_TINY = 2.220446049250313e-16;    // numpy_sugar.epsilon.tiny
+constexpr double EPS_SMALL = 1.4901161193847656e-08;  // numpy_sugar.epsilon.small
+constexpr double LOGMAX = 709.782712893384;           // log(finfo.max)
+constexpr double GOLDEN = 0.381966011250105097;
+constexpr int MAXITER = 500;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline double logistic_clamped(double x) {
+    double v;
+    if (x > 0.0) {
+        v = 1.0 / (1.0 + exp(-x));
+    } else {
+        v = exp(x);
+        v = v / (v + 1.0);
+    }
+    return fmin(fmax(v, EPS_TINY), 1.0 - EPS_TINY);
+}
+
+__host__ __device__ constexpr int pair_index(int u, int v, int U) {
+    // u <= v, row-major upper triangle
+    return u * U - u * (u - 1) / 2 + (v - u);
+}
+
+// In-place Cholesky of the leading P x P block; returns false on a non-positive pivot.
+template <int P>
+__device__ inline bool cholesky(double (&A)[P][P], double& logdet) {
+    logdet = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+        if (!(d > 0.0)) return false;
+        const double l = sqrt(d);
+        A[j][j] = l;
+        logdet += 2.0 * log(l);
+#pragma unroll
+        for (int i = j + 1; i < P; i++) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s / l;
+        }
+    }
+    return true;
+}
+
+template <int P>
+__device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i][k] * b[k];
+        b[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < P; k++) s -= L[k][i] * b[k];
+        b[i] = s / L[i][i];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
+    constexpr int P = C + 1;  // columns of X = [W, g]
+    constexpr int U = C + 2;  // ... plus y
+    constexpr int NP = U * (U + 1) / 2;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int w = blockIdx.y;  // rho index
+    const NullFitRho R = a.rho[w];
+    const double* __restrict__ tg = R.T + (long)b * R.ldT;
+    const int r = R.r;
+    const double n = (double)a.n;
+
+    // plain inner products u'v:  W'W, W'y, y'y per gene; W'g, g'g, g'y per variant
+    double uv[NP];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+#pragma unroll
+        for (int j = i; j < C; j++) uv[pair_index(i, j, U)] = a.WW[i * C + j];
+        uv[pair_index(i, C, U)] = a.gW[(long)b * a.ld_gW + i];
+        uv[pair_index(i, C + 1, U)] = a.Wy[i];
+    }
+    uv[pair_index(C, C, U)] = a.gg[b];
+    uv[pair_index(C, C + 1, U)] = a.gy[b];
+    uv[pair_index(C + 1, C + 1, U)] = a.yy;
+
+    // Is g (numerically) inside span(W)?  Then X = [W, g] has rank C and the reference's
+    // SVD-reduced covariates drop that direction (glimix-core LMM; lstsq in PMat).
+    bool use_g = true;
+    double logdetXX = 0.0;
+    {
+        double A[P][P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) A[i][j] = uv[pair_index(j, i, U)];
+        // Cholesky with the last pivot inspected by hand
+        double ld = 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            double d = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+            if (j == P - 1) {
+                if (!(d > 1e-12 * A[j][j])) {
+                    use_g = false;
+                    break;
+                }
+            } else if (!(d > 0.0)) {
+                ok = false;
+                break;
+            }
+            const double l = sqrt(d);
+            A[j][j] = l;
+            ld += 2.0 * log(l);
+#pragma unroll
+            for (int i = j + 1; i < P; i++) {
+                double s = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+                A[i][j] = s / l;
+            }
+        }
+        logdetXX = ok ? ld : NAN;
+    }
+    const double p_eff = use_g ? (double)P : (double)C;
+    const double df = a.restricted ? n - p_eff : n;
+
+    // one pass over the spectrum: weighted pair sums (+ log-determinant part)
+    auto spectrum_pass = [&](double delta, bool weighted, double (&S)[NP], double& lsum) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) S[i] = 0.0;
+        lsum = 0.0;
+        const double omd = 1.0 - delta;
+        for (int j = lane; j < r; j += 64) {
+            double t[U];
+#pragma unroll
+            for (int i = 0; i < C; i++) t[i] = R.tW[(long)i * R.ldW + j];
+            t[C] = tg[j];
+            t[C + 1] = R.ty[j];
+            double wgt = 1.0;
+            if (weighted) {
+                const double D = omd * R.S0[j] + delta;
+                wgt = 1.0 / D;
+                lsum += log(D);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double tw = t[u] * wgt;
+#pragma unroll
+                for (int v = u; v < U; v++) S[pair_index(u, v, U)] += tw * t[v];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) S[i] = wave_sum(S[i]);
+        if (weighted) lsum = wave_sum(lsum);
+    };
+
+    double tt[NP];  // t_u' t_v (complement correction)
+    {
+        double dummy;
+        spectrum_pass(1.0, false, tt, dummy);
+    }
+
+    double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
+    int nfev = 0;
+    // f(x) = -lml at d = logistic(x), with beta and scale profiled out
+    auto f = [&](double x) -> double {
+        nfev++;
+        const double delta = logistic_clamped(x);
+        double S[NP], lsum;
+        spectrum_pass(delta, true, S, lsum);
+        const double inv_d = 1.0 / delta;
+        double K[NP];  // u' Kt^-1 v
+#pragma unroll
+        for (int i = 0; i < NP; i++) K[i] = S[i] + (uv[i] - tt[i]) * inv_d;
+        const double logdetK = lsum + (n - (double)r) * log(delta);
+        double A[P][P], rhs[P], xky[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) A[i][j] = K[pair_index(j, i, U)];
+            rhs[i] = K[pair_index(i, C + 1, U)];
+        }
+        if (!use_g) {
+#pragma unroll
+            for (int j = 0; j < C; j++) A[C][j] = 0.0;
+            A[C][C] = 1.0;
+            rhs[C] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) xky[i] = rhs[i];
+        double logdetH;
+        double val;
+        if (!cholesky<P>(A, logdetH)) {
+            cur_delta = delta;
+            cur_scale = NAN;
+            cur_lml = NAN;
+            return INFINITY;
+        }
+        cholesky_solve<P>(A, rhs);  // rhs <- beta
+        double rss = K[pair_index(C + 1, C + 1, U)];
+#pragma unroll
+        for (int i = 0; i < P; i++) rss -= xky[i] * rhs[i];
+        const double s = fmax(rss / df, EPS_SMALL);
+        val = -0.5 * (df * LOG2PI + df + n * log(s) + logdetK);
+        if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log(s)));
+        cur_delta = delta;
+        cur_scale = s;
+        cur_lml = val;
+        return -val;
+    };
+
+    {
+        // ---- bracket (oracle/brent.py: bracket) ------------------------------------------
+        double lo = -LOGMAX, hi = LOGMAX;
+        double x0 = 0.0, x1 = 1.0;
+        double f0 = f(x0), f1 = f(x1);
+        if (f1 > f0) {
+            double t = x0; x0 = x1; x1 = t;
+            t = f0; f0 = f1; f1 = t;
+        }
+        double bl, bm, bh, fm;
+        bool bracketed = false;
+        for (int it = 0; it < MAXITER; it++) {
+            double x2 = x1 + 2.0 * (x1 - x0);
+            x2 = fmin(fmax(x2, lo), hi);
+            if (x2 == x1) break;
+            const double f2 = f(x2);
+            if (f2 > f1) {
+                bl = x0 < x2 ? x0 : x2;
+                bh = x0 < x2 ? x2 : x0;
+                bm = x1;
+                fm = f1;
+                bracketed = true;
+                break;
+            }
+            x0 = x1; f0 = f1;
+            x1 = x2; f1 = f2;
+        }
+        if (!bracketed) {
+            bl = x0 < x1 ? x0 : x1;
+            bh = x0 < x1 ? x1 : x0;
+            bm = x1;
+            fm = f1;
+        }
+        // ---- Brent localmin (oracle/brent.py: localmin), rtol = atol = 1e-6 ---------------
+        const double rtol = 1e-6, atol = 1e-6;
+        double A_ = bl, B_ = bh;
+        double bx0 = bm, bf0 = fm;
+        double bx1 = bx0, bx2 = bx0, bf1 = bf0, bf2 = bf0;
+        double d = 0.0, e = 0.0;
+        for (int it = 0; it < MAXITER; it++) {
+            const double m = 0.5 * (A_ + B_);
+            const double tol = rtol * fabs(bx0) + atol;
+            const double tol2 = 2.0 * tol;
+            if (fabs(bx0 - m) <= tol2 - 0.5 * (B_ - A_)) break;
+            double p = 0.0, q = 0.0, rr = 0.0;
+            if (tol < fabs(e)) {
+                rr = (bx0 - bx1) * (bf0 - bf2);
+                q = (bx0 - bx2) * (bf0 - bf1);
+                p = (bx0 - bx2) * q - (bx0 - bx1) * rr;
+                q = 2.0 * (q - rr);
+                if (0.0 < q) p = -p;
+                q = fabs(q);
+                rr = e;
+                e = d;
+            }
+            double u;
+            if (fabs(p) < fabs(0.5 * q * rr) && q * (A_ - bx0) < p && p < q * (B_ - bx0)) {
+                d = p / q;
+                u = bx0 + d;
+                if ((u - A_) < tol2 || (B_ - u) < tol2) d = bx0 < m ? tol : -tol;
+            } else {
+                e = bx0 < m ? B_ - bx0 : A_ - bx0;
+                d = GOLDEN * e;
+            }
+            if (tol <= fabs(d)) u = bx0 + d;
+            else if (0.0 < d) u = bx0 + tol;
+            else u = bx0 - tol;
+            const double fu = f(u);
+            if (fu <= bf0) {
+                if (u < bx0) B_ = bx0; else A_ = bx0;
+                bx2 = bx1; bf2 = bf1;
+                bx1 = bx0; bf1 = bf0;
+                bx0 = u; bf0 = fu;
+            } else {
+                if (u < bx0) A_ = u; else B_ = u;
+                if (fu <= bf1 || bx1 == bx0) {
+                    bx2 = bx1; bf2 = bf1;
+                    bx1 = u; bf1 = fu;
+                } else if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
+                    bx2 = u; bf2 = fu;
+                }
+            }
+        }
+        (void)f(bx0);  // LMM.fit(): beta and scale refreshed at the optimum
+        if (lane == 0) {
+            NullFitTrial t;
+            t.lml = cur_lml;
+            t.delta = cur_delta;
+            t.scale = cur_scale;
+            t.use_g = use_g ? 1 : 0;
+            t.nfev = nfev;
+            a.trial[(long)b * a.nrho + w] = t;
+        }
+    }
+}
+
+// rho* = first strictly larger lml over the grid (_cellregmap.py:354-357)
+__global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nrho, int variants,
+                                  NullFitOut* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= variants) return;
+    double best = -INFINITY;
+    int bi = -1;
+    for (int i = 0; i < nrho; i++) {
+        const double v = trial[(long)b * nrho + i].lml;
+        if (v > best) {
+            best = v;
+            bi = i;
+        }
+    }
+    NullFitOut o;
+    o.use_g = trial[(long)b * nrho].use_g;
+    if (bi < 0) {
+        o.rho_index = 0;
+        o.lml = NAN; o.delta = NAN; o.scale = NAN; o.v0 = NAN; o.v1 = NAN;
+    } else {
+        const NullFitTrial t = trial[(long)b * nrho + bi];
+        o.rho_index = bi;
+        o.lml = best;
+        o.delta = t.delta;
+        o.scale = t.scale;
+        o.v0 = t.scale * (1.0 - t.delta);
+        o.v1 = t.scale * t.delta;
+    }
+    out[b] = o;
+}
+
+}  // namespace
+
+template <int C>
+static void launch_c(hipStream_t st, const NullFitArgs& a, int variants) {
+    hipLaunchKernelGGL(nullfit_kernel<C>, dim3(variants, a.nrho), dim3(64), 0, st, a);
+}
+
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants) {
+    if (variants <= 0) return CRM_OK;
+    if (a.nrho < 1 || a.nrho > CRM_MAX_RHO) {
+        set_error("null fit: %d grid points (supported 1..%d)", a.nrho, CRM_MAX_RHO);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    switch (a.c) {
+        case 1: launch_c<1>(st, a, variants); break;
+        case 2: launch_c<2>(st, a, variants); break;
+        case 3: launch_c<3>(st, a, variants); break;
+        case 4: launch_c<4>(st, a, variants); break;
+        case 5: launch_c<5>(st, a, variants); break;
+        case 6: launch_c<6>(st, a, variants); break;
+        case 7: launch_c<7>(st, a, variants); break;
+        case 8: launch_c<8>(st, a, variants); break;
+        default:
+            set_error("null fit: %d covariate columns (supported 1..%d)", a.c, CRM_MAX_COV);
+            return CRM_ERR_UNSUPPORTED;
+    }
+    CRM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(select_rho_kernel, dim3((variants + 127) / 128), dim3(128), 0, st, a.trial, a.nrho,
+                       variants, a.out);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+}  // namespace crm

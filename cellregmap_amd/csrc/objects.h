@@ -1,0 +1,42 @@
+// Device-resident objects behind the opaque handles of include/crm_hip.h.
+#pragma once
+#include <cmath>
+
+#include "crm_internal.h"
+
+namespace crm {
+constexpr long CELL_PAD = 128;  // cell axis padded (zero rows) to a multiple of this
+}
+
+// Sigma(rho) = Q0 diag(S0) Q0' for every grid point (cellregmap/_cellregmap.py:95-131).
+struct crm_background {
+    crm_ctx* ctx = nullptr;
+    long n = 0, n_pad = 0;
+    int nrho = 0;
+    double rho[crm::CRM_MAX_RHO] = {0};
+    int r[crm::CRM_MAX_RHO] = {0};
+    long ldq = 0;                        // common leading dimension (multiple of 128)
+    crm::DevBuf Q0[crm::CRM_MAX_RHO];    // [n_pad x ldq], zero padded
+    crm::DevBuf S0[crm::CRM_MAX_RHO];    // [ldq]
+};
+
+// One phenotype: y, W, E0 and what only depends on them.
+struct crm_gene {
+    crm_background* bg = nullptr;
+    int c = 0, k0 = 0;
+    long ld_yw = 0, ldw = 0, lde = 0;
+    crm::DevBuf yW;   // [n_pad x ld_yw]: column 0 = y, columns 1..c = W
+    crm::DevBuf E0;   // [n_pad x lde]
+    crm::DevBuf WW, Wy;
+    double yy = 0.0;
+    crm::DevBuf rot;  // [nrho][(1+c) x ldq]: rows Q0(rho)'y, Q0(rho)'W_i
+    // features of the (possibly row-permuted) contexts, rebuilt per scan call
+    crm::DevBuf Ep, YE, EE, idx;
+    long ld_ep = 0, ld_ye = 0, ld_ee = 0;
+};
+
+struct crm_panel {
+    crm_ctx* ctx = nullptr;
+    long n = 0, n_pad = 0, p = 0, ld = 0;
+    crm::DevBuf G;  // [n_pad x ld]
+};

@@ -1,0 +1,490 @@
+// Host orchestration of the interaction scan behind the C-ABI: device-resident background,
+// gene and genotype-panel objects, and the per-block kernel pipeline
+//   stats -> T(rho) = G' Q0(rho) -> null fits + rho* -> sort by rho* -> Khatri-Rao contraction
+//   -> side contractions -> assemble (Q, F) -> eigenvalues + Davies.
+// Reference loop being replaced: cellregmap/_cellregmap.py:340-436.
+#include <algorithm>
+
+#include "nullfit.h"
+#include "objects.h"
+
+using namespace crm;
+
+namespace crm {
+
+static int pick_split(long cells_pad, long blocks_without_split) {
+    // enough workgroups to cover the 256 CUs twice, within what the padded cell count allows
+    int s = 1;
+    while (s < 16 && blocks_without_split * s < 512 && cells_pad % (GEMM_BK * (long)s * 2) == 0) s *= 2;
+    return s;
+}
+
+}  // namespace crm
+
+extern "C" {
+
+// ---- background ---------------------------------------------------------------------------
+int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, const int* r,
+                             const double* const* Q0, const double* const* S0,
+                             crm_background** out) {
+    if (!ctx || !out || n <= 0 || nrho < 1 || !rho || !r || !Q0 || !S0) return CRM_ERR_ARG;
+    if (nrho > CRM_MAX_RHO) {
+        set_error("background: %d grid points (supported up to %d)", nrho, CRM_MAX_RHO);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    *out = nullptr;
+    CRM_HIP(hipSetDevice(ctx->device));
+    crm_background* bg = new crm_background();
+    bg->ctx = ctx;
+    bg->n = n;
+    bg->n_pad = round_up(n, CELL_PAD);
+    bg->nrho = nrho;
+    long rmax = 1;
+    for (int i = 0; i < nrho; i++) {
+        if (r[i] < 0) { delete bg; return CRM_ERR_ARG; }
+        bg->rho[i] = rho[i];
+        bg->r[i] = r[i];
+        rmax = std::max<long>(rmax, r[i]);
+    }
+    bg->ldq = round_up(rmax, 128);
+    for (int i = 0; i < nrho; i++) {
+        int rc = bg->Q0[i].ensure(sizeof(double) * bg->n_pad * bg->ldq);
+        if (rc == CRM_OK) rc = bg->S0[i].ensure(sizeof(double) * bg->ldq);
+        if (rc == CRM_OK)
+            rc = upload_padded(ctx->stream, bg->Q0[i].as<double>(), bg->ldq, bg->n_pad, Q0[i], r[i], n, r[i]);
+        if (rc == CRM_OK)
+            rc = upload_padded(ctx->stream, bg->S0[i].as<double>(), bg->ldq, 1, S0[i], r[i], 1, r[i]);
+        if (rc != CRM_OK) { crm_background_destroy(bg); return rc; }
+    }
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = bg;
+    return CRM_OK;
+}
+
+void crm_background_destroy(crm_background* bg) {
+    if (!bg) return;
+    (void)hipSetDevice(bg->ctx->device);
+    (void)hipStreamSynchronize(bg->ctx->stream);
+    for (int i = 0; i < CRM_MAX_RHO; i++) {
+        bg->Q0[i].release();
+        bg->S0[i].release();
+    }
+    delete bg;
+}
+
+int crm_background_rank(const crm_background* bg, int i) {
+    if (!bg || i < 0 || i >= bg->nrho) return -1;
+    return bg->r[i];
+}
+
+int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0) {
+    if (!bg || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(bg->ctx->device));
+    const int r = bg->r[i];
+    if (Q0 && r > 0)
+        CRM_HIP(hipMemcpy2D(Q0, r * sizeof(double), bg->Q0[i].ptr, bg->ldq * sizeof(double),
+                            r * sizeof(double), bg->n, hipMemcpyDeviceToHost));
+    if (S0 && r > 0) CRM_HIP(hipMemcpy(S0, bg->S0[i].ptr, r * sizeof(double), hipMemcpyDeviceToHost));
+    return CRM_OK;
+}
+
+// ---- gene -----------------------------------------------------------------------------------
+int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
+                    int k0, crm_gene** out) {
+    if (!bg || !y || !W || !E0 || !out) return CRM_ERR_ARG;
+    *out = nullptr;
+    if (c < 1 || c > CRM_MAX_COV) {
+        set_error("gene: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    if (k0 < 1 || k0 > CRM_MAX_K0) {
+        set_error("gene: %d contexts (supported 1..%d)", k0, CRM_MAX_K0);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    crm_ctx* ctx = bg->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    const long n = bg->n, np = bg->n_pad;
+    for (long i = 0; i < n; i++) {
+        bool fin = std::isfinite(y[i]);
+        for (int j = 0; j < c && fin; j++) fin = std::isfinite(W[i * c + j]);
+        if (!fin) {
+            set_error("gene: non-finite values in the outcome or the covariates");
+            return CRM_ERR_NUMERIC;
+        }
+    }
+    crm_gene* g = new crm_gene();
+    g->bg = bg;
+    g->c = c;
+    g->k0 = k0;
+    g->ldw = 16;
+    g->lde = round_up(k0, 16);
+    int rc = CRM_OK;
+    auto fail = [&](int code) { crm_gene_destroy(g); return code; };
+    // [y | W] packed as one operand (column 0 = y) for the rotations, plus separate views
+    const long ldyw = 128;
+    if ((rc = g->yW.ensure(sizeof(double) * np * ldyw)) != CRM_OK) return fail(rc);
+    if ((rc = g->E0.ensure(sizeof(double) * np * g->lde)) != CRM_OK) return fail(rc);
+    {
+        std::vector<double> pack((size_t)n * (1 + c));
+        for (long i = 0; i < n; i++) {
+            pack[i * (1 + c)] = y[i];
+            for (int j = 0; j < c; j++) pack[i * (1 + c) + 1 + j] = W[i * c + j];
+        }
+        if ((rc = upload_padded(ctx->stream, g->yW.as<double>(), ldyw, np, pack.data(), 1 + c, n, 1 + c)) != CRM_OK)
+            return fail(rc);
+        CRM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    g->ld_yw = ldyw;
+    if ((rc = upload_padded(ctx->stream, g->E0.as<double>(), g->lde, np, E0, k0, n, k0)) != CRM_OK) return fail(rc);
+    // host-side inner products
+    g->yy = 0.0;
+    std::vector<double> WW((size_t)c * c, 0.0), Wy(c, 0.0);
+    for (long i = 0; i < n; i++) {
+        g->yy += y[i] * y[i];
+        for (int a = 0; a < c; a++) {
+            Wy[a] += W[i * c + a] * y[i];
+            for (int b = a; b < c; b++) WW[a * c + b] += W[i * c + a] * W[i * c + b];
+        }
+    }
+    for (int a = 0; a < c; a++)
+        for (int b = 0; b < a; b++) WW[a * c + b] = WW[b * c + a];
+    if ((rc = g->WW.ensure(sizeof(double) * c * c)) != CRM_OK) return fail(rc);
+    if ((rc = g->Wy.ensure(sizeof(double) * c)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipMemcpyAsync(g->WW.ptr, WW.data(), sizeof(double) * c * c, hipMemcpyHostToDevice, ctx->stream));
+    CRM_HIP(hipMemcpyAsync(g->Wy.ptr, Wy.data(), sizeof(double) * c, hipMemcpyHostToDevice, ctx->stream));
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    // rotations t = Q0(rho)' [y, W] for every grid point: rows of a [(1+c) x ldq] matrix
+    const int nrho = bg->nrho;
+    const long ldq = bg->ldq;
+    const int ks = pick_split(np, (ldq / GEMM_BN) * nrho);
+    const long slab = (long)(1 + c) * ldq;
+    if ((rc = g->rot.ensure(sizeof(double) * slab * nrho * ks)) != CRM_OK) return fail(rc);
+    std::vector<GemmProblem> probs(nrho);
+    for (int i = 0; i < nrho; i++) {
+        GemmProblem p{};
+        p.X = g->yW.as<double>(); p.ldx = ldyw;
+        p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+        p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
+        p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+        probs[i] = p;
+    }
+    if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * CRM_MAX_RHO)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, ctx->stream));
+    // splits write slabs nrho*slab apart
+    CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho * ks, ctx->stream));
+    if ((rc = launch_gemm_tn(ctx->stream, ctx->ws_probs.as<GemmProblem>(), nrho, 1 + c, (int)ldq, np, false, 0, ks, slab * nrho)) != CRM_OK) return fail(rc);
+    if ((rc = launch_reduce_splits(ctx->stream, g->rot.as<double>(), slab * nrho, ks, slab * nrho)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = g;
+    return CRM_OK;
+}
+
+void crm_gene_destroy(crm_gene* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->bg->ctx->device);
+    (void)hipStreamSynchronize(g->bg->ctx->stream);
+    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx}) b->release();
+    delete g;
+}
+
+// ---- panel ----------------------------------------------------------------------------------
+int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out) {
+    if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
+    *out = nullptr;
+    CRM_HIP(hipSetDevice(ctx->device));
+    crm_panel* P = new crm_panel();
+    P->ctx = ctx;
+    P->n = n;
+    P->n_pad = round_up(n, CELL_PAD);
+    P->p = p;
+    P->ld = round_up(p, 128);
+    int rc = P->G.ensure(sizeof(double) * P->n_pad * P->ld);
+    if (rc == CRM_OK) rc = upload_padded(ctx->stream, P->G.as<double>(), P->ld, P->n_pad, G, ldg, n, p);
+    if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = P;
+    return CRM_OK;
+}
+
+void crm_panel_destroy(crm_panel* P) {
+    if (!P) return;
+    (void)hipSetDevice(P->ctx->device);
+    (void)hipStreamSynchronize(P->ctx->stream);
+    P->G.release();
+    delete P;
+}
+
+// ---- the scan ---------------------------------------------------------------------------------
+int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
+                         const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
+                         double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
+                         double* out_delta, double* out_scale, double* out_lambda, double* out_F) {
+    if (!gene || !panel) return CRM_ERR_ARG;
+    crm_background* bg = gene->bg;
+    crm_ctx* ctx = bg->ctx;
+    if (panel->ctx != ctx) {
+        set_error("scan: gene and panel live on different contexts");
+        return CRM_ERR_ARG;
+    }
+    if (panel->n != bg->n) {
+        set_error("scan: panel has %ld cells, background has %ld", panel->n, bg->n);
+        return CRM_ERR_ARG;
+    }
+    if (first < 0 || count < 0 || first + count > panel->p) {
+        set_error("scan: variants [%ld, %ld) outside the panel (p = %ld)", first, first + count, panel->p);
+        return CRM_ERR_ARG;
+    }
+    if (count == 0) return CRM_OK;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
+    const int nrho = bg->nrho, c = gene->c, k0 = gene->k0;
+    for (long i = 0; i < n; i++) {
+        if ((idx_E && (idx_E[i] < 0 || idx_E[i] >= n)) || (idx_G && (idx_G[i] < 0 || idx_G[i] >= n))) {
+            set_error("scan: permutation index out of range at position %ld", i);
+            return CRM_ERR_ARG;
+        }
+    }
+    const int BLK = (int)std::min<long>(ctx->block_variants, round_up(count, 128));
+    const long ldb = BLK + 128;  // slack columns for the Khatri-Rao tile over-read
+    const long ldA = ldq;
+    const long ldT = ldq;
+    const int npair = k0 * (k0 + 1) / 2;
+    const long ldZ1 = round_up((long)k0 * (1 + c), 128), ldZ2 = round_up(k0, 128), ldZ3 = round_up(npair, 128);
+    const int KT = k0 + c + 2;
+
+    // ---- context features for this permutation ------------------------------------------------
+    gene->ld_ep = round_up(k0, 128);
+    gene->ld_ye = ldZ1;
+    gene->ld_ee = ldZ3;
+    CRM_TRY(gene->Ep.ensure(sizeof(double) * np * gene->ld_ep));
+    CRM_TRY(gene->YE.ensure(sizeof(double) * np * gene->ld_ye));
+    CRM_TRY(gene->EE.ensure(sizeof(double) * np * gene->ld_ee));
+    CRM_TRY(gene->idx.ensure(sizeof(int) * 2 * n));
+    int* d_idxE = nullptr;
+    int* d_idxG = nullptr;
+    if (idx_E) {
+        d_idxE = gene->idx.as<int>();
+        CRM_HIP(hipMemcpyAsync(d_idxE, idx_E, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    }
+    if (idx_G) {
+        d_idxG = gene->idx.as<int>() + n;
+        CRM_HIP(hipMemcpyAsync(d_idxG, idx_G, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    }
+    const double* d_y = gene->yW.as<double>();          // column 0, ld ld_yw
+    const double* d_W = gene->yW.as<double>() + 1;      // columns 1..c
+    CRM_TRY(launch_context_features(st, gene->E0.as<double>(), gene->lde, d_idxE, n, np, k0, d_y, d_W,
+                                    gene->ld_yw, c, gene->Ep.as<double>(), gene->ld_ep,
+                                    gene->YE.as<double>(), gene->ld_ye, gene->EE.as<double>(),
+                                    gene->ld_ee));
+    // y with unit stride for the stats kernel: it reads y[i], W[i*ldw + q] -> pass strided views
+    // (the kernel takes explicit leading dimensions)
+
+    // ---- workspaces ----------------------------------------------------------------------------
+    CRM_TRY(ctx->ws_T.ensure(sizeof(double) * (size_t)nrho * BLK * ldT));
+    CRM_TRY(ctx->ws_A.ensure(sizeof(double) * (size_t)BLK * k0 * ldA));
+    CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
+    CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldb));
+    CRM_TRY(ctx->ws_G2.ensure(sizeof(double) * (size_t)np * ldb));
+    if (idx_G) {
+        CRM_TRY(ctx->ws_Gt.ensure(sizeof(double) * (size_t)np * ldb));
+        CRM_TRY(ctx->ws_GG.ensure(sizeof(double) * (size_t)np * ldb));
+    }
+    const int mt_blk = (BLK + GEMM_BM - 1) / GEMM_BM;
+    const int ks1 = pick_split(np, (long)mt_blk * (ldZ1 / GEMM_BN));
+    const int ks2 = pick_split(np, (long)mt_blk * (ldZ2 / GEMM_BN));
+    const int ks3 = pick_split(np, (long)mt_blk * (ldZ3 / GEMM_BN));
+    const long z1_sz = (long)BLK * ldZ1, z2_sz = (long)BLK * ldZ2, z3_sz = (long)BLK * ldZ3;
+    CRM_TRY(ctx->ws_Z.ensure(sizeof(double) * (size_t)(z1_sz * ks1 + z2_sz * ks2 + z3_sz * ks3)));
+    double* dZ1 = ctx->ws_Z.as<double>();
+    double* dZ2 = dZ1 + z1_sz * ks1;
+    double* dZ3 = dZ2 + z2_sz * ks2;
+    CRM_TRY(ctx->ws_F.ensure(sizeof(double) * (size_t)BLK * k0 * k0));
+    CRM_TRY(ctx->ws_Gext.ensure(sizeof(double) * (size_t)BLK * KT * KT));
+    // small arrays carved out of one buffer
+    const size_t stats_ws = variant_stats_workspace(BLK, c);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_gg = carve(sizeof(double) * BLK), o_gy = carve(sizeof(double) * BLK),
+                 o_gW = carve(sizeof(double) * BLK * CRM_MAX_COV), o_trial = carve(sizeof(NullFitTrial) * BLK * nrho),
+                 o_fit = carve(sizeof(NullFitOut) * BLK), o_pos = carve(sizeof(int) * BLK),
+                 o_ord = carve(sizeof(int) * BLK), o_Q = carve(sizeof(double) * BLK),
+                 o_pv = carve(sizeof(double) * BLK), o_lam = carve(sizeof(double) * BLK * k0),
+                 o_if = carve(sizeof(int) * BLK), o_liu = carve(sizeof(double) * BLK),
+                 o_part = carve(stats_ws);
+    CRM_TRY(ctx->ws_small.ensure(off));
+    char* sm = ctx->ws_small.as<char>();
+    double* d_gg = (double*)(sm + o_gg);
+    double* d_gy = (double*)(sm + o_gy);
+    double* d_gW = (double*)(sm + o_gW);
+    NullFitTrial* d_trial = (NullFitTrial*)(sm + o_trial);
+    NullFitOut* d_fit = (NullFitOut*)(sm + o_fit);
+    int* d_pos = (int*)(sm + o_pos);
+    int* d_ord = (int*)(sm + o_ord);
+    double* d_Q = (double*)(sm + o_Q);
+    double* d_pv = (double*)(sm + o_pv);
+    double* d_lam = (double*)(sm + o_lam);
+    int* d_if = (int*)(sm + o_if);
+    double* d_liu = (double*)(sm + o_liu);
+    double* d_part = (double*)(sm + o_part);
+    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
+    GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
+
+    const long slab = (long)(1 + c) * ldq;  // rotations of [y, W] per grid point
+    std::vector<NullFitOut> h_fit(BLK);
+    std::vector<int> h_pos(BLK), h_ord(BLK);
+    std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
+
+    for (long done = 0; done < count; done += BLK) {
+        const int nb = (int)std::min<long>(BLK, count - done);
+        const long col0 = first + done;
+        double* Gb = ctx->ws_Gb.as<double>();
+        // 1. aligned copy of the block (and its row-permuted twin for the test direction)
+        CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, nullptr, nullptr, nb, Gb, ldb, (int)ldb));
+        double* Gt = Gb;
+        if (idx_G) {
+            Gt = ctx->ws_Gt.as<double>();
+            CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, d_idxG, nullptr, nb, Gt, ldb, (int)ldb));
+        }
+        // 2. g'g, g'y, g'W
+        CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, CRM_MAX_COV));
+        // 3. T(rho) = G' Q0(rho) for all grid points in one launch
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = Gb; p.ldx = ldb;
+            p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
+            p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            probs[i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, np, false, 0, 1, 0));
+        // 4. null fits + rho*
+        NullFitArgs fa{};
+        fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n;
+        for (int i = 0; i < nrho; i++) {
+            NullFitRho& R = fa.rho[i];
+            R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
+            R.ty = gene->rot.as<double>() + (long)i * slab;
+            R.tW = R.ty + ldq; R.ldW = ldq;
+            R.S0 = bg->S0[i].as<double>();
+            R.r = bg->r[i];
+        }
+        fa.WW = gene->WW.as<double>(); fa.Wy = gene->Wy.as<double>(); fa.yy = gene->yy;
+        fa.gg = d_gg; fa.gy = d_gy; fa.gW = d_gW; fa.ld_gW = CRM_MAX_COV;
+        fa.trial = d_trial; fa.out = d_fit;
+        CRM_TRY(launch_nullfit(st, fa, nb));
+        // 5. order the block by rho* (host counting sort; nb * 48 bytes cross PCIe)
+        CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * nb, hipMemcpyDeviceToHost, st));
+        CRM_HIP(hipStreamSynchronize(st));
+        int cnt[CRM_MAX_RHO] = {0}, start[CRM_MAX_RHO + 1] = {0};
+        for (int b = 0; b < nb; b++) cnt[h_fit[b].rho_index]++;
+        for (int i = 0; i < nrho; i++) start[i + 1] = start[i] + cnt[i];
+        {
+            int fill[CRM_MAX_RHO];
+            for (int i = 0; i < nrho; i++) fill[i] = start[i];
+            for (int b = 0; b < nb; b++) {
+                const int pos = fill[h_fit[b].rho_index]++;
+                h_pos[b] = pos;
+                h_ord[pos] = b;
+            }
+        }
+        CRM_HIP(hipMemcpyAsync(d_pos, h_pos.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
+        CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
+        double* Gs = ctx->ws_Gs.as<double>();
+        CRM_TRY(launch_gather_block(st, Gt, ldb, np, np, nullptr, d_ord, nb, Gs, ldb, (int)ldb));
+        // 6. A~ = KR(Gs, Ep)' Q0(rho*), one problem per non-empty rho* group
+        int nz = 0, max_m = 0;
+        double kr_flops = 0.0;
+        for (int i = 0; i < nrho; i++) {
+            if (cnt[i] == 0) continue;
+            GemmProblem p{};
+            p.X = Gs + start[i]; p.ldx = ldb;
+            p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
+            p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.C = ctx->ws_A.as<double>() + (size_t)start[i] * k0 * ldA; p.ldc = ldA;
+            p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            max_m = std::max(max_m, p.M);
+            kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
+            probs[nz++] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
+        if (ctx->timing) {
+            if (ctx->timed_used == ctx->timed.size()) {
+                hipEvent_t a, b;
+                CRM_HIP(hipEventCreate(&a));
+                CRM_HIP(hipEventCreate(&b));
+                ctx->timed.emplace_back(a, b);
+            }
+            CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
+        }
+        CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, np, true, k0, 1, 0));
+        if (ctx->timing) {
+            CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
+            ctx->timed_used++;
+            ctx->kr_flops += kr_flops;
+        }
+        // 7. elementwise products for the side contractions
+        double* G2 = ctx->ws_G2.as<double>();
+        double* GG = idx_G ? ctx->ws_GG.as<double>() : nullptr;
+        CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, np, (int)ldb, G2, GG, ldb));
+        if (!GG) GG = G2;
+        // 8. Z1 = Gt' [y o E, W o E], Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
+        {
+            GemmProblem p{};
+            p.X = Gt; p.ldx = ldb; p.Y = gene->YE.as<double>(); p.ldy = gene->ld_ye;
+            p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
+            probs[0] = p;
+            p.X = GG; p.Y = gene->Ep.as<double>(); p.ldy = gene->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
+            probs[1] = p;
+            p.X = G2; p.Y = gene->EE.as<double>(); p.ldy = gene->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
+            probs[2] = p;
+            CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * 3, hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_gemm_tn(st, d_probs + 0, 1, nb, k0 * (1 + c), np, false, 0, ks1, z1_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, ks1, z1_sz));
+            CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, np, false, 0, ks2, z2_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, ks2, z2_sz));
+            CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, np, false, 0, ks3, z3_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, ks3, z3_sz));
+        }
+        // 9. Q and F
+        AssembleArgs aa{};
+        for (int i = 0; i < nrho; i++) {
+            AssembleRho& R = aa.rho[i];
+            R.ty = gene->rot.as<double>() + (long)i * slab;
+            R.tW = R.ty + ldq; R.ldW = ldq;
+            R.S0 = bg->S0[i].as<double>();
+            R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
+            R.r = bg->r[i];
+        }
+        aa.fit = d_fit; aa.sorted_pos = d_pos;
+        aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
+        aa.Z1 = dZ1; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
+        aa.WW = gene->WW.as<double>(); aa.Wy = gene->Wy.as<double>(); aa.yy = gene->yy;
+        aa.gg = d_gg; aa.gy = d_gy; aa.gW = d_gW; aa.ld_gW = CRM_MAX_COV;
+        aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
+        CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
+        // 10. eigenvalues + Davies
+        CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));
+        // 11. results
+        if (out_pvalue) CRM_HIP(hipMemcpyAsync(out_pvalue + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+        if (out_Q) CRM_HIP(hipMemcpyAsync(out_Q + done, d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+        if (out_lambda) CRM_HIP(hipMemcpyAsync(out_lambda + done * k0, d_lam, sizeof(double) * nb * k0, hipMemcpyDeviceToHost, st));
+        if (out_F) CRM_HIP(hipMemcpyAsync(out_F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
+        for (int b = 0; b < nb; b++) {
+            const NullFitOut& f = h_fit[b];
+            const double rho = bg->rho[f.rho_index];
+            if (out_rho1) out_rho1[done + b] = rho;
+            if (out_e2) out_e2[done + b] = f.v0 * rho;
+            if (out_g2) out_g2[done + b] = f.v0 * (1 - rho);
+            if (out_eps2) out_eps2[done + b] = f.v1;
+            if (out_lml) out_lml[done + b] = f.lml;
+            if (out_delta) out_delta[done + b] = f.delta;
+            if (out_scale) out_scale[done + b] = f.scale;
+        }
+        CRM_HIP(hipStreamSynchronize(st));
+    }
+    return CRM_OK;
+}
+
+}  // extern "C"

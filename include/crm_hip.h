@@ -1,0 +1,110 @@
+/* C-ABI of the MI355X score-test engine (libcrm_hip.so).
+ *
+ * Status: the reference (limix/CellRegMap, pure Python) has no FFI seam of its
+ * own; its boundary for this path is the Python API
+ *     CellRegMap.__init__            cellregmap/_cellregmap.py:63-131
+ *     CellRegMap.scan_interaction    cellregmap/_cellregmap.py:317-440
+ *     CellRegMap.scan_association*   cellregmap/_cellregmap.py:246-314
+ *     run_interaction / run_association(_fast)   :471-587
+ * The entry points below are what a ctypes binding inside those methods binds
+ * (see INTEGRATION.md for the stub).  Conventions: plain pointers and sizes,
+ * float64 host buffers owned by the caller, int status (0 = OK, < 0 = error,
+ * text via crm_last_error()), no exceptions across the boundary, one context =
+ * one device + one HIP stream, calls on one context serialised by the caller.
+ */
+#ifndef CRM_HIP_H
+#define CRM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRM_OK 0
+#define CRM_ERR_HIP (-1)
+#define CRM_ERR_ARG (-2)
+#define CRM_ERR_UNSUPPORTED (-3)
+#define CRM_ERR_NUMERIC (-4)
+
+typedef struct crm_ctx crm_ctx;
+typedef struct crm_background crm_background;
+typedef struct crm_gene crm_gene;
+typedef struct crm_panel crm_panel;
+
+/* Thread-local text of the last error raised on this thread. */
+const char* crm_last_error(void);
+/* Library version, "major.minor.patch". */
+const char* crm_version(void);
+
+/* ---- context ------------------------------------------------------------------- */
+int crm_ctx_create(int device, crm_ctx** out);
+void crm_ctx_destroy(crm_ctx* ctx);
+/* Block until all work queued on the context's stream has finished. */
+int crm_ctx_synchronize(crm_ctx* ctx);
+
+/* ---- background covariance: replaces CellRegMap.__init__'s rho loop ---------------
+ * (_cellregmap.py:101-131 + numpy_sugar.economic_qs_linear, twin _math.py:238-256).
+ *
+ * From precomputed economic decompositions: for each of `nrho` grid points,
+ * Q0[i] is n x r[i] (row-major, leading dimension r[i]) and S0[i] has r[i] entries. */
+int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, const int* r,
+                             const double* const* Q0, const double* const* S0,
+                             crm_background** out);
+/* On-device decomposition of the half covariances
+ *     hS(rho) = [ sqrt(rho) * E1 , sqrt(1-rho) * B ]        B: n x kb (row-major, ld kb)
+ * (mode B: B = hK; mode C: B = [L_1 ... L_q]; mode A: kb = 0 and rho = {1}).
+ * Columns whose squared singular value is below `rel_tol` * max are dropped (they are
+ * inert in every quantity of the path); rel_tol <= 0 selects the default 1e-12. */
+int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
+                          int nrho, const double* rho, double rel_tol, crm_background** out);
+void crm_background_destroy(crm_background* bg);
+/* Introspection / read-back (tests): rank at grid point i; copy of S0 / Q0 (n x r, ld r). */
+int crm_background_rank(const crm_background* bg, int i);
+int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0);
+
+/* ---- one phenotype bound to a background: y, W (n x c), E0 (n x k0) ------------------
+ * (the per-object state of CellRegMap: _y, _W, _E0; _cellregmap.py:64-79). */
+int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
+                    int k0, crm_gene** out);
+void crm_gene_destroy(crm_gene* gene);
+
+/* ---- genotype panel resident in HBM: G is n x p, row-major, leading dimension ldg ------ */
+int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out);
+void crm_panel_destroy(crm_panel* panel);
+
+/* ---- interaction scan: replaces the loop body of scan_interaction (_cellregmap.py:340-436)
+ * for variants [first, first + count) of the panel.  idx_E / idx_G are the permutation
+ * hooks of :398-413 (NULL = identity; n entries each).  Outputs have `count` entries;
+ * optional outputs may be NULL.  out_lambda (count x k0) receives the eigenvalues of F in
+ * ascending order, out_F (count x k0 x k0) the matrix itself. */
+int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
+                         const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
+                         double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
+                         double* out_delta, double* out_scale, double* out_lambda, double* out_F);
+
+/* Block size (variants per internal batch); 0 restores the default. */
+int crm_set_block_variants(crm_ctx* ctx, int variants);
+
+/* ---- instrumentation ----------------------------------------------------------------
+ * Sum of HIP-event durations (ms) and launch count of the dominant kernel (the Khatri-Rao
+ * contraction) since the last reset, measured on the context's stream. */
+int crm_kernel_timer_reset(crm_ctx* ctx);
+int crm_kernel_timer_read(crm_ctx* ctx, double* kr_ms, long* kr_launches, double* kr_flops,
+                          double* total_ms);
+
+/* ---- unit-test hooks (exercise single kernels through the same ABI) --------------------
+ * C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
+int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
+                      double* C, int ksplit);
+/* C ((B*k0) x N) = KR(G, E)' Y with G: cells x B, E: cells x k0, Y: cells x N. */
+int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
+                         const double* E, const double* Y, double* C);
+/* Eigenvalues (ascending) of `count` symmetric k x k matrices (lower triangle read). */
+int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* lambda);
+/* Davies/Liu p-values for `count` (Q, lambda[k]) pairs after the eigenvalue filter. */
+int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const double* lambda,
+                    double* pvalue, int* ifault, double* liu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRM_HIP_H */

@@ -1,0 +1,122 @@
+"""End-to-end parity of the HIP interaction scan against the CPU oracle (same seeded inputs).
+
+Tolerances (BASELINE.json north_star): score statistic Q rtol 1e-6, p-values rtol 1e-5.  The
+p-value check carries an absolute floor of 1e-13 because Davies' result is 1 - (0.5 - sum): for
+p < 1e-8 the last digits are summation-order noise in both implementations."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+P_RTOL, P_ATOL = 1e-5, 1e-13
+Q_RTOL = 1e-6
+
+
+def _cohort(donors, cells, k, p, seed):
+    from cellregmap_amd.synth import make_cohort
+
+    return make_cohort(donors, cells, k, p, seed=seed)
+
+
+def _compare(pv, info, stats, opv, oinfo, ostats):
+    assert_allclose(info["rho1"], oinfo["rho1"], rtol=0, atol=1e-12)
+    assert_allclose(stats["delta"], ostats["delta"], rtol=2e-6)
+    assert_allclose(stats["lml"], ostats["lml"], rtol=1e-9)
+    for key in ("e2", "g2", "eps2"):
+        assert_allclose(info[key], oinfo[key], rtol=1e-5, atol=1e-12)
+    assert_allclose(stats["Q"], ostats["Q"], rtol=Q_RTOL)
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
+@pytest.mark.parametrize("mode", ["A", "B", "C", "C-eigh"])
+def test_interaction_matches_oracle(mode):
+    from cellregmap_amd import CellRegMap, get_L_values
+    from oracle.crm import OracleCellRegMap, khatri_rao_halves
+
+    if mode == "C-eigh":      # cols = k + k*donors >= n -> the reference's eigh branch
+        c = _cohort(12, 10, 10, 24, seed=3)
+    elif mode == "C":         # cols = 4 + 4*6 = 28 < n = 240 -> thin branch
+        c = _cohort(6, 40, 4, 24, seed=4)
+    else:
+        c = _cohort(10, 20, 5, 24, seed=5)
+    kw, okw = {}, {}
+    if mode == "B":
+        kw["hK"] = okw["hK"] = c.hK
+    elif mode.startswith("C"):
+        kw["Ls"] = get_L_values(c.hK, c.E)
+        okw["Ls"] = khatri_rao_halves(c.hK, c.E)
+    crm = CellRegMap(c.y, c.E, W=c.W, **kw)
+    pv, info, stats = crm.scan_interaction(c.G, return_stats=True)
+    ocrm = OracleCellRegMap(c.y, c.E, W=c.W, **okw)
+    opv, oinfo, ostats = ocrm.scan_interaction(c.G, return_stats=True)
+    _compare(pv, info, stats, opv, oinfo, ostats)
+    F = np.stack(ostats["F"])
+    scale = np.abs(F).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(stats["F"] - F) <= 1e-9 * scale)
+
+
+def test_run_interaction_config1_subset():
+    """BASELINE config 1 (500 cells, 10 contexts; first 48 of the 200 variants), through the
+    functional wrapper, mode C with cols = 510 >= n."""
+    from cellregmap_amd import run_interaction
+    from cellregmap_amd.synth import make_config
+    from oracle import crm as ocrm
+
+    c = make_config("cfg1", n_variants=48)
+    pv, info = run_interaction(c.y, c.E, c.G, W=c.W, hK=c.hK)
+    opv, oinfo = ocrm.run_interaction(c.y, c.E, c.G, W=c.W, hK=c.hK)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+    # the planted GxC variants (10, 11) must be the most significant ones
+    assert set(np.argsort(pv)[:2]) == {10, 11}
+
+
+def test_permutation_hooks_and_extra_covariates():
+    from cellregmap_amd import CellRegMap
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(8, 25, 4, 16, seed=9)
+    rng = np.random.default_rng(1)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 2))], axis=1)
+    idx_E = rng.permutation(c.y.size)
+    idx_G = rng.permutation(c.y.size)
+    crm = CellRegMap(c.y, c.E, W=W, hK=c.hK)
+    ocrm = OracleCellRegMap(c.y, c.E, W=W, hK=c.hK)
+    for kw in ({"idx_E": idx_E}, {"idx_G": idx_G}, {"idx_E": idx_E, "idx_G": idx_G}):
+        pv, info, stats = crm.scan_interaction(c.G, return_stats=True, **kw)
+        opv, oinfo, ostats = ocrm.scan_interaction(c.G, return_stats=True, **kw)
+        _compare(pv, info, stats, opv, oinfo, ostats)
+
+
+def test_blocks_and_ragged_tail():
+    """Block boundaries must not matter: 300 variants in blocks of 128 == one block."""
+    import ctypes
+
+    from cellregmap_amd import CellRegMap, _engine, _lib
+
+    c = _cohort(10, 12, 3, 300, seed=11)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib = _lib.load()
+    pv1, info1 = crm.scan_interaction(c.G)
+    _lib.check(lib.crm_set_block_variants(_engine._context(0), 128))
+    try:
+        pv2, info2 = crm.scan_interaction(c.G)
+    finally:
+        _lib.check(lib.crm_set_block_variants(_engine._context(0), 0))
+    assert np.array_equal(pv1, pv2)
+    assert np.array_equal(info1["rho1"], info2["rho1"])
+
+
+def test_errors_are_loud():
+    from cellregmap_amd import CellRegMap
+
+    c = _cohort(5, 8, 3, 4, seed=2)
+    with pytest.raises(AssertionError):
+        CellRegMap(c.y, c.E[:-1], W=c.W)
+    y = c.y.copy()
+    y[3] = np.nan
+    with pytest.raises(ValueError):
+        CellRegMap(y, c.E, W=c.W).scan_interaction(c.G)
+    with pytest.raises(ValueError):
+        CellRegMap(c.y, c.E, W=c.W).scan_interaction(c.G[:-1])

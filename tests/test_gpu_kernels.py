@@ -1,0 +1,112 @@
+"""Single-kernel parity on a real MI355X, through the C-ABI test hooks."""
+import ctypes
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cellregmap_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.crm_ctx_create(0, ctypes.byref(h)))
+    yield lib, h
+    lib.crm_ctx_destroy(h)
+
+
+def _contract(ctx, X, Y, ksplit=1):
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    X, Y = _lib.f64(X), _lib.f64(Y)
+    C = np.empty((X.shape[1], Y.shape[1]))
+    _lib.check(lib.crm_test_contract(h, X.shape[0], X.shape[1], Y.shape[1], _lib.ptr(X), _lib.ptr(Y),
+                                     _lib.ptr(C), ksplit))
+    return C
+
+
+def test_contract_layout_with_integer_data(ctx):
+    # exact small integers + asymmetric operands: catches any row/column swap of the
+    # v_mfma_f64_16x16x4_f64 fragment maps
+    rng = np.random.default_rng(0)
+    X = rng.integers(-3, 4, size=(24, 37)).astype(float)
+    Y = rng.integers(-3, 4, size=(24, 150)).astype(float)
+    X[:, 5] = np.arange(24)
+    Y[:, 7] = np.arange(24) ** 2
+    assert np.array_equal(_contract(ctx, X, Y), X.T @ Y)
+
+
+@pytest.mark.parametrize("cells,M,N,ksplit", [(1000, 130, 257, 1), (4096, 256, 128, 4), (777, 16, 16, 1),
+                                               (20000, 200, 1275, 5)])
+def test_contract_random(ctx, cells, M, N, ksplit):
+    rng = np.random.default_rng(cells + M)
+    X = rng.normal(size=(cells, M))
+    Y = rng.normal(size=(cells, N))
+    ref = X.T @ Y
+    assert_allclose(_contract(ctx, X, Y, ksplit), ref, rtol=0, atol=1e-11 * np.sqrt(cells))
+
+
+@pytest.mark.parametrize("cells,B,k0,N", [(500, 7, 10, 140), (2048, 20, 50, 300), (333, 40, 3, 64),
+                                           (1024, 5, 128, 130), (640, 300, 1, 128)])
+def test_contract_khatri_rao(ctx, cells, B, k0, N):
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    rng = np.random.default_rng(B * k0)
+    G = _lib.f64(rng.normal(size=(cells, B)))
+    E = _lib.f64(rng.normal(size=(cells, k0)))
+    Y = _lib.f64(rng.normal(size=(cells, N)))
+    C = np.empty((B * k0, N))
+    _lib.check(lib.crm_test_contract_kr(h, cells, B, k0, N, _lib.ptr(G), _lib.ptr(E), _lib.ptr(Y),
+                                        _lib.ptr(C)))
+    KR = (G[:, :, None] * E[:, None, :]).reshape(cells, B * k0)
+    assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 50, 64, 65, 128])
+def test_eigvalsh_batched(ctx, k):
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    rng = np.random.default_rng(k)
+    count = 9
+    F = np.empty((count, k, k))
+    for i in range(count):
+        A = rng.normal(size=(k, max(1, k // (1 + i % 3))))
+        S = A @ A.T
+        F[i] = S + 1e-14 * rng.normal(size=(k, k))  # asymmetric noise: only the lower triangle counts
+    lam = np.empty((count, k))
+    _lib.check(lib.crm_test_eigvalsh(h, count, k, _lib.ptr(F), _lib.ptr(lam)))
+    for i in range(count):
+        ref = np.linalg.eigvalsh(F[i])  # UPLO='L'
+        assert_allclose(lam[i], ref, rtol=0, atol=1e-13 * max(1.0, abs(ref).max()))
+
+
+def test_davies_matches_oracle(ctx):
+    from cellregmap_amd import _lib
+    from oracle.davies import filter_weights, pvalue_from_weights
+
+    lib, h = ctx
+    rng = np.random.default_rng(5)
+    k, count = 12, 64
+    lam = np.sort(rng.gamma(0.7, 1.0, size=(count, k)), axis=1)
+    lam[::7, : k - 3] *= 1e-9          # mostly filtered away
+    lam[3::11, : k - 1] = -1e-12        # a single survivor -> Liu
+    frac = rng.choice([0.2, 1.0, 2.0, 4.0, 8.0, 20.0, 60.0], size=count)
+    Q = frac * lam.sum(1)
+    pv = np.empty(count); ifault = np.empty(count, np.int32); liu = np.empty(count)
+    _lib.check(lib.crm_test_davies(h, count, k, _lib.ptr(Q), _lib.ptr(lam), _lib.ptr(pv), _lib.ptr(ifault),
+                                   _lib.ptr(liu)))
+    for i in range(count):
+        nonneg = lam[i][lam[i] >= 0]
+        kept = lam[i][lam[i] > nonneg.mean() / 1e5]
+        p_ref, info = pvalue_from_weights(Q[i], kept)
+        # Davies' integral is a 0.5 - sum cancellation: absolute floor from the summation order
+        assert abs(pv[i] - p_ref) <= 1e-5 * p_ref + 1e-13, (i, pv[i], p_ref, info)
+        assert_allclose(liu[i], info["liu_pval"], rtol=1e-8, atol=1e-300)
+        assert ifault[i] == info["ifault"]

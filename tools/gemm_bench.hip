@@ -1,0 +1,96 @@
+// Stand-alone probe: (1) bare v_mfma_f64_16x16x4_f64 issue rate, (2) throughput of the
+// contraction kernel (plain and Khatri-Rao) at config-3 shapes.  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip cellregmap_amd/csrc/gemm_tn.hip \
+//         cellregmap_amd/csrc/api_core.hip -o tools/gemm_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../cellregmap_amd/csrc/crm_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma_rate(double* out, int iters) {
+    v4d acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = (v4d){0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void fill(double* p, long n, unsigned seed) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    p[i] = ((double)(x & 0xffffff) / 8388608.0) - 1.0;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms;
+    {  // bare MFMA rate: 256 CUs x 2 blocks x 4 waves, 8 independent accumulators
+        double* out;
+        int blocks = 256 * 2, iters = 20000;
+        CK(hipMalloc(&out, sizeof(double) * blocks * 256));
+        hipLaunchKernelGGL(mfma_rate, dim3(blocks), dim3(256), 0, st, out, 100);
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(mfma_rate, dim3(blocks), dim3(256), 0, st, out, iters);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        double flops = (double)blocks * 4 * iters * 8 * 2048.0;
+        printf("bare mfma_f64_16x16x4: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms * 1e-9);
+    }
+    const long cells = 20000, r = 5120;
+    const int k0 = 50;
+    int Bs[] = {128, 512};
+    double *Q0, *G, *E, *C;
+    CK(hipMalloc(&Q0, sizeof(double) * cells * r));
+    CK(hipMalloc(&G, sizeof(double) * cells * (1024 + 128)));
+    CK(hipMalloc(&E, sizeof(double) * cells * 64));
+    CK(hipMalloc(&C, sizeof(double) * 1024L * k0 * r));
+    hipLaunchKernelGGL(fill, dim3((cells * r + 255) / 256), dim3(256), 0, st, Q0, cells * r, 1u);
+    hipLaunchKernelGGL(fill, dim3((cells * 1152 + 255) / 256), dim3(256), 0, st, G, cells * 1152, 2u);
+    hipLaunchKernelGGL(fill, dim3((cells * 64 + 255) / 256), dim3(256), 0, st, E, cells * 64, 3u);
+    crm::GemmProblem* pd;
+    CK(hipMalloc(&pd, sizeof(crm::GemmProblem)));
+    for (int B : Bs) {
+        // plain: T = G' Q0  (M = B, N = r)
+        crm::GemmProblem p{};
+        p.X = G; p.Y = Q0; p.C = C; p.ldx = 1152; p.ldy = r; p.ldc = r; p.M = B; p.N = (int)r;
+        CK(hipMemcpy(pd, &p, sizeof p, hipMemcpyHostToDevice));
+        crm::launch_gemm_tn(st, pd, 1, B, (int)r, cells, false, 0, 1, 0);
+        CK(hipEventRecord(e0, st));
+        crm::launch_gemm_tn(st, pd, 1, B, (int)r, cells, false, 0, 1, 0);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("plain  B=%4d: %.3f ms  %.2f TFLOP/s\n", B, ms, 2.0 * cells * r * B / ms * 1e-9);
+        // KR: A = KR(G, E)' Q0   (M = B*k0, N = r)
+        p.E = E; p.lde = 64; p.M = B * k0; p.k0 = k0;
+        CK(hipMemcpy(pd, &p, sizeof p, hipMemcpyHostToDevice));
+        crm::launch_gemm_tn(st, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
+        CK(hipEventRecord(e0, st));
+        crm::launch_gemm_tn(st, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("KR     B=%4d: %.3f ms  %.2f TFLOP/s  (%.1f variants/s on this term)\n", B, ms,
+               2.0 * cells * r * B * k0 / ms * 1e-9, B / (ms * 1e-3));
+    }
+    printf("last error: '%s'\n", crm::last_error_text());
+    return 0;
+}
