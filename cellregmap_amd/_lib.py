@@ -37,6 +37,7 @@ SIGNATURES = {
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
     "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_set_null_fit_polish": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
     "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,

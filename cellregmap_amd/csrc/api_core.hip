@@ -102,6 +102,12 @@ int crm_set_block_variants(crm_ctx* c, int variants) {
     return CRM_OK;
 }
 
+int crm_set_null_fit_polish(crm_ctx* c, int on) {
+    if (!c) return CRM_ERR_ARG;
+    c->polish = on != 0;
+    return CRM_OK;
+}
+
 int crm_kernel_timer_reset(crm_ctx* c) {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));

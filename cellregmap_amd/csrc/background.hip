@@ -112,7 +112,7 @@ __global__ void gather_vectors_kernel(const double* __restrict__ V, long ldv, co
 }
 
 struct Scratch {
-    DevBuf bufs[12];
+    DevBuf bufs[13];
     ~Scratch() {
         for (auto& b : bufs) b.release();
     }
@@ -167,8 +167,8 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
 
     Scratch S;
     DevBuf &dH = S.bufs[0], &dHt = S.bufs[1], &dC = S.bufs[2], &dCr = S.bufs[3], &dW = S.bufs[4],
-           &dE = S.bufs[5], &dInfo = S.bufs[6], &dKeep = S.bufs[7], &dM = S.bufs[8], &dMt = S.bufs[9],
-           &dG = S.bufs[10], &dErr = S.bufs[11];
+           &dE = S.bufs[5], &dInfo = S.bufs[6], &dKeep = S.bufs[7], &dMt = S.bufs[9],
+           &dG = S.bufs[10], &dErr = S.bufs[11], &dQt = S.bufs[12];
     // H = [E1, B] (cells x cols) and its transpose
     CRM_TRY(dH.ensure(sizeof(double) * np * cp));
     CRM_HIP(hipMemsetAsync(dH.ptr, 0, sizeof(double) * np * cp, st));
@@ -317,11 +317,14 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
     // pass 2: Q0 buffers with the common leading dimension
     bg->ldq = round_up(rmax, 128);
     const long ldq = bg->ldq;
-    if (thin) {
-        CRM_BG(dG.ensure(sizeof(double) * ldq * ldq * 2));
-        CRM_BG(dMt.ensure(sizeof(double) * ldq * cp));
-        CRM_BG(dErr.ensure(sizeof(double) * ((ldq + 255) / 256) * ldq));
-    }
+    dG.release();
+    dMt.release();
+    dC.release();
+    dCr.release();
+    dH.release();
+    CRM_BG(dG.ensure(sizeof(double) * ldq * ldq * 2));
+    CRM_BG(dQt.ensure(sizeof(double) * ldq * np));
+    CRM_BG(dErr.ensure(sizeof(double) * ((ldq + 255) / 256) * ldq));
     for (int i = 0; i < nrho; i++) {
         const int r = bg->r[i];
         CRM_BG(bg->Q0[i].ensure(sizeof(double) * np * ldq));
@@ -334,18 +337,20 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
         if (!thin) {
             CRM_BG_HIP(hipMemcpy2DAsync(bg->Q0[i].ptr, ldq * sizeof(double), Mbuf[i].ptr, ldm * sizeof(double),
                                         r * sizeof(double), n, hipMemcpyDeviceToDevice, st));
-            CRM_BG_HIP(hipStreamSynchronize(st));
-            Mbuf[i].release();
-            continue;
+        } else {
+            // Q0 = H M  ==  Ht' M  (contraction over the cols axis)
+            CRM_BG(contract(ctx, dHt.as<double>(), np, Mbuf[i].as<double>(), ldm, bg->Q0[i].as<double>(), ldq,
+                            (int)n, r, cp));
         }
-        double* M = Mbuf[i].as<double>();
+        CRM_BG_HIP(hipStreamSynchronize(st));
+        Mbuf[i].release();
+        // Newton-Schulz polish of the orthonormality: Q0 <- Q0 (1.5 I - 0.5 Q0'Q0).  The Gram route
+        // loses it for small eigenvalues (defect ~ eps * S_max / S_j) and the library eigenvectors
+        // of the n x n route carry ~1e-13; the path's complement terms (u'v - (Q0'u)'(Q0'v)) / d see
+        // any defect directly.
         double* Gq = dG.as<double>();
         double* N = Gq + ldq * ldq;
         for (int pass = 0; pass < 4; pass++) {
-            // Q0 = H M  ==  Ht' M  (contraction over the cols axis)
-            CRM_BG(contract(ctx, dHt.as<double>(), np, M, ldm, bg->Q0[i].as<double>(), ldq, (int)n, r, cp));
-            if (pass == 3) break;
-            // orthonormality defect and the Newton-Schulz correction M <- M (1.5 I - 0.5 Q0'Q0)
             CRM_BG(contract(ctx, bg->Q0[i].as<double>(), ldq, bg->Q0[i].as<double>(), ldq, Gq, ldq, r, r, np));
             dim3 grid((unsigned)((r + 255) / 256), (unsigned)r);
             CRM_BG_HIP(hipMemsetAsync(N, 0, sizeof(double) * ldq * ldq, st));
@@ -360,13 +365,13 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
                 set_error("background: Q0 lost orthonormality at rho=%g (defect %g)", rho[i], err);
                 return fail(CRM_ERR_NUMERIC);
             }
-            if (err < 2e-14) break;
-            // M <- M N : contraction over r with X = M' (r x cols)
-            CRM_BG_HIP(hipMemsetAsync(dMt.ptr, 0, sizeof(double) * ldq * cp, st));
-            CRM_BG(transpose(st, M, ldm, cols, r, dMt.as<double>(), cp));
-            CRM_BG(contract(ctx, dMt.as<double>(), cp, N, ldq, M, ldm, (int)cols, r, round_up(r, GEMM_BK)));
+            bg->ortho_defect[i] = err;
+            if (err < 2e-14 || pass == 2) break;
+            // Q0 <- Q0 N : contraction over r with X = Q0' (r x cells)
+            CRM_BG_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * np, st));
+            CRM_BG(transpose(st, bg->Q0[i].as<double>(), ldq, n, r, dQt.as<double>(), np));
+            CRM_BG(contract(ctx, dQt.as<double>(), np, N, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, round_up(r, GEMM_BK)));
         }
-        Mbuf[i].release();
     }
     CRM_BG_HIP(hipStreamSynchronize(st));
 #undef CRM_BG

@@ -28,7 +28,8 @@ struct NullFitOut {
 
 struct NullFitArgs {
     NullFitRho rho[CRM_MAX_RHO];
-    int nrho, c, restricted, pad_;
+    int nrho, c, restricted;
+    int polish;        // secant refinement of the optimum on the analytic derivative
     long n;            // cells (unpadded)
     const double* WW;  // [c x c]
     const double* Wy;  // [c]

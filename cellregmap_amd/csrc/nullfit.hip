@@ -160,11 +160,14 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
     const double p_eff = use_g ? (double)P : (double)C;
     const double df = a.restricted ? n - p_eff : n;
 
-    // one pass over the spectrum: weighted pair sums (+ log-determinant part)
-    auto spectrum_pass = [&](double delta, bool weighted, double (&S)[NP], double& lsum) {
+    // one pass over the spectrum: weighted pair sums (+ log-determinant part); with GRAD also the
+    // sums with weight (1 - S_j) / D_j^2 that make up d/d(delta) of every bilinear form
+    auto spectrum_pass = [&](double delta, bool weighted, double (&S)[NP], double& lsum,
+                             bool grad, double (&S2)[NP], double& lsum2) {
 #pragma unroll
-        for (int i = 0; i < NP; i++) S[i] = 0.0;
+        for (int i = 0; i < NP; i++) { S[i] = 0.0; S2[i] = 0.0; }
         lsum = 0.0;
+        lsum2 = 0.0;
         const double omd = 1.0 - delta;
         for (int j = lane; j < r; j += 64) {
             double t[U];
@@ -172,28 +175,43 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
             for (int i = 0; i < C; i++) t[i] = R.tW[(long)i * R.ldW + j];
             t[C] = tg[j];
             t[C + 1] = R.ty[j];
-            double wgt = 1.0;
+            double wgt = 1.0, wgt2 = 0.0;
             if (weighted) {
-                const double D = omd * R.S0[j] + delta;
+                const double s0 = R.S0[j];
+                const double D = omd * s0 + delta;
                 wgt = 1.0 / D;
                 lsum += log(D);
+                if (grad) {
+                    const double oms = 1.0 - s0;
+                    lsum2 += oms * wgt;
+                    wgt2 = oms * wgt * wgt;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const double tw = t[u] * wgt;
+                const double tw2 = t[u] * wgt2;
 #pragma unroll
-                for (int v = u; v < U; v++) S[pair_index(u, v, U)] += tw * t[v];
+                for (int v = u; v < U; v++) {
+                    S[pair_index(u, v, U)] += tw * t[v];
+                    if (grad) S2[pair_index(u, v, U)] += tw2 * t[v];
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) S[i] = wave_sum(S[i]);
         if (weighted) lsum = wave_sum(lsum);
+        if (grad) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) S2[i] = wave_sum(S2[i]);
+            lsum2 = wave_sum(lsum2);
+        }
     };
 
     double tt[NP];  // t_u' t_v (complement correction)
     {
-        double dummy;
-        spectrum_pass(1.0, false, tt, dummy);
+        double dummy, dummy2, unused[NP];
+        spectrum_pass(1.0, false, tt, dummy, false, unused, dummy2);
     }
 
     double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
@@ -202,8 +220,8 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
     auto f = [&](double x) -> double {
         nfev++;
         const double delta = logistic_clamped(x);
-        double S[NP], lsum;
-        spectrum_pass(delta, true, S, lsum);
+        double S[NP], lsum, unused[NP], unused2;
+        spectrum_pass(delta, true, S, lsum, false, unused, unused2);
         const double inv_d = 1.0 / delta;
         double K[NP];  // u' Kt^-1 v
 #pragma unroll
@@ -243,6 +261,73 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
         cur_scale = s;
         cur_lml = val;
         return -val;
+    };
+
+    // g(x) = d(-lml)/dx with beta and scale profiled out (oracle/lmm.py: _neg_lml_grad_at)
+    auto g = [&](double x) -> double {
+        const double delta = logistic_clamped(x);
+        if (delta <= EPS_TINY || delta >= 1.0 - EPS_TINY) return 0.0;
+        double S[NP], S2[NP], lsum, lsum2;
+        spectrum_pass(delta, true, S, lsum, true, S2, lsum2);
+        const double inv_d = 1.0 / delta, inv_d2 = inv_d * inv_d;
+        double K[NP], dK[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double cpl = uv[i] - tt[i];
+            K[i] = S[i] + cpl * inv_d;
+            dK[i] = -S2[i] - cpl * inv_d2;
+        }
+        const double dlogdet = lsum2 + (n - (double)r) * inv_d;
+        double A[P][P], dA[P][P], b[P], db[P], beta[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                const int pi = i <= j ? pair_index(i, j, U) : pair_index(j, i, U);
+                A[i][j] = K[pi];
+                dA[i][j] = dK[pi];
+            }
+            b[i] = K[pair_index(i, C + 1, U)];
+            db[i] = dK[pair_index(i, C + 1, U)];
+        }
+        if (!use_g) {
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                A[C][j] = 0.0; A[j][C] = 0.0;
+                dA[C][j] = 0.0; dA[j][C] = 0.0;
+            }
+            A[C][C] = 1.0;
+            b[C] = 0.0;
+            db[C] = 0.0;
+        }
+        double ld;
+        if (!cholesky<P>(A, ld)) return NAN;
+#pragma unroll
+        for (int i = 0; i < P; i++) beta[i] = b[i];
+        cholesky_solve<P>(A, beta);
+        double Rv = K[pair_index(C + 1, C + 1, U)];
+        double dR = dK[pair_index(C + 1, C + 1, U)];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            Rv -= b[i] * beta[i];
+            dR -= 2.0 * db[i] * beta[i];
+#pragma unroll
+            for (int j = 0; j < P; j++) dR += beta[i] * dA[i][j] * beta[j];
+        }
+        double d = df * dR / Rv + dlogdet;
+        if (a.restricted) {
+            double tr = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                double col[P];
+#pragma unroll
+                for (int i = 0; i < P; i++) col[i] = dA[i][j];
+                cholesky_solve<P>(A, col);
+                tr += col[j];
+            }
+            d += tr;
+        }
+        return 0.5 * d * delta * (1.0 - delta);
     };
 
     {
@@ -325,6 +410,30 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
                     bx1 = u; bf1 = fu;
                 } else if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
                     bx2 = u; bf2 = fu;
+                }
+            }
+        }
+        if (a.polish) {
+            // secant steps on the analytic derivative (oracle/lmm.py: _polish)
+            const double xs = bx0, fs = bf0;
+            double xa = xs, ga = g(xa);
+            if (isfinite(ga) && ga != 0.0) {
+                double xb = ga > 0.0 ? xa - 1e-4 : xa + 1e-4;
+                double gb = g(xb);
+                bool reject = false;
+                for (int it = 0; it < 8; it++) {
+                    if (!isfinite(gb) || gb == ga) break;
+                    const double xn = xb - gb * (xb - xa) / (gb - ga);
+                    if (!isfinite(xn) || fabs(xn - xs) > 1e-2) { reject = true; break; }
+                    const double step = fabs(xn - xb);
+                    xa = xb; ga = gb;
+                    xb = xn;
+                    gb = g(xb);
+                    if (gb == 0.0 || step <= 1e-12 * (1.0 + fabs(xn))) break;
+                }
+                if (!reject && isfinite(gb)) {
+                    const double fb = f(xb);
+                    if (fb <= fs + 1e-9 * fabs(fs)) bx0 = xb;
                 }
             }
         }

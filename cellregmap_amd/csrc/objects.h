@@ -15,6 +15,7 @@ struct crm_background {
     int nrho = 0;
     double rho[crm::CRM_MAX_RHO] = {0};
     int r[crm::CRM_MAX_RHO] = {0};
+    double ortho_defect[crm::CRM_MAX_RHO] = {0};  // max |Q0'Q0 - I| after the polish
     long ldq = 0;                        // common leading dimension (multiple of 128)
     crm::DevBuf Q0[crm::CRM_MAX_RHO];    // [n_pad x ldq], zero padded
     crm::DevBuf S0[crm::CRM_MAX_RHO];    // [ldq]

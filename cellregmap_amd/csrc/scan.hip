@@ -361,7 +361,7 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, np, false, 0, 1, 0));
         // 4. null fits + rho*
         NullFitArgs fa{};
-        fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n;
+        fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0;
         for (int i = 0; i < nrho; i++) {
             NullFitRho& R = fa.rho[i];
             R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;

@@ -30,7 +30,10 @@ def khatri_rao_halves(hK, E2):
 class OracleCellRegMap:
     """CellRegMap(y, E, W=None, Ls=None, E1=None, hK=None)  (_cellregmap.py:63)."""
 
-    def __init__(self, y, E, W=None, Ls=None, E1=None, hK=None):
+    def __init__(self, y, E, W=None, Ls=None, E1=None, hK=None, polish=True):
+        # polish=False is the reference procedure verbatim (Brent, 1e-6); polish=True adds the
+        # derivative-based refinement of the null fit that the HIP engine performs (oracle/lmm.py)
+        self._polish = bool(polish)
         self._y = np.asarray(y, float).flatten()
         self._E0 = np.asarray(E, float)
         Ls = [] if Ls is None else Ls
@@ -70,7 +73,7 @@ class OracleCellRegMap:
         best_lml, best_rho, best = -np.inf, 0, None
         for rho in self._rho:
             lmm = LMM(self._y, X, self._qs[rho], restricted=restricted)
-            lmm.fit(verbose=False)
+            lmm.fit(verbose=False, polish=self._polish)
             val = lmm.lml()
             if val > best_lml:
                 best_lml, best_rho, best = val, rho, lmm
@@ -126,7 +129,7 @@ class OracleCellRegMap:
         for i in range(G.shape[1]):
             X = np.concatenate((self._W, G[:, [i]]), axis=1)
             lmm = LMM(self._y, X, self._qs[rho], restricted=False)
-            lmm.fit(verbose=False)
+            lmm.fit(verbose=False, polish=self._polish)
             alt[i] = lmm.lml()
         return lrt_pvalues(null_lml, alt, dof=1), info
 
@@ -146,13 +149,13 @@ def lrt_pvalues(null_lml, alt_lmls, dof=1):
     return np.clip(pv, epsilon.super_tiny, 1 - epsilon.tiny)
 
 
-def run_interaction(y, E, G, W=None, E1=None, E2=None, hK=None, idx_G=None):
+def run_interaction(y, E, G, W=None, E1=None, E2=None, hK=None, idx_G=None, polish=True):
     """_cellregmap.py:547-587.  NB ``idx_G`` is handed over positionally and so
     lands in ``scan_interaction``'s ``idx_E`` slot (:586 vs :318)."""
     E1 = E if E1 is None else E1
     E2 = E if E2 is None else E2
     Ls = None if hK is None else khatri_rao_halves(hK, E2)
-    crm = OracleCellRegMap(y=y, E=E, W=W, E1=E1, Ls=Ls)
+    crm = OracleCellRegMap(y=y, E=E, W=W, E1=E1, Ls=Ls, polish=polish)
     return crm.scan_interaction(G, idx_G)
 
 

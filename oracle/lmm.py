@@ -136,10 +136,68 @@ class LMM:
         self._update()
         return -self.lml()
 
-    def fit(self, verbose=False):
-        x, _, _ = brent.minimize(self._neg_lml_at, a=-LOGMAX, b=LOGMAX, rtol=1e-6, atol=1e-6)
+    # -- derivative of the profiled objective (for the polish) ---------------------------------
+    def _neg_lml_grad_at(self, x):
+        """d(-lml)/dx at x = logit(delta), beta and scale profiled out (envelope theorem)."""
+        self._x = float(x)
+        delta = self.delta
+        if delta <= epsilon.tiny or delta >= 1.0 - epsilon.tiny:
+            return 0.0
+        S0, ty, tX = self._S0, self._ty, self._tXr
+        D = (1.0 - delta) * S0 + delta
+        w = 1.0 / D
+        w2 = (1.0 - S0) * w * w
+        yKy, XKy, XKX, _ = self._terms(delta)
+        i2 = 1.0 / (delta * delta)
+        dyKy = -float((ty * w2) @ ty) - (self._yy - self._tyty) * i2
+        dXKy = -(tX.T @ (w2 * ty)) - (self._Xy - self._tXty) * i2
+        dXKX = -((tX.T * w2) @ tX) - (self._XX - self._tXtX) * i2
+        dlogdet = float(((1.0 - S0) * w).sum()) + (self._n - S0.shape[0]) / delta
+        beta = _rsolve(XKX, XKy)
+        R = yKy - float(XKy @ beta)
+        dR = dyKy - 2.0 * float(dXKy @ beta) + float(beta @ dXKX @ beta)
+        m = self._df  # n (ML) or n - rank(X) (REML): net power of the scale in the objective
+        d = m * dR / R + dlogdet
+        if self._restricted:
+            d += float(np.trace(_rsolve(XKX, dXKX)))
+        return 0.5 * d * delta * (1.0 - delta)
+
+    def fit(self, verbose=False, polish=False):
+        """``polish=False``: the reference procedure (brent-search, rtol = atol = 1e-6).
+        ``polish=True``: followed by secant steps on the analytic derivative, which pins the
+        optimum to ~1e-12 instead of the ~1e-6 a function-value search can guarantee; this is
+        what the HIP engine does (cellregmap_amd/csrc/nullfit.hip, same statements)."""
+        x, fx, _ = brent.minimize(self._neg_lml_at, a=-LOGMAX, b=LOGMAX, rtol=1e-6, atol=1e-6)
+        if polish:
+            x = self._polish(float(x), float(fx))
         self._x = float(x)
         self._update()
+
+    def _polish(self, x0, f0):
+        xa = x0
+        ga = self._neg_lml_grad_at(xa)
+        if not np.isfinite(ga) or ga == 0.0:
+            return x0
+        xb = xa - 1e-4 if ga > 0.0 else xa + 1e-4
+        gb = self._neg_lml_grad_at(xb)
+        for _ in range(8):
+            if not np.isfinite(gb) or gb == ga:
+                break
+            xn = xb - gb * (xb - xa) / (gb - ga)
+            if not np.isfinite(xn) or abs(xn - x0) > 1e-2:
+                return x0
+            step = abs(xn - xb)
+            xa, ga = xb, gb
+            xb = xn
+            gb = self._neg_lml_grad_at(xb)
+            if gb == 0.0 or step <= 1e-12 * (1.0 + abs(xn)):
+                break
+        if not np.isfinite(gb):
+            return x0
+        fb = self._neg_lml_at(xb)
+        if not (fb <= f0 + 1e-9 * abs(f0)):
+            return x0
+        return xb
 
     # -- fitted quantities ------------------------------------------------------
     @property

@@ -92,3 +92,23 @@ def test_fast_scanner_equals_refit_with_frozen_delta():
         Xa = np.concatenate([X, G[:, [i]]], axis=1)
         ref, _, _ = _dense_lml(y, Xa, H @ H.T, null.delta, False)
         assert_allclose(lmls[i], ref, rtol=1e-10)
+
+
+def test_polish_stays_within_the_reference_tolerance():
+    """The derivative-based polish moves the Brent(1e-6) optimum by less than Brent's own
+    tolerance and lands on a stationary point of the profiled likelihood."""
+    for seed, restricted in ((3, True), (4, False), (5, True)):
+        y, X, H = _problem(seed)
+        QS = economic_qs_linear(H, return_q1=False)
+        a = LMM(y, X, QS, restricted=restricted)
+        b = LMM(y, X, QS, restricted=restricted)
+        a.fit(polish=False)
+        b.fit(polish=True)
+        assert abs(a._x - b._x) <= 2e-6 * (1 + abs(a._x))
+        assert b.lml() >= a.lml() - 1e-12 * abs(a.lml())
+        assert abs(b._neg_lml_grad_at(b._x)) < 1e-9
+        # analytic derivative vs central difference
+        for x in (-1.0, 0.4, 2.0):
+            h = 1e-5
+            num = (b._neg_lml_at(x + h) - b._neg_lml_at(x - h)) / (2 * h)
+            assert abs(num - b._neg_lml_grad_at(x)) < 1e-6 * (1 + abs(num))
