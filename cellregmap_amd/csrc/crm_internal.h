@@ -30,7 +30,7 @@ struct crm_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = crm::CRM_DEFAULT_BLOCK;
-    bool polish = true;  // refine the null-fit optimum beyond Brent's 1e-6 (see nullfit.hip)
+    bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;

@@ -83,10 +83,11 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
 
 /* Block size (variants per internal batch); 0 restores the default. */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
-/* Null-fit convergence.  on = 0: the reference's procedure verbatim (Brent on logit(delta),
- * rtol = atol = 1e-6, glimix-core LMM.fit as called at _cellregmap.py:352).  on = 1 (default):
- * followed by secant steps on the analytic derivative, which makes the optimum -- and therefore
- * Q and the p-value -- insensitive to summation-order noise in the likelihood. */
+/* Null-fit convergence.  on = 0 (default): the reference's procedure verbatim (Brent on
+ * logit(delta), rtol = atol = 1e-6, glimix-core LMM.fit as called at _cellregmap.py:352).
+ * on = 1: followed by secant steps on the analytic derivative, which pins the optimum to ~1e-12
+ * and makes Q and the p-value insensitive to summation-order noise in the likelihood; the result
+ * then differs from the reference's by the reference's own optimiser tolerance (~1e-6 on Q). */
 int crm_set_null_fit_polish(crm_ctx* ctx, int on);
 
 /* ---- instrumentation ----------------------------------------------------------------

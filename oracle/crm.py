@@ -30,9 +30,9 @@ def khatri_rao_halves(hK, E2):
 class OracleCellRegMap:
     """CellRegMap(y, E, W=None, Ls=None, E1=None, hK=None)  (_cellregmap.py:63)."""
 
-    def __init__(self, y, E, W=None, Ls=None, E1=None, hK=None, polish=True):
-        # polish=False is the reference procedure verbatim (Brent, 1e-6); polish=True adds the
-        # derivative-based refinement of the null fit that the HIP engine performs (oracle/lmm.py)
+    def __init__(self, y, E, W=None, Ls=None, E1=None, hK=None, polish=False):
+        # polish=False (default) is the reference procedure verbatim (Brent, 1e-6); polish=True adds
+        # the derivative-based refinement the HIP engine offers as an option (oracle/lmm.py)
         self._polish = bool(polish)
         self._y = np.asarray(y, float).flatten()
         self._E0 = np.asarray(E, float)
@@ -149,7 +149,7 @@ def lrt_pvalues(null_lml, alt_lmls, dof=1):
     return np.clip(pv, epsilon.super_tiny, 1 - epsilon.tiny)
 
 
-def run_interaction(y, E, G, W=None, E1=None, E2=None, hK=None, idx_G=None, polish=True):
+def run_interaction(y, E, G, W=None, E1=None, E2=None, hK=None, idx_G=None, polish=False):
     """_cellregmap.py:547-587.  NB ``idx_G`` is handed over positionally and so
     lands in ``scan_interaction``'s ``idx_E`` slot (:586 vs :318)."""
     E1 = E if E1 is None else E1

@@ -165,8 +165,8 @@ class LMM:
     def fit(self, verbose=False, polish=False):
         """``polish=False``: the reference procedure (brent-search, rtol = atol = 1e-6).
         ``polish=True``: followed by secant steps on the analytic derivative, which pins the
-        optimum to ~1e-12 instead of the ~1e-6 a function-value search can guarantee; this is
-        what the HIP engine does (cellregmap_amd/csrc/nullfit.hip, same statements)."""
+        optimum to ~1e-12 instead of the ~1e-6 a function-value search can guarantee; the HIP
+        engine offers the same option (cellregmap_amd/csrc/nullfit.hip, same statements)."""
         x, fx, _ = brent.minimize(self._neg_lml_at, a=-LOGMAX, b=LOGMAX, rtol=1e-6, atol=1e-6)
         if polish:
             x = self._polish(float(x), float(fx))
