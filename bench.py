@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Throughput of the interaction score test on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = the whole hot path (null fits over the rho grid, Khatri-Rao contraction, score
+statistic, eigenvalues, Davies) over one batch of `--batch` synthetic variants of BASELINE
+config 3 (20 000 cells, 50 contexts, mode C background K o EE' + EE', r ~ 5 000).  Inputs
+(background decomposition, phenotype, genotype panel) are resident in HBM before the timed
+region; the background constructor is timed separately.  N > 1: one process per GPU, variants
+sharded across ranks (weak scaling: every rank runs K steps on its own shard), the only
+collective is the final gather of p-values over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor sheet)
+
+
+def algorithmic_flops(n, r_list, r_star, k0, c):
+    """F_alg per variant-test (dense general G)."""
+    R = float(sum(r_list))
+    return 2.0 * n * R + 2.0 * n * r_star * k0 + n * k0 * (k0 + 1) + 2.0 * n * k0 * (c + 2) + r_star * k0 * (k0 + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="variants per step")
+    ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 (BASELINE.json configs[1] / [2])")
+    ap.add_argument("--cpu-variants", type=int, default=8, help="variants of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--polish", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
+    from cellregmap_amd.synth import CONFIGS, make_cohort
+
+    lib = _lib.load()
+    donors, cells, k0, p_total = CONFIGS[args.config]
+    n = donors * cells
+    steps, warmup, batch = args.steps, args.warmup, args.batch
+    p_need = batch * max(steps, 1)
+    # every rank draws its own shard of variants (same cohort otherwise): seed offset on the panel
+    t0 = time.time()
+    cohort = make_cohort(donors, cells, k0, 16, seed=20)  # phenotype, contexts, kinship factor
+    shard = make_cohort(donors, cells, k0, p_need, seed=1000 + rank, with_phenotype=False)
+    G = shard.G
+    t_data = time.time() - t0
+
+    ctx = _engine._context(local_rank)
+    _lib.check(lib.crm_set_null_fit_polish(ctx, int(args.polish)))
+    t0 = time.time()
+    Ls = get_L_values(cohort.hK, cohort.E)
+    crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, Ls=Ls, device=local_rank)
+    crm._bind_gene()
+    _lib.check(lib.crm_ctx_synchronize(ctx))
+    t_ctor = time.time() - t0
+    ranks = [crm._bg.rank(i) for i in range(len(crm._rho1))]
+    t0 = time.time()
+    panel = GenotypePanel(G, device=local_rank)
+    t_upload = time.time() - t0
+
+    gene = crm._gene
+    pv = np.empty(p_need)
+    rho1 = np.empty(p_need)
+    Q = np.empty(p_need)
+
+    def run_step(i):
+        first = (i % max(steps, 1)) * batch
+        sl = slice(first, first + batch)
+        _lib.check(lib.crm_scan_interaction(
+            gene, panel.handle, first, batch, None, None, _lib.ptr(pv[sl]), _lib.ptr(rho1[sl]), None, None,
+            None, _lib.ptr(Q[sl]), None, None, None, None, None))
+
+    def fence():
+        _lib.check(lib.crm_ctx_synchronize(ctx))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(warmup):
+        run_step(i)
+    fence()
+    _lib.check(lib.crm_kernel_timer_reset(ctx))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kr_ms, kr_n, kr_fl, tot = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.crm_kernel_timer_read(ctx, ctypes.byref(kr_ms), ctypes.byref(kr_n), ctypes.byref(kr_fl),
+                                         ctypes.byref(tot)))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the path's one collective: gather the shard results on every rank (RCCL over xGMI)
+        mine = torch.from_numpy(pv).to("cuda")
+        allpv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allpv, mine)
+        torch.cuda.synchronize()
+    total_variants = steps * batch * world
+    value = total_variants / elapsed
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (Khatri-Rao contraction, FP64 MFMA bound) ----------
+    kr_s = kr_ms.value * 1e-3
+    achieved = kr_fl.value / kr_s * 1e-12 if kr_s > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "gemm_tn_kernel<true> (Khatri-Rao contraction A~ = KR(G,E)' Q0)",
+        "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+        "launches": int(kr_n.value), "avg_launch_ms": round(kr_ms.value / max(kr_n.value, 1), 3),
+        "flops_per_launch": kr_fl.value / max(kr_n.value, 1),
+        "share_of_step_time": round(kr_s / elapsed, 4),
+    }
+    rstar = float(np.mean([ranks[int(round(x * 10))] if len(ranks) > 1 else ranks[0] for x in rho1[: steps * batch]]))
+    f_alg = algorithmic_flops(n, ranks, rstar, k0, cohort.W.shape[1])
+    whole_path_tflops = f_alg * (steps * batch) / elapsed * 1e-12
+
+    # ---- CPU baseline: the oracle (reference-shaped per-variant loop) on this host -------------
+    cpu = None
+    if args.cpu_variants > 0 and world == 1:
+        from oracle.crm import OracleCellRegMap
+
+        t0 = time.time()
+        qs = {}
+        for i, rho in enumerate(crm._rho1):
+            Q0, S0 = crm._bg.read(i, n)
+            qs[rho] = ((Q0,), S0)
+        ocrm = OracleCellRegMap.__new__(OracleCellRegMap)
+        ocrm._polish = False
+        ocrm._y, ocrm._E0, ocrm._W, ocrm._E1 = cohort.y, cohort.E, cohort.W, cohort.E
+        ocrm._Ls, ocrm._rho, ocrm._half, ocrm._qs = Ls, list(crm._rho1), {}, qs
+        t_read = time.time() - t0
+        m = args.cpu_variants
+        ocrm.scan_interaction(G[:, :1])  # warm-up variant, discarded
+        t0 = time.time()
+        opv, _ = ocrm.scan_interaction(G[:, :m])
+        t_cpu = time.time() - t0
+        import threadpoolctl
+
+        blas = threadpoolctl.threadpool_info()
+        nthreads = max([b.get("num_threads", 1) for b in blas] or [1])
+        dev = np.abs(opv - pv[:m]) / np.maximum(opv, 1e-300)
+        cpu = {
+            "value": round(m / t_cpu, 4), "unit": "variant-tests/s", "cores": int(nthreads), "kind": "port",
+            "sample": f"first {m} variants of the GPU shard, scan only (decomposition shared with the GPU run), "
+                      f"numpy on {blas[0].get('internal_api', '?') if blas else '?'} with {nthreads} threads, "
+                      f"host has {os.cpu_count()} logical cpus",
+            "max_rel_dp_vs_gpu": float(dev.max()),
+        }
+    out = {
+        "metric": "variant-tests/sec (interaction test)",
+        "value": round(value, 2), "unit": "variant-tests/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {n} cells x {k0} contexts, mode C background (ranks {min(ranks)}..{max(ranks)}), "
+                        f"{steps} steps x {batch} variants per GPU of the {p_total}-variant panel, 1 gene",
+            "batch_variants": batch, "cells": n, "contexts": k0, "rho_grid": len(ranks),
+            "null_fit": "brent-1e-6" + ("+polish" if args.polish else ""),
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "whole_path": {"algorithmic_flop_per_variant": f_alg, "achieved_tflops": round(whole_path_tflops, 3),
+                       "frac_of_fp64_mfma_peak": round(whole_path_tflops / PEAK_FP64_MFMA_TFLOPS, 4)},
+        "setup_s": {"synthetic_data": round(t_data, 2), "background_constructor": round(t_ctor, 2),
+                    "panel_upload": round(t_upload, 2)},
+        "speedup_vs_cpu_baseline": None if not cpu else round(value / cpu["value"], 1),
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
