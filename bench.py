@@ -126,9 +126,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the path's one collective: gather the shard results on every rank (RCCL over xGMI)
-        mine = torch.from_numpy(pv).to("cuda")
-        allpv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allpv, mine)
+        from cellregmap_amd.distributed import gather_variant_results
+
+        full = gather_variant_results({"pv": pv, "rho1": rho1, "Q": Q}, p_need * world)
+        assert full["pv"].shape == (p_need * world,)
         torch.cuda.synchronize()
     total_variants = steps * batch * world
     value = total_variants / elapsed

@@ -169,7 +169,7 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
     if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !C) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK);
-    const long ldg = round_up(B, 128) + 128, lde = round_up(k0, 16), ldy = round_up(N, 128);
+    const long ldg = round_up(B, 128) + 128, lde = round_up(k0, 32), ldy = round_up(N, 128);
     const int M = B * k0;
     DevBuf bg, be, by, bc, bp;
     CRM_TRY(bg.ensure(sizeof(double) * cp * ldg));

@@ -38,7 +38,7 @@ inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 // Khatri-Rao form: X[i, b*k0 + j] = Gs[i, b] * E[i, j] is formed on the fly.
 struct GemmProblem {
     const double* X;  // plain: [cells x ldx]; KR: Gs [cells x ldx] (first variant of the group)
-    const double* E;  // KR only: [cells x lde]
+    const double* E;  // KR only: [cells x lde], lde >= round_up(k0, 32), zero padded
     const double* Y;  // [cells x ldy]
     double* C;        // [M x ldc]
     long ldx, lde, ldy, ldc;
@@ -49,7 +49,7 @@ struct GemmProblem {
 
 constexpr int GEMM_BM = 128;
 constexpr int GEMM_BN = 128;
-constexpr int GEMM_BK = 8;
+constexpr int GEMM_BK = 16;
 
 // Launch nz problems (device array `probs`), each over `cells` (multiple of GEMM_BK)
 // rows, optionally split into `ksplit` slices along the cell axis (slice s writes

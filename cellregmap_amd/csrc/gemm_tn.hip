@@ -23,7 +23,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int LDT = GEMM_BM + 16;  // LDS row stride of a plain operand tile (doubles)
-constexpr int KR_MAX_PREF = 4;      // prefetch registers per thread for the small KR tiles
 
 __host__ __device__ inline int kr_variants_per_tile(int k0) {
     int nb = GEMM_BM / k0 + 2;
@@ -37,7 +36,11 @@ __host__ __device__ inline int kr_e_stride(int k0) {
     return s;
 }
 
-template <bool KR>
+typedef const double __attribute__((address_space(1))) * gptr_t;   // global (not flat) loads
+typedef const v2d __attribute__((address_space(1))) * gptr2_t;
+
+// KRQ: 8-byte prefetch slots per thread for the G tile of the Khatri-Rao operand
+template <bool KR, int KRQ>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
                                                           int mtiles_max, long cells_per_split,
                                                           long split_stride, int k0) {
@@ -58,62 +61,73 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     const long cell_begin = (long)blockIdx.y * cells_per_split;
     const int stages = (int)(cells_per_split / GEMM_BK);
 
-    // ---- LDS carve-up -------------------------------------------------------------
+    // ---- LDS carve-up (two stages of every tile) --------------------------------------
     const int nb = KR ? kr_variants_per_tile(k0) : 0;
     const int lde_s = KR ? kr_e_stride(k0) : 0;
     double* Ys = smem;                                  // [2][BK][LDT]
     double* Xs = Ys + 2 * GEMM_BK * LDT;                // plain: [2][BK][LDT]
-    double* Gt = Xs;                                    // KR: [2][BK][nb]
-    double* Et = Gt + 2 * GEMM_BK * (KR ? nb : 0);      // KR: [2][BK][lde_s]
+    double* Et = Xs;                                    // KR: [2][BK][lde_s]
+    double* Gt = Et + 2 * GEMM_BK * lde_s;              // KR: [2][BK][nb]
 
-    // ---- global -> register prefetch state --------------------------------------------
-    const int ld_row = tid >> 6;        // 0..3 (+4 on the second pass)
-    const int ld_col = (tid & 63) * 2;  // 16-byte pieces
-    v2d ry[2], rx[2];
-    double rg[KR_MAX_PREF], re[KR_MAX_PREF];
+    // ---- global -> register prefetch ----------------------------------------------------
+    // plain tiles: BK x 128 doubles = BK*64 16-byte pieces, 256 threads -> BK/4 pieces each
+    constexpr int NPF = GEMM_BK / 4;
+    const int ld_row = tid >> 6;        // + 4 per piece
+    const int ld_col = (tid & 63) * 2;
+    v2d ry[NPF], rx[NPF];
+    // KR context tile: BK rows x round32(k0) columns (P.lde >= that, zero padded), 16-byte pieces
+    const int e_pieces_row = KR ? ((k0 + 31) / 32 * 16) : 1;  // 16-byte pieces per row (k0 rounded to 32)
+    constexpr int NPE = GEMM_BK / 4;                        // pieces per thread (lde <= 128)
+    v2d re[NPE];
+    double rg[KRQ];
     const int b0 = KR ? (m0 / k0) : 0;
 
-    const double* Yp = P.Y + (cell_begin + ld_row) * P.ldy + n0 + ld_col;
-    const double* Xp = KR ? nullptr : P.X + (cell_begin + ld_row) * P.ldx + m0 + ld_col;
+    gptr_t Yp = (gptr_t)P.Y + (cell_begin + ld_row) * P.ldy + n0 + ld_col;
+    gptr_t Xp = KR ? (gptr_t)P.X + cell_begin * P.ldx + b0
+                   : (gptr_t)P.X + (cell_begin + ld_row) * P.ldx + m0 + ld_col;
+    gptr_t Ep = KR ? (gptr_t)P.E + cell_begin * P.lde : nullptr;
 
     auto fetch = [&](int s) {
         const long roff = (long)s * GEMM_BK;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            ry[q] = *reinterpret_cast<const v2d*>(Yp + (roff + 4 * q) * P.ldy);
-            if (!KR) rx[q] = *reinterpret_cast<const v2d*>(Xp + (roff + 4 * q) * P.ldx);
+        for (int q = 0; q < NPF; q++) {
+            ry[q] = *(gptr2_t)(Yp + (roff + 4 * q) * P.ldy);
+            if (!KR) rx[q] = *(gptr2_t)(Xp + (roff + 4 * q) * P.ldx);
         }
         if (KR) {
 #pragma unroll
-            for (int q = 0; q < KR_MAX_PREF; q++) {
-                int e = tid + 256 * q;
-                if (e < GEMM_BK * nb) {
-                    int row = e / nb, col = e - row * nb;
-                    rg[q] = P.X[(cell_begin + roff + row) * P.ldx + b0 + col];
-                }
-                if (e < GEMM_BK * k0) {
-                    int row = e / k0, col = e - row * k0;
-                    re[q] = P.E[(cell_begin + roff + row) * P.lde + col];
-                }
+            for (int q = 0; q < NPE; q++) {
+                const int e = tid + 256 * q;          // piece index inside the BK x lde tile
+                const int row = e / e_pieces_row, pc = e - row * e_pieces_row;
+                if (row < GEMM_BK) re[q] = *(gptr2_t)(Ep + (roff + row) * P.lde + 2 * pc);
+            }
+#pragma unroll
+            for (int q = 0; q < KRQ; q++) {
+                const int e = tid + 256 * q;
+                const int row = e / nb, col = e - row * nb;
+                if (row < GEMM_BK) rg[q] = Xp[(roff + row) * P.ldx + col];
             }
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NPF; q++) {
             *reinterpret_cast<v2d*>(Ys + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = ry[q];
             if (!KR)
                 *reinterpret_cast<v2d*>(Xs + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = rx[q];
         }
         if (KR) {
 #pragma unroll
-            for (int q = 0; q < KR_MAX_PREF; q++) {
-                int e = tid + 256 * q;
+            for (int q = 0; q < NPE; q++) {
+                const int e = tid + 256 * q;
+                const int row = e / e_pieces_row, pc = e - row * e_pieces_row;
+                if (row < GEMM_BK && 2 * pc < lde_s)
+                    *reinterpret_cast<v2d*>(Et + (buf * GEMM_BK + row) * lde_s + 2 * pc) = re[q];
+            }
+#pragma unroll
+            for (int q = 0; q < KRQ; q++) {
+                const int e = tid + 256 * q;
                 if (e < GEMM_BK * nb) Gt[buf * GEMM_BK * nb + e] = rg[q];
-                if (e < GEMM_BK * k0) {
-                    int row = e / k0, col = e - row * k0;
-                    Et[(buf * GEMM_BK + row) * lde_s + col] = re[q];
-                }
             }
         }
     };
@@ -135,39 +149,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     }
     const int yb = wn * 64 + l15;
 
+    auto load_frags = [&](int buf, int ks, double (&a)[4], double (&b)[4]) {
+        const int row = buf * GEMM_BK + ks * 4 + lq;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            b[t] = Ys[row * LDT + yb + t * 16];
+            if (KR)
+                a[t] = Gt[row * nb + xg[t]] * Et[row * lde_s + xe[t]];
+            else
+                a[t] = Xs[row * LDT + xa[t]];
+        }
+    };
+
     v4d acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+    auto mma = [&](const double (&a)[4], const double (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    // Software pipeline, one barrier per stage: global loads of stage s+1 are issued first, land in
+    // LDS (other buffer) half way through the stage's matrix work, the barrier sits before the last
+    // k-step, and the first fragments of stage s+1 are read while that k-step runs.
+    constexpr int KS = GEMM_BK / 4;  // k-steps per stage
+    static_assert(KS >= 2, "pipeline needs at least two k-steps per stage");
+    double fa[2][4], fb[2][4];
     fetch(0);
     stash(0);
     __syncthreads();
+    load_frags(0, 0, fa[0], fb[0]);
 
     for (int s = 0; s < stages; s++) {
         const int buf = s & 1;
-        if (s + 1 < stages) fetch(s + 1);
+        const bool more = s + 1 < stages;
+        if (more) fetch(s + 1);
 #pragma unroll
-        for (int ks = 0; ks < GEMM_BK / 4; ks++) {
-            const int row = buf * GEMM_BK + ks * 4 + lq;
-            double a[4], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                b[t] = Ys[row * LDT + yb + t * 16];
-                if (KR)
-                    a[t] = Gt[row * nb + xg[t]] * Et[row * lde_s + xe[t]];
-                else
-                    a[t] = Xs[row * LDT + xa[t]];
+        for (int ks = 0; ks < KS; ks++) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
+                load_frags(buf, ks + 1, fa[nxt], fb[nxt]);
+            } else {
+                __syncthreads();  // every wave has stashed stage s+1 and is done reading `buf^1`
+                if (more) load_frags(buf ^ 1, 0, fa[nxt], fb[nxt]);
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            mma(fa[cur], fb[cur]);
+            if (ks == KS / 2 - 1 && more) stash(buf ^ 1);
         }
-        if (s + 1 < stages) stash(buf ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue: D[row = lq + 4*reg][col = l15] per 16x16 tile ---------------------------
@@ -214,11 +248,15 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
             return CRM_ERR_UNSUPPORTED;
         }
         lds += (size_t)2 * GEMM_BK * (kr_variants_per_tile(k0) + kr_e_stride(k0)) * sizeof(double);
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), lds, st, probs_dev, mt,
-                           cells / ksplit, split_stride, k0);
+        if (GEMM_BK * kr_variants_per_tile(k0) <= 256)
+            hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, dim3(256), lds, st, probs_dev, mt,
+                               cells / ksplit, split_stride, k0);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<true, (GEMM_BK * GEMM_BM + 255) / 256>), grid, dim3(256), lds,
+                               st, probs_dev, mt, cells / ksplit, split_stride, k0);
     } else {
         lds += (size_t)2 * GEMM_BK * LDT * sizeof(double);
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), lds, st, probs_dev, mt,
+        hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, dim3(256), lds, st, probs_dev, mt,
                            cells / ksplit, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());

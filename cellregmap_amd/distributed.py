@@ -1,0 +1,71 @@
+"""Multi-GPU layer of the scan: variants are independent (cellregmap/_cellregmap.py:340), so
+they are sharded across ranks as contiguous blocks with no data-path collective; the one
+exchange is the final gather of the per-variant results (RCCL all_gather over xGMI when the
+process group is ``nccl``; ``gloo`` on CPU in the tests).  One process per GPU.
+"""
+import numpy as np
+
+
+def variant_shard(p, rank, world):
+    """Contiguous shard [first, first + count) of p variants for ``rank`` of ``world``."""
+    base, extra = divmod(int(p), int(world))
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return first, count
+
+
+def gather_variant_results(local, p, group=None):
+    """All-gather per-variant float64 arrays.
+
+    ``local`` maps names to 1-D arrays holding this rank's shard (``variant_shard`` order).
+    Returns the same mapping with the full length-``p`` arrays, on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        return {k: np.asarray(v, float) for k, v in local.items()}
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    names = sorted(local)
+    first, count = variant_shard(p, rank, world)
+    width = variant_shard(p, 0, world)[1]  # rank 0 holds the largest shard
+    pack = torch.zeros((len(names), width), dtype=torch.float64)
+    for i, k in enumerate(names):
+        v = np.asarray(local[k], float)
+        if v.shape != (count,):
+            raise ValueError(f"{k}: expected {count} entries for rank {rank}, got {v.shape}")
+        pack[i, :count] = torch.from_numpy(v)
+    pack = pack.to(device)
+    parts = [torch.empty_like(pack) for _ in range(world)]
+    dist.all_gather(parts, pack, group=group)
+    out = {k: np.empty(p) for k in names}
+    for r, part in enumerate(parts):
+        f, c = variant_shard(p, r, world)
+        part = part.cpu().numpy()
+        for i, k in enumerate(names):
+            out[k][f:f + c] = part[i, :c]
+    return out
+
+
+def scan_interaction_distributed(crm, G, idx_E=None, idx_G=None, group=None, scan=None):
+    """``crm.scan_interaction`` over this rank's shard of the columns of ``G`` followed by the
+    gather; returns the reference's ``(pvalues, info)`` for all variants on every rank.
+
+    ``scan`` overrides the per-shard call (tests inject the CPU oracle)."""
+    import torch.distributed as dist
+
+    G = np.asarray(G, float)
+    p = G.shape[1]
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    first, count = variant_shard(p, rank, world)
+    fn = scan if scan is not None else crm.scan_interaction
+    if count > 0:
+        pv, info = fn(np.ascontiguousarray(G[:, first:first + count]), idx_E, idx_G)
+    else:
+        pv, info = np.empty(0), {k: np.empty(0) for k in ("rho1", "e2", "g2", "eps2")}
+    full = gather_variant_results({"pv": pv, **info}, p, group)
+    return full.pop("pv"), full

@@ -1,0 +1,81 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/crm_hip.h declares;
+the host-side mirror keeps the reference's public surface."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "crm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cellregmap_amd import _lib
+
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert declared, "no prototypes found in include/crm_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in crm_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+    assert lib.crm_version().decode().count(".") == 2
+
+
+def test_public_surface_matches_reference():
+    import cellregmap_amd as pkg
+
+    # cellregmap/__init__.py:1-20
+    for name in ("CellRegMap", "run_association", "run_association_fast", "run_interaction", "estimate_betas",
+                 "Term", "__version__"):
+        assert hasattr(pkg, name)
+    sig = inspect.signature(pkg.CellRegMap.__init__)
+    assert list(sig.parameters)[:7] == ["self", "y", "E", "W", "Ls", "E1", "hK"]  # _cellregmap.py:63
+    sig = inspect.signature(pkg.CellRegMap.scan_interaction)
+    assert list(sig.parameters)[:4] == ["self", "G", "idx_E", "idx_G"]            # :317-319
+    sig = inspect.signature(pkg.run_interaction)
+    assert list(sig.parameters)[:8] == ["y", "E", "G", "W", "E1", "E2", "hK", "idx_G"]  # :547
+    sig = inspect.signature(pkg.run_association)
+    assert list(sig.parameters)[:5] == ["y", "W", "E", "G", "hK"]                 # :471
+    assert pkg.Term.FIXED.value == 1 and pkg.Term.RANDOM.value == 2
+
+
+def test_get_L_values_is_the_hadamard_factorisation():
+    # proof.md: sum_i L_i L_i' == K o EE'
+    from cellregmap_amd import get_L_values
+
+    rng = np.random.default_rng(0)
+    hK = rng.normal(size=(30, 4))
+    E = rng.normal(size=(30, 3))
+    Ls = get_L_values(hK, E)
+    lhs = sum(L @ L.T for L in Ls)
+    assert np.allclose(lhs, (hK @ hK.T) * (E @ E.T), atol=1e-10)
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a GPU the product path must raise, never fall back to a CPU computation."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cellregmap_amd import CellRegMap, _lib
+
+    rng = np.random.default_rng(1)
+    with pytest.raises(_lib.CrmError):
+        CellRegMap(rng.normal(size=20), rng.normal(size=(20, 2)))
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "cellregmap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libcrm_oracle" not in src, f

@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     }
     const long cells = 20000, r = 5120;
     const int k0 = 50;
-    int Bs[] = {128, 512};
+    int Bs[] = {128, 1024};
     double *Q0, *G, *E, *C;
     CK(hipMalloc(&Q0, sizeof(double) * cells * r));
     CK(hipMalloc(&G, sizeof(double) * cells * (1024 + 128)));
