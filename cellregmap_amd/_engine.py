@@ -281,14 +281,35 @@ class CellRegMap:
             return out["pv"], info, extra
         return out["pv"], info
 
-    # -- association scans (_cellregmap.py:246-314): not on the device yet ----------------------------
-    def scan_association(self, G):
-        raise NotImplementedError(
-            "scan_association (LRT, _cellregmap.py:246-281) is not built yet in the MI355X engine")
+    # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
+    def _scan_association(self, G, fast, return_stats=False):
+        lib = _lib.load()
+        panel = G if isinstance(G, GenotypePanel) else GenotypePanel(np.asarray(G, float), self._device)
+        n, p = panel.shape
+        if n != self.n_samples:
+            raise ValueError(f"G has {n} rows, expected {self.n_samples}")
+        if not isinstance(G, GenotypePanel) and not np.all(np.isfinite(np.asarray(G, float))):
+            raise ValueError("There are non-finite values in the covariates matrix.")
+        gene = self._bind_gene()
+        pv = np.empty(p)
+        alt = np.empty(p)
+        null = np.empty(6)
+        _lib.check(lib.crm_scan_association(gene, panel.handle, 0, p, int(bool(fast)), _lib.ptr(pv),
+                                            _lib.ptr(alt), _lib.ptr(null)))
+        info = {"rho1": np.asarray([null[0]], float), "e2": np.asarray([null[1]], float),
+                "g2": np.asarray([null[2]], float), "eps2": np.asarray([null[3]], float)}
+        if return_stats:
+            return pv, info, {"alt_lml": alt, "null_lml": null[4], "null_delta": null[5]}
+        return pv, info
 
-    def scan_association_fast(self, G):
-        raise NotImplementedError(
-            "scan_association_fast (_cellregmap.py:284-314) is not built yet in the MI355X engine")
+    def scan_association(self, G, return_stats: bool = False):
+        """Persistent-effect LRT with a full ML refit per SNP (_cellregmap.py:246-281)."""
+        return self._scan_association(G, False, return_stats)
+
+    def scan_association_fast(self, G, return_stats: bool = False):
+        """Persistent-effect LRT with the covariance ratio frozen at the null model
+        (glimix-core FastScanner; _cellregmap.py:284-314)."""
+        return self._scan_association(G, True, return_stats)
 
     def predict_interaction(self, G, MAF):
         raise NotImplementedError("effect-size estimation is outside the score-test path")

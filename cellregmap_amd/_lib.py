@@ -36,6 +36,7 @@ SIGNATURES = {
                                         ctypes.POINTER(vp)]),
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
+    "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
     "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_set_null_fit_polish": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),

@@ -48,6 +48,31 @@ __global__ __launch_bounds__(256) void variant_stats_kernel(const double* __rest
     }
 }
 
+// any number of covariate columns: one thread per (variant, quantity); q = 0 gg, 1 gy, 2.. gW_i
+__global__ __launch_bounds__(64) void variant_stats_general_kernel(const double* __restrict__ G, long ldg,
+                                                                  long cells, int variants,
+                                                                  const double* __restrict__ yW, long ldw,
+                                                                  double* __restrict__ gg,
+                                                                  double* __restrict__ gy,
+                                                                  double* __restrict__ gW, long ld_gW) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int q = blockIdx.y;
+    if (b >= variants) return;
+    double acc = 0.0;
+    if (q == 0) {
+        for (long i = 0; i < cells; i++) {
+            const double g = G[i * ldg + b];
+            acc += g * g;
+        }
+        gg[b] = acc;
+    } else {
+        const double* col = yW + (q - 1);  // column 0 = y, 1.. = W
+        for (long i = 0; i < cells; i++) acc += G[i * ldg + b] * col[i * ldw];
+        if (q == 1) gy[b] = acc;
+        else gW[(long)b * ld_gW + (q - 2)] = acc;
+    }
+}
+
 __global__ void variant_stats_finish(const double* __restrict__ partial, int variants, int c,
                                      double* __restrict__ gg, double* __restrict__ gy,
                                      double* __restrict__ gW, long ld_gW) {
@@ -143,9 +168,14 @@ int launch_variant_stats(hipStream_t st, const double* G, long ldg, long cells, 
     switch (c) {
         CRM_STATS(1) CRM_STATS(2) CRM_STATS(3) CRM_STATS(4)
         CRM_STATS(5) CRM_STATS(6) CRM_STATS(7) CRM_STATS(8)
-        default:
-            set_error("variant statistics: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV);
-            return CRM_ERR_UNSUPPORTED;
+        default: {
+            // y points at column 0 of the packed [y | W] matrix
+            dim3 g2((variants + 63) / 64, c + 2);
+            hipLaunchKernelGGL(variant_stats_general_kernel, g2, dim3(64), 0, st, G, ldg, cells, variants, y,
+                               ldw, gg, gy, gW, ld_gW);
+            CRM_HIP(hipGetLastError());
+            return CRM_OK;
+        }
     }
 #undef CRM_STATS
     CRM_HIP(hipGetLastError());

@@ -9,6 +9,7 @@ namespace crm {
 constexpr int CRM_DEFAULT_BLOCK = 1024;  // variants per internal batch
 constexpr int CRM_MAX_RHO = 16;    // rho grid points (the reference uses 1 or 11)
 constexpr int CRM_MAX_COV = 8;    // columns of W the interaction null fit is instantiated for
+constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W the association paths accept (LDS null-fit kernel)
 constexpr int CRM_MAX_K0 = 128;   // contexts (columns of E0)
 
 struct DevBuf {

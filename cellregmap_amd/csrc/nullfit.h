@@ -42,7 +42,30 @@ struct NullFitArgs {
     NullFitOut* out;      // [variants]
 };
 
-int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants);
+// c <= CRM_MAX_COV: register kernel (nullfit.hip); larger c (or force_wide): LDS kernel
+// (nullfit_wide.hip).  Both end with the rho* selection into a.out.
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide = false);
+int launch_nullfit_wide(hipStream_t st, const NullFitArgs& a, int variants);
+
+// ---- association paths (assoc.hip) ---------------------------------------------------------------
+struct AssocArgs {
+    const double* T;   // [variants x ldT] rows Q0(rho*)' g
+    const double* ty;  // [r]
+    const double* tW;  // [c x ldW]
+    const double* S0;  // [r]
+    long ldT, ldW;
+    int r, c;
+    long n;
+    double delta0;     // the null model's delta
+    const double* WW; const double* Wy; double yy;
+    const double* gg; const double* gy; const double* gW; long ld_gW;
+};
+size_t fastscan_prep_doubles();
+int launch_fastscan_prep(hipStream_t st, const AssocArgs& a, double* prep, double* wts);
+int launch_fastscan(hipStream_t st, const AssocArgs& a, const double* prep, const double* wts,
+                    int variants, double* alt_lml);
+int launch_lrt(hipStream_t st, const double* alt_lml, double null_lml, int count, double* pv);
+int launch_gather_trial_lml(hipStream_t st, const NullFitTrial* trial, int count, double* out);
 
 // ---- small per-block kernels (blockops.hip) ----------------------------------------------------
 // gg, gy, gW for a block of variants: column reductions of G (cells x ldg), deterministic.

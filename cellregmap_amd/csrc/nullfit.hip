@@ -488,12 +488,15 @@ static void launch_c(hipStream_t st, const NullFitArgs& a, int variants) {
     hipLaunchKernelGGL(nullfit_kernel<C>, dim3(variants, a.nrho), dim3(64), 0, st, a);
 }
 
-int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants) {
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide) {
     if (variants <= 0) return CRM_OK;
     if (a.nrho < 1 || a.nrho > CRM_MAX_RHO) {
         set_error("null fit: %d grid points (supported 1..%d)", a.nrho, CRM_MAX_RHO);
         return CRM_ERR_UNSUPPORTED;
     }
+    if (force_wide || a.c > CRM_MAX_COV) {
+        CRM_TRY(launch_nullfit_wide(st, a, variants));
+    } else
     switch (a.c) {
         case 1: launch_c<1>(st, a, variants); break;
         case 2: launch_c<2>(st, a, variants); break;

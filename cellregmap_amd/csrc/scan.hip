@@ -93,8 +93,8 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
                     int k0, crm_gene** out) {
     if (!bg || !y || !W || !E0 || !out) return CRM_ERR_ARG;
     *out = nullptr;
-    if (c < 1 || c > CRM_MAX_COV) {
-        set_error("gene: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV);
+    if (c < 1 || c > CRM_MAX_COV_WIDE) {
+        set_error("gene: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV_WIDE);
         return CRM_ERR_UNSUPPORTED;
     }
     if (k0 < 1 || k0 > CRM_MAX_K0) {
@@ -235,6 +235,10 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         return CRM_ERR_ARG;
     }
     if (count == 0) return CRM_OK;
+    if (gene->c > CRM_MAX_COV) {
+        set_error("interaction scan: %d covariate columns (supported 1..%d)", gene->c, CRM_MAX_COV);
+        return CRM_ERR_UNSUPPORTED;
+    }
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;

@@ -81,6 +81,15 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
                          double* out_delta, double* out_scale, double* out_lambda, double* out_F);
 
+/* ---- association scans: replace scan_association (fast = 0, _cellregmap.py:246-281: ML refit per
+ * SNP at the null model's rho) and scan_association_fast (fast = 1, :284-314: glimix-core
+ * FastScanner, delta frozen at the null) including lrt_pvalues (:443-469).  The null model (ML,
+ * X = W, first strictly larger lml over the rho grid) is refitted on every call.
+ * out_pvalue / out_alt_lml: `count` entries (may be NULL); out_null: 6 doubles
+ * {rho1, e2, g2, eps2, null lml, null delta} (may be NULL). */
+int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long count, int fast,
+                         double* out_pvalue, double* out_alt_lml, double* out_null);
+
 /* Block size (variants per internal batch); 0 restores the default. */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
 /* Null-fit convergence.  on = 0 (default): the reference's procedure verbatim (Brent on

@@ -1,0 +1,71 @@
+"""Association LRT paths on the GPU vs the CPU oracle (cellregmap/_cellregmap.py:246-314, 443-531).
+
+Tolerance: p-values rtol 1e-5 (north star); the LRT statistic is a difference of two
+log-likelihoods of size ~n, so p carries |d lml| ~ 1e-11 * n of rounding on top."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+
+def _cohort(donors, cells, k, p, seed):
+    from cellregmap_amd.synth import make_cohort
+
+    return make_cohort(donors, cells, k, p, seed=seed)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_scan_association_matches_oracle(fast, mode):
+    from cellregmap_amd import CellRegMap
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(10, 20, 3, 24, seed=21)
+    rng = np.random.default_rng(0)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 2))], axis=1)
+    kw = {"hK": c.hK} if mode == "B" else {}
+    crm = CellRegMap(c.y, c.E, W=W, **kw)
+    ocrm = OracleCellRegMap(c.y, c.E, W=W, **kw)
+    if fast:
+        pv, info, st = crm.scan_association_fast(c.G, return_stats=True)
+        opv, oinfo = ocrm.scan_association_fast(c.G)
+    else:
+        pv, info, st = crm.scan_association(c.G, return_stats=True)
+        opv, oinfo = ocrm.scan_association(c.G)
+    for k in ("rho1", "e2", "g2", "eps2"):
+        assert info[k].shape == (1,)
+        assert_allclose(info[k], oinfo[k], rtol=1e-5, atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
+    # persistent-effect causals of the generator (variants 5, 6) are the top hits
+    assert set(np.argsort(pv)[:2]) == {5, 6}
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_run_association_wrapper_keeps_the_positional_swap(fast):
+    """run_association(y, W, E, G, hK) binds W to the contexts slot and E to the fixed effects
+    (_cellregmap.py:498, :529): the 6 contexts become covariates -> the wide null-fit kernel."""
+    from cellregmap_amd import run_association, run_association_fast
+    from oracle import crm as ocrm
+
+    c = _cohort(12, 15, 6, 16, seed=22)
+    f, of = (run_association_fast, ocrm.run_association_fast) if fast else (run_association, ocrm.run_association)
+    pv, info = f(c.y, c.W, c.E, c.G, hK=c.hK)
+    opv, oinfo = of(c.y, c.W, c.E, c.G, hK=c.hK)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
+
+
+def test_wide_and_register_null_fit_agree():
+    """c = 9 > CRM_MAX_COV forces the LDS kernel; compare with the oracle directly."""
+    from cellregmap_amd import CellRegMap
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(10, 20, 3, 8, seed=23)
+    rng = np.random.default_rng(1)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 8))], axis=1)  # 9 columns
+    pv, info, st = CellRegMap(c.y, c.E, W=W, hK=c.hK).scan_association(c.G, return_stats=True)
+    ocrm = OracleCellRegMap(c.y, c.E, W=W, hK=c.hK)
+    opv, oinfo = ocrm.scan_association(c.G)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
