@@ -4,8 +4,8 @@
 // -> eigvalsh(F) (lower triangle), SKAT's eigenvalue filter, Davies' AS 155 algorithm
 // (chi2comb, lim = 10000, acc = 1e-6), modified-Liu fall-back.  Same procedure as
 // oracle/davies.py + oracle/qfc.c, re-organised for 64 lanes:
-//   * eigenvalues: cyclic Jacobi in LDS with a round-robin pair schedule (k/2 disjoint
-//     rotations per round; lanes over pairs, then over rows / columns);
+//   * eigenvalues: Householder tridiagonalisation in LDS (lanes over the rows of the trailing
+//     block) followed by Sturm-sequence bisection, one eigenvalue index per lane;
 //   * qfc: the scalar search logic (truncation point, cut-offs, step) runs wave-uniform;
 //     every sum over the eigenvalues is lane-parallel + butterfly, and the trapezoid rule
 //     puts one abscissa per lane.
@@ -385,7 +385,7 @@ __device__ double liu_mod_sf(const double* lb, int r, double t, int lane) {
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
-// LDS: A [k][ks] (ks = k | 1), ev [k], kept [k], rotation tables
+// LDS: A [k][ks] (ks = k | 1), ev [k], kept [k], tridiagonal + Householder scratch
 __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict__ Fall,
                                                          const double* __restrict__ Qall, int k,
                                                          double* __restrict__ lambda_out,
@@ -401,8 +401,7 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
     double* kept = ev + k;        // k
     double* rc = kept + k;        // k/2+1 cos
     double* rs = rc + (k / 2 + 1);  // k/2+1 sin
-    int* rp = reinterpret_cast<int*>(rs + (k / 2 + 1));  // pairs p
-    int* rq = rp + (k / 2 + 1);
+    int* rp = reinterpret_cast<int*>(rs + (k / 2 + 1));  // start of the 2k-double Householder scratch
 
     bool bad = false;
     if (do_eig) {
@@ -415,75 +414,113 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
         }
         bad = __any(bad);
         __syncthreads();
-        const int m = k + (k & 1);  // players (a dummy one when k is odd)
-        if (!bad && k > 1) {
-            for (int sweep = 0; sweep < 40; sweep++) {
-                double off = 0.0, dg = 0.0;
-                for (int e = lane; e < k * k; e += 64) {
-                    const int i = e / k, j = e - i * k;
-                    const double v = A[i * ks + j];
-                    if (i == j) dg += v * v; else off += v * v;
+        double* dd = kept;      // diagonal of the tridiagonal form (kept[] is free until the filter)
+        double* ee = rc;        // sub-diagonal, k-1 entries (rc/rs are contiguous: 2*(k/2+1) >= k)
+        double* hv = reinterpret_cast<double*>(rp);  // Householder vector / w, 2k doubles (see launch)
+        double* hw = hv + k;
+        if (!bad && k > 2) {
+            // Householder tridiagonalisation of the full symmetric matrix (LAPACK dsytd2, lower),
+            // lanes over the rows of the trailing block
+            for (int j = 0; j < k - 2; j++) {
+                const int m = k - j - 1;
+                double sig = 0.0;
+                for (int i = lane; i < m; i += 64) {
+                    const double x = A[(j + 1 + i) * ks + j];
+                    hv[i] = x;
+                    if (i >= 1) sig += x * x;
                 }
-                off = wsum(off);
-                dg = wsum(dg);
-                if (off <= 1e-33 * (dg + off) || off == 0.0) break;
-                for (int rd = 0; rd < m - 1; rd++) {
-                    // rotation angles, one pair per lane
-                    for (int s = lane; s < m / 2; s += 64) {
-                        int p, qq;
-                        if (s == 0) { p = m - 1; qq = rd; }
-                        else { p = (rd + s) % (m - 1); qq = (rd - s + (m - 1)) % (m - 1); }
-                        double cs = 1.0, sn = 0.0;
-                        if (p < k && qq < k) {
-                            const double apq = A[p * ks + qq];
-                            if (apq != 0.0) {
-                                const double theta = (A[qq * ks + qq] - A[p * ks + p]) / (2.0 * apq);
-                                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                                cs = 1.0 / sqrt(t * t + 1.0);
-                                sn = t * cs;
-                            }
-                        } else {
-                            p = -1;
-                        }
-                        rp[s] = p; rq[s] = qq; rc[s] = cs; rs[s] = sn;
-                    }
+                sig = wsum(sig);
+                __syncthreads();
+                const double alpha = hv[0];
+                double tau = 0.0, beta = alpha;
+                if (sig != 0.0) {
+                    beta = -copysign(sqrt(alpha * alpha + sig), alpha);
+                    tau = (beta - alpha) / beta;
+                    const double sc = 1.0 / (alpha - beta);
                     __syncthreads();
-                    // A <- A J : lanes over rows
-                    for (int i = lane; i < k; i += 64) {
-                        for (int s = 0; s < m / 2; s++) {
-                            const int p = rp[s], qq = rq[s];
-                            if (p < 0) continue;
-                            const double cs = rc[s], sn = rs[s];
-                            const double aip = A[i * ks + p], aiq = A[i * ks + qq];
-                            A[i * ks + p] = cs * aip - sn * aiq;
-                            A[i * ks + qq] = sn * aip + cs * aiq;
-                        }
+                    for (int i = lane; i < m; i += 64) hv[i] = i == 0 ? 1.0 : hv[i] * sc;
+                }
+                if (lane == 0) {
+                    dd[j] = A[j * ks + j];
+                    ee[j] = beta;
+                }
+                __syncthreads();
+                if (tau != 0.0) {
+                    double pv = 0.0;
+                    for (int i = lane; i < m; i += 64) {
+                        const double* row = A + (j + 1 + i) * ks + (j + 1);
+                        double p = 0.0;
+                        for (int cidx = 0; cidx < m; cidx++) p += row[cidx] * hv[cidx];
+                        p *= tau;
+                        hw[i] = p;
+                        pv += p * hv[i];
                     }
+                    pv = wsum(pv);
+                    const double a2 = -0.5 * tau * pv;
                     __syncthreads();
-                    // A <- J' A : lanes over columns
-                    for (int j = lane; j < k; j += 64) {
-                        for (int s = 0; s < m / 2; s++) {
-                            const int p = rp[s], qq = rq[s];
-                            if (p < 0) continue;
-                            const double cs = rc[s], sn = rs[s];
-                            const double apj = A[p * ks + j], aqj = A[qq * ks + j];
-                            A[p * ks + j] = cs * apj - sn * aqj;
-                            A[qq * ks + j] = sn * apj + cs * aqj;
-                        }
+                    for (int i = lane; i < m; i += 64) hw[i] += a2 * hv[i];
+                    __syncthreads();
+                    for (int i = lane; i < m; i += 64) {
+                        double* row = A + (j + 1 + i) * ks + (j + 1);
+                        const double vi = hv[i], wi = hw[i];
+                        for (int cidx = 0; cidx < m; cidx++) row[cidx] -= vi * hw[cidx] + wi * hv[cidx];
                     }
                     __syncthreads();
                 }
             }
         }
-        // ascending rank sort of the diagonal
-        for (int i = lane; i < k; i += 64) {
-            const double v = A[i * ks + i];
-            int rank = 0;
-            for (int j = 0; j < k; j++) {
-                const double w = A[j * ks + j];
-                rank += (w < v) || (w == v && j < i);
+        if (lane == 0) {
+            if (k == 1) {
+                dd[0] = A[0];
+            } else if (k == 2) {
+                dd[0] = A[0]; dd[1] = A[ks + 1]; ee[0] = A[ks];
+            } else {
+                dd[k - 2] = A[(k - 2) * ks + (k - 2)];
+                dd[k - 1] = A[(k - 1) * ks + (k - 1)];
+                ee[k - 2] = A[(k - 1) * ks + (k - 2)];
             }
-            ev[rank] = v;
+        }
+        __syncthreads();
+        // eigenvalues of the tridiagonal matrix by Sturm bisection (LAPACK dstebz), one index per lane
+        double gl = INFINITY, gu = -INFINITY, emax = 0.0;
+        for (int i = lane; i < k; i += 64) {
+            const double lo = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i < k - 1 ? fabs(ee[i]) : 0.0);
+            gl = fmin(gl, dd[i] - lo);
+            gu = fmax(gu, dd[i] + lo);
+            if (i < k - 1) emax = fmax(emax, ee[i] * ee[i]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            gl = fmin(gl, __shfl_xor(gl, off, 64));
+            gu = fmax(gu, __shfl_xor(gu, off, 64));
+            emax = fmax(emax, __shfl_xor(emax, off, 64));
+        }
+        const double eps = 2.220446049250313e-16, safemin = 2.2250738585072014e-308;
+        const double pivmin = safemin * fmax(1.0, emax);
+        const double tnorm = fmax(fabs(gl), fabs(gu));
+        gl -= 2.1 * tnorm * eps * k + 2.1 * pivmin;
+        gu += 2.1 * tnorm * eps * k + 2.1 * pivmin;
+        const double atol = 2.0 * eps * tnorm + 2.0 * pivmin;
+        if (!bad) {
+            for (int idx = lane; idx < k; idx += 64) {
+                double lo = gl, hi = gu;
+                for (int it = 0; it < 200; it++) {
+                    const double mid = 0.5 * (lo + hi);
+                    if (hi - lo <= fmax(atol, 2.0 * eps * fmax(fabs(lo), fabs(hi))) || mid == lo || mid == hi) break;
+                    // number of eigenvalues below mid
+                    int cnt = 0;
+                    double q = dd[0] - mid;
+                    if (fabs(q) < pivmin) q = -pivmin;
+                    cnt += q < 0.0;
+                    for (int i = 1; i < k; i++) {
+                        q = dd[i] - mid - ee[i - 1] * ee[i - 1] / q;
+                        if (fabs(q) < pivmin) q = -pivmin;
+                        cnt += q < 0.0;
+                    }
+                    if (cnt > idx) hi = mid; else lo = mid;
+                }
+                ev[idx] = 0.5 * (lo + hi);
+            }
         }
         __syncthreads();
         for (int i = lane; i < k; i += 64) lambda_out[(long)b * k + i] = bad ? NAN : ev[i];
@@ -550,7 +587,9 @@ int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int coun
         return CRM_ERR_UNSUPPORTED;
     }
     const int ks = k | 1;
-    size_t lds = sizeof(double) * ((size_t)k * ks + 2 * k + 2 * (k / 2 + 1)) + sizeof(int) * 2 * (k / 2 + 1);
+    // A [k x ks], ev [k], kept [k] (doubles as the tridiagonal's diagonal), rc/rs [2*(k/2+1)] (its
+    // sub-diagonal), then 2k doubles for the Householder vectors
+    size_t lds = sizeof(double) * ((size_t)k * ks + 2 * k + 2 * (k / 2 + 1) + 2 * k);
     lds = (lds + 15) / 16 * 16;
     hipLaunchKernelGGL(eig_davies_kernel, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
                        ifault, liu, do_eig ? 1 : 0);
