@@ -176,9 +176,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     };
 
     // Software pipeline, one barrier per stage: global loads of stage s+1 are issued first, land in
-    // LDS (other buffer) half way through the stage's matrix work, the barrier sits before the last
+    // LDS (other buffer) after the last-but-one k-step of the stage, the barrier sits before the last
     // k-step, and the first fragments of stage s+1 are read while that k-step runs.
     constexpr int KS = GEMM_BK / 4;  // k-steps per stage
+    constexpr int STASH_AFTER = KS - 2;  // latest point that still precedes the stage's barrier
     static_assert(KS >= 2, "pipeline needs at least two k-steps per stage");
     double fa[2][4], fb[2][4];
     fetch(0);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
                 if (more) load_frags(buf ^ 1, 0, fa[nxt], fb[nxt]);
             }
             mma(fa[cur], fb[cur]);
-            if (ks == KS / 2 - 1 && more) stash(buf ^ 1);
+            if (ks == STASH_AFTER && more) stash(buf ^ 1);
         }
     }
 
