@@ -7,6 +7,7 @@ from enum import Enum
 from ._engine import (
     CellRegMap,
     GenotypePanel,
+    detect_groups,
     estimate_betas,
     get_L_values,
     lrt_pvalues,
@@ -29,6 +30,7 @@ __all__ = [
     "__version__",
     "CellRegMap",
     "GenotypePanel",
+    "detect_groups",
     "run_association",
     "run_association_fast",
     "run_interaction",

@@ -126,22 +126,83 @@ def background_from_qs(qs_list, rho, device=0):
     return _Background(h, rho, device)
 
 
-class GenotypePanel:
-    """A genotype matrix (n x p) resident in HBM; build once, scan many genes against it."""
+def detect_groups(G, max_groups=2048, sample_columns=64, chunk=2048):
+    """Find the donor structure of an expanded genotype matrix: groups of cells whose rows are
+    identical in every variant.  Returns ``(group_of_cell int32 (n,), rows_of_representatives)``
+    or ``None`` when the rows do not collapse (more than ``max_groups`` or n/2 distinct rows).
+    Candidates come from a column sample; every column is then verified exactly."""
+    G = np.asarray(G)
+    n, p = G.shape
+    cols = np.unique(np.linspace(0, p - 1, min(p, sample_columns)).astype(int))
+    key = np.ascontiguousarray(G[:, cols])
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    m = first.size
+    if m > max_groups or m > n // 2:
+        return None
+    rep = first[inv]
+    for c0 in range(0, p, chunk):
+        blk = G[:, c0:c0 + chunk]
+        if not np.array_equal(blk, blk[rep]):
+            return None
+    # label groups in order of first appearance
+    order = np.argsort(first, kind="stable")
+    relabel = np.empty(m, np.int32)
+    relabel[order] = np.arange(m, dtype=np.int32)
+    return relabel[inv].astype(np.int32), first[order]
 
-    def __init__(self, G, device=0):
+
+class GenotypePanel:
+    """A genotype matrix (n x p) resident in HBM; build once, scan many genes against it.
+
+    ``groups``: ``"auto"`` (default) looks for the donor structure of expanded genotypes
+    (``detect_groups``) and, when found, stores one row per donor -- scans then run the exact
+    donor-collapsed path; ``None`` keeps the matrix dense (general G)."""
+
+    def __init__(self, G, device=0, groups="auto"):
         lib = _lib.load()
         G = np.asarray(G, float)
         assert G.ndim == 2
-        if not G.flags.c_contiguous:
-            G = np.ascontiguousarray(G)
         self.shape = G.shape
         self.device = device
+        self.n_groups = None
         h = ctypes.c_void_p()
-        _lib.check(lib.crm_panel_create(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
-                                        ctypes.byref(h)))
+        found = detect_groups(G) if isinstance(groups, str) and groups == "auto" else None
+        if found is not None:
+            group, reps = found
+            Gd = np.ascontiguousarray(G[reps, :])
+            self._create_grouped(lib, group, Gd, device, h)
+        else:
+            if not G.flags.c_contiguous:
+                G = np.ascontiguousarray(G)
+            _lib.check(lib.crm_panel_create(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
+                                            ctypes.byref(h)))
         self.handle = h
         self._fin = weakref.finalize(self, lib.crm_panel_destroy, h)
+
+    def _create_grouped(self, lib, group, Gd, device, h):
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        Gd = _lib.f64(Gd)
+        self.n_groups = int(Gd.shape[0])
+        _lib.check(lib.crm_panel_create_grouped(_context(device), group.shape[0], _lib.ptr(group), Gd.shape[0],
+                                                _lib.ptr(Gd), Gd.shape[1], Gd.shape[1], ctypes.byref(h)))
+
+    @classmethod
+    def from_donors(cls, Gd, donor_of_cell, device=0):
+        """Panel from donor-level genotypes (m x p) and the donor index of every cell (n,),
+        without materialising the expanded n x p matrix."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        Gd = np.asarray(Gd, float)
+        donor_of_cell = np.asarray(donor_of_cell)
+        assert Gd.ndim == 2 and donor_of_cell.ndim == 1
+        self.shape = (donor_of_cell.shape[0], Gd.shape[1])
+        self.device = device
+        h = ctypes.c_void_p()
+        self._create_grouped(lib, donor_of_cell, Gd, device, h)
+        self.handle = h
+        self._fin = weakref.finalize(self, lib.crm_panel_destroy, h)
+        return self
 
 
 class CellRegMap:
@@ -234,6 +295,20 @@ class CellRegMap:
         self._gene_fin = weakref.finalize(self, lib.crm_gene_destroy, h)
         return h
 
+    def _panel(self, G):
+        if isinstance(G, GenotypePanel):
+            panel = G
+        else:
+            G = np.asarray(G, float)
+            if G.ndim != 2 or G.shape[0] != self.n_samples:
+                raise ValueError(f"G must be {self.n_samples} x p, got {G.shape}")
+            if not np.all(np.isfinite(G)):
+                raise ValueError("There are non-finite values in the covariates matrix.")
+            panel = GenotypePanel(G, self._device)
+        if panel.shape[0] != self.n_samples:
+            raise ValueError(f"G has {panel.shape[0]} rows, expected {self.n_samples}")
+        return panel
+
     # -- interaction scan (_cellregmap.py:317-440) ----------------------------------------------
     def scan_interaction(self, G, idx_E: Optional[any] = None, idx_G: Optional[any] = None,
                          return_stats: bool = False):
@@ -243,12 +318,8 @@ class CellRegMap:
         (:439-440); with ``return_stats=True`` additionally a dict holding Q, the eigenvalues
         of F, F itself and the null-fit scalars (for parity tests)."""
         lib = _lib.load()
-        panel = G if isinstance(G, GenotypePanel) else GenotypePanel(np.asarray(G, float), self._device)
+        panel = self._panel(G)
         n, p = panel.shape
-        if n != self.n_samples:
-            raise ValueError(f"G has {n} rows, expected {self.n_samples}")
-        if not isinstance(G, GenotypePanel) and not np.all(np.isfinite(np.asarray(G, float))):
-            raise ValueError("There are non-finite values in the covariates matrix.")
         gene = self._bind_gene()
         k0 = self._E0.shape[1]
 
@@ -284,12 +355,8 @@ class CellRegMap:
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False):
         lib = _lib.load()
-        panel = G if isinstance(G, GenotypePanel) else GenotypePanel(np.asarray(G, float), self._device)
+        panel = self._panel(G)
         n, p = panel.shape
-        if n != self.n_samples:
-            raise ValueError(f"G has {n} rows, expected {self.n_samples}")
-        if not isinstance(G, GenotypePanel) and not np.all(np.isfinite(np.asarray(G, float))):
-            raise ValueError("There are non-finite values in the covariates matrix.")
         gene = self._bind_gene()
         pv = np.empty(p)
         alt = np.empty(p)

@@ -34,6 +34,9 @@ SIGNATURES = {
     "crm_gene_destroy": (None, [vp]),
     "crm_panel_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long,
                                         ctypes.POINTER(vp)]),
+    "crm_panel_create_grouped": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_long,
+                                                ctypes.c_long, ctypes.POINTER(vp)]),
+    "crm_set_donor_collapse": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
     "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),

@@ -112,8 +112,12 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     for (long done = 0; done < count; done += BLK) {
         const int nb = (int)std::min<long>(BLK, count - done);
         double* Gb = ctx->ws_Gb.as<double>();
-        CRM_TRY(launch_gather_block(st, panel->G.as<double>() + first + done, panel->ld, np, n, nullptr, nullptr,
-                                    nb, Gb, ldb, (int)ldb));
+        if (panel->grouped)
+            CRM_TRY(launch_expand_block(st, panel->Gd.as<double>() + first + done, panel->ld, panel->group.as<int>(),
+                                        np, n, nullptr, nb, Gb, ldb, (int)ldb));
+        else
+            CRM_TRY(launch_gather_block(st, panel->G.as<double>() + first + done, panel->ld, np, n, nullptr, nullptr,
+                                        nb, Gb, ldb, (int)ldb));
         CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, ld_gW));
         GemmProblem p{};
         p.X = Gb; p.ldx = ldb; p.Y = bg->Q0[ri].as<double>(); p.ldy = ldq;

@@ -103,6 +103,44 @@ __global__ void gather_block_kernel(const double* __restrict__ src, long ld_src,
     dst[i * ld_dst + j] = v;
 }
 
+__global__ void expand_block_kernel(const double* __restrict__ Gd, long ld_gd, const int* __restrict__ group,
+                                    long cells, const int* __restrict__ row_index, int variants,
+                                    double* __restrict__ dst, long ld_dst, int dst_cols) {
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    const long i = blockIdx.x;
+    if (j >= dst_cols) return;
+    double v = 0.0;
+    if (i < cells && j < variants) {
+        const long si = row_index ? row_index[i] : i;
+        v = Gd[(long)group[si] * ld_gd + j];
+    }
+    dst[i * ld_dst + j] = v;
+}
+
+__global__ void indicator_kernel(const int* __restrict__ group, long cells, int m, double* __restrict__ Z,
+                                 long ldz) {
+    const int d = blockIdx.y * blockDim.x + threadIdx.x;
+    const long i = blockIdx.x;
+    if (d >= ldz) return;
+    Z[i * ldz + d] = (i < cells && d < m && group[i] == d) ? 1.0 : 0.0;
+}
+
+__global__ void donor_stats_kernel(const double* __restrict__ Gam, long ld_gam, int m, int variants,
+                                   const double* __restrict__ sums, int c, double* __restrict__ gg,
+                                   double* __restrict__ gy, double* __restrict__ gW, long ld_gW) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;  // 0 gg, 1 gy, 2.. gW
+    if (b >= variants) return;
+    double acc = 0.0;
+    for (int d = 0; d < m; d++) {
+        const double g = Gam[(long)d * ld_gam + b];
+        acc += (q == 0 ? g * g : g) * sums[d * 16 + q];
+    }
+    if (q == 0) gg[b] = acc;
+    else if (q == 1) gy[b] = acc;
+    else gW[(long)b * ld_gW + (q - 2)] = acc;
+}
+
 __global__ void square_block_kernel(const double* __restrict__ Gt, const double* __restrict__ G,
                                     long ldg, long ldg_t, int cols, double* __restrict__ G2,
                                     double* __restrict__ GG, long ld_out) {
@@ -195,6 +233,33 @@ int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cel
     dim3 grid((unsigned)cells_pad, (dst_cols + 255) / 256);
     hipLaunchKernelGGL(gather_block_kernel, grid, dim3(256), 0, st, src, ld_src, cells_pad, cells,
                        row_index, col_index, variants, dst, ld_dst, dst_cols);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
+                        long cells, const int* row_index, int variants, double* dst, long ld_dst,
+                        int dst_cols) {
+    dim3 grid((unsigned)cells_pad, (dst_cols + 255) / 256);
+    hipLaunchKernelGGL(expand_block_kernel, grid, dim3(256), 0, st, Gd, ld_gd, group, cells, row_index, variants,
+                       dst, ld_dst, dst_cols);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_indicator(hipStream_t st, const int* group, long cells, long cells_pad, int m, double* Z, long ldz) {
+    dim3 grid((unsigned)cells_pad, (unsigned)((ldz + 127) / 128));
+    hipLaunchKernelGGL(indicator_kernel, grid, dim3(128), 0, st, group, cells, m, Z, ldz);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_donor_stats(hipStream_t st, const double* Gam, long ld_gam, int m, int variants,
+                       const double* sums, int c, double* gg, double* gy, double* gW, long ld_gW) {
+    if (variants <= 0) return CRM_OK;
+    dim3 grid((variants + 127) / 128, c + 2);
+    hipLaunchKernelGGL(donor_stats_kernel, grid, dim3(128), 0, st, Gam, ld_gam, m, variants, sums, c, gg, gy, gW,
+                       ld_gW);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

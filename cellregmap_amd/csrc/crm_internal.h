@@ -11,6 +11,7 @@ constexpr int CRM_MAX_RHO = 16;    // rho grid points (the reference uses 1 or 1
 constexpr int CRM_MAX_COV = 8;    // columns of W the interaction null fit is instantiated for
 constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W the association paths accept (LDS null-fit kernel)
 constexpr int CRM_MAX_K0 = 128;   // contexts (columns of E0)
+constexpr int BLOCK_SLACK_MAX = 4096;  // groups of a donor-constant panel
 
 struct DevBuf {
     void* ptr = nullptr;
@@ -31,6 +32,7 @@ struct crm_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = crm::CRM_DEFAULT_BLOCK;
+    bool collapse = true;  // use the donor-collapsed path for grouped panels
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
     bool timing = false;

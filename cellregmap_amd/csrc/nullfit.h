@@ -77,6 +77,15 @@ size_t variant_stats_workspace(int variants, int c);
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols);
+// dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]
+int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
+                        long cells, const int* row_index, int variants, double* dst, long ld_dst,
+                        int dst_cols);
+// Z[i, d] = (group[i] == d)
+int launch_indicator(hipStream_t st, const int* group, long cells, long cells_pad, int m, double* Z, long ldz);
+// collapsed statistics: gg = sum_d gamma^2 n_d, gy = sum_d gamma ysum_d, gW likewise (sums: [m_pad x 16])
+int launch_donor_stats(hipStream_t st, const double* Gam, long ld_gam, int m, int variants,
+                       const double* sums, int c, double* gg, double* gy, double* gW, long ld_gW);
 // G2 = Gt o Gt, GG = Gt o G
 int launch_square_block(hipStream_t st, const double* Gt, const double* G, long ldg, long ldg_t,
                         long cells_pad, int cols, double* G2, double* GG, long ld_out);

@@ -34,10 +34,23 @@ struct crm_gene {
     // features of the (possibly row-permuted) contexts, rebuilt per scan call
     crm::DevBuf Ep, YE, EE, idx;
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
+    // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
+    const crm_panel* dt_panel = nullptr;
+    crm::DevBuf dt_TZ;    // [nrho][m_pad x ldq]          Z' Q0(rho)
+    crm::DevBuf dt_Bd;    // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
+    crm::DevBuf dt_Z1, dt_Z2, dt_Z3;  // [m_pad x ld]     Z'[y o E, W o E],  Z'E,  Z'(E (x) E)
+    crm::DevBuf dt_sums;  // [m_pad x 16]: column 0 group size, 1 sum y, 2.. sum W_i
 };
 
 struct crm_panel {
     crm_ctx* ctx = nullptr;
     long n = 0, n_pad = 0, p = 0, ld = 0;
-    crm::DevBuf G;  // [n_pad x ld]
+    crm::DevBuf G;  // dense: [n_pad x ld]
+    // grouped (donor-constant) panel: cell i carries the genotypes of group[i]
+    bool grouped = false;
+    long m = 0, m_pad = 0;
+    crm::DevBuf Gd;     // [m_pad x ld] one row per donor
+    crm::DevBuf group;  // int[n]
+    crm::DevBuf Z;      // [n_pad x ldz] 0/1 indicator of the groups (operand of the table builds)
+    long ldz = 0;
 };

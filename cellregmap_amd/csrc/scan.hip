@@ -183,7 +183,9 @@ void crm_gene_destroy(crm_gene* g) {
     if (!g) return;
     (void)hipSetDevice(g->bg->ctx->device);
     (void)hipStreamSynchronize(g->bg->ctx->stream);
-    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx}) b->release();
+    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_TZ, &g->dt_Bd,
+                    &g->dt_Z1, &g->dt_Z2, &g->dt_Z3, &g->dt_sums})
+        b->release();
     delete g;
 }
 
@@ -211,8 +213,140 @@ void crm_panel_destroy(crm_panel* P) {
     (void)hipSetDevice(P->ctx->device);
     (void)hipStreamSynchronize(P->ctx->stream);
     P->G.release();
+    P->Gd.release();
+    P->group.release();
+    P->Z.release();
     delete P;
 }
+
+// ---- grouped (donor-constant) panel --------------------------------------------------------------
+int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
+                             long p, crm_panel** out) {
+    if (!ctx || !group || !Gd || !out || n <= 0 || m <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
+    *out = nullptr;
+    for (long i = 0; i < n; i++) {
+        if (group[i] < 0 || group[i] >= m) {
+            set_error("grouped panel: group index %d at cell %ld outside [0, %ld)", group[i], i, m);
+            return CRM_ERR_ARG;
+        }
+    }
+    CRM_HIP(hipSetDevice(ctx->device));
+    crm_panel* P = new crm_panel();
+    P->ctx = ctx;
+    P->n = n;
+    P->n_pad = round_up(n, CELL_PAD);
+    P->p = p;
+    P->ld = round_up(p, 128);
+    P->grouped = true;
+    P->m = m;
+    P->m_pad = round_up(m, GEMM_BK);
+    P->ldz = round_up(m, 128) + 128;
+    int rc = P->Gd.ensure(sizeof(double) * P->m_pad * P->ld);
+    if (rc == CRM_OK) rc = upload_padded(ctx->stream, P->Gd.as<double>(), P->ld, P->m_pad, Gd, ldg, m, p);
+    if (rc == CRM_OK) rc = P->group.ensure(sizeof(int) * n);
+    if (rc == CRM_OK) rc = P->Z.ensure(sizeof(double) * P->n_pad * P->ldz);
+    if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
+    CRM_HIP(hipMemcpyAsync(P->group.ptr, group, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_indicator(ctx->stream, P->group.as<int>(), n, P->n_pad, (int)m, P->Z.as<double>(), P->ldz);
+    if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = P;
+    return CRM_OK;
+}
+
+int crm_set_donor_collapse(crm_ctx* ctx, int on) {
+    if (!ctx) return CRM_ERR_ARG;
+    ctx->collapse = on != 0;
+    return CRM_OK;
+}
+
+}  // extern "C"
+
+namespace crm {
+
+__global__ void donor_sums_kernel(const int* __restrict__ group, long cells, int m, const double* __restrict__ yW,
+                                  long ldw, int c, double* __restrict__ sums) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;  // 0 count, 1 y, 2.. W
+    if (d >= m) return;
+    double acc = 0.0;
+    for (long i = 0; i < cells; i++)
+        if (group[i] == d) acc += q == 0 ? 1.0 : yW[i * ldw + (q - 1)];
+    sums[d * 16 + q] = acc;
+}
+
+// Per-donor tables of the collapsed path: every n-length contraction of the scan is linear in
+// diag(g) (or diag(g)^2 = sum_d gamma_d^2 diag(z_d) for donor-constant g), so it is taken once per donor
+// indicator z_d with the same kernels and afterwards combined with the donor dosages gamma.
+static int build_donor_tables(crm_gene* gene, const crm_panel* panel) {
+    crm_background* bg = gene->bg;
+    crm_ctx* ctx = bg->ctx;
+    hipStream_t st = ctx->stream;
+    const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
+    const int nrho = bg->nrho, c = gene->c, k0 = gene->k0;
+    const long m = panel->m, mp = panel->m_pad;
+    const int npair = k0 * (k0 + 1) / 2;
+    const long ldZ1 = gene->ld_ye, ldZ2 = gene->ld_ep, ldZ3 = gene->ld_ee;
+    CRM_TRY(gene->dt_TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
+    CRM_TRY(gene->dt_Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
+    CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * 16));
+    CRM_HIP(hipMemsetAsync(gene->dt_TZ.ptr, 0, sizeof(double) * (size_t)nrho * mp * ldq, st));
+    CRM_HIP(hipMemsetAsync(gene->dt_Bd.ptr, 0, sizeof(double) * (size_t)nrho * mp * k0 * ldq, st));
+    CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * 16, st));
+    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
+    GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
+    std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
+    const double* Z = panel->Z.as<double>();
+    for (int i = 0; i < nrho; i++) {
+        GemmProblem p{};
+        p.X = Z; p.ldx = panel->ldz; p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+        p.C = gene->dt_TZ.as<double>() + (size_t)i * mp * ldq; p.ldc = ldq;
+        p.M = (int)m; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+        probs[i] = p;
+    }
+    CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+    CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m, (int)ldq, np, false, 0, 1, 0));
+    CRM_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < nrho; i++) {
+        GemmProblem p{};
+        p.X = Z; p.ldx = panel->ldz; p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
+        p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+        p.C = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
+        p.M = (int)m * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+        probs[i] = p;
+    }
+    CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+    CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m * k0, (int)ldq, np, true, k0, 1, 0));
+    CRM_HIP(hipStreamSynchronize(st));
+    // side tables (split over the cell axis: only one M tile)
+    struct { DevBuf* buf; const double* Y; long ldy; int N; long ld; } side[3] = {
+        {&gene->dt_Z1, gene->YE.as<double>(), gene->ld_ye, k0 * (1 + c), ldZ1},
+        {&gene->dt_Z2, gene->Ep.as<double>(), gene->ld_ep, k0, ldZ2},
+        {&gene->dt_Z3, gene->EE.as<double>(), gene->ld_ee, npair, ldZ3}};
+    for (auto& sd : side) {
+        const int ks = pick_split(np, sd.ld / GEMM_BN);
+        const long sz = mp * sd.ld;
+        CRM_TRY(sd.buf->ensure(sizeof(double) * (size_t)sz * ks));
+        CRM_HIP(hipMemsetAsync(sd.buf->ptr, 0, sizeof(double) * (size_t)sz * ks, st));
+        GemmProblem p{};
+        p.X = Z; p.ldx = panel->ldz; p.Y = sd.Y; p.ldy = sd.ldy; p.C = sd.buf->as<double>(); p.ldc = sd.ld;
+        p.M = (int)m; p.N = sd.N;
+        CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)m, sd.N, np, false, 0, ks, sz));
+        CRM_TRY(launch_reduce_splits(st, sd.buf->as<double>(), sz, ks, sz));
+        CRM_HIP(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(donor_sums_kernel, dim3((unsigned)((m + 63) / 64), c + 2), dim3(64), 0, st,
+                       panel->group.as<int>(), n, (int)m, gene->yW.as<double>(), gene->ld_yw, c,
+                       gene->dt_sums.as<double>());
+    CRM_HIP(hipGetLastError());
+    CRM_HIP(hipStreamSynchronize(st));
+    return CRM_OK;
+}
+
+}  // namespace crm
+
+extern "C" {
 
 // ---- the scan ---------------------------------------------------------------------------------
 int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
@@ -229,6 +363,10 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     if (panel->n != bg->n) {
         set_error("scan: panel has %ld cells, background has %ld", panel->n, bg->n);
         return CRM_ERR_ARG;
+    }
+    if (panel->grouped && panel->m + 1 > BLOCK_SLACK_MAX) {
+        set_error("scan: grouped panel with %ld groups (supported up to %d)", panel->m, BLOCK_SLACK_MAX - 1);
+        return CRM_ERR_UNSUPPORTED;
     }
     if (first < 0 || count < 0 || first + count > panel->p) {
         set_error("scan: variants [%ld, %ld) outside the panel (p = %ld)", first, first + count, panel->p);
@@ -335,6 +473,18 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
     const long slab = (long)(1 + c) * ldq;  // rotations of [y, W] per grid point
+    // donor-collapsed mode: exact when every variant is constant within the panel's groups and the
+    // genotype permutation hook is not in use
+    const bool grouped = panel->grouped;
+    const size_t bd_bytes = grouped ? sizeof(double) * (size_t)nrho * panel->m_pad * k0 * ldq : 0;
+    const bool collapsed = grouped && !idx_G && ctx->collapse && bd_bytes <= ((size_t)48 << 30);
+    const long mp = grouped ? panel->m_pad : 0;
+    if (collapsed && (gene->dt_panel != panel || idx_E)) {
+        gene->dt_panel = nullptr;
+        CRM_TRY(build_donor_tables(gene, panel));
+        if (!idx_E) gene->dt_panel = panel;
+    }
+    const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit(BLK);
     std::vector<int> h_pos(BLK), h_ord(BLK);
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
@@ -343,26 +493,40 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         const int nb = (int)std::min<long>(BLK, count - done);
         const long col0 = first + done;
         double* Gb = ctx->ws_Gb.as<double>();
-        // 1. aligned copy of the block (and its row-permuted twin for the test direction)
-        CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, nullptr, nullptr, nb, Gb, ldb, (int)ldb));
+        // 1. aligned copy of the block (and its row-permuted twin for the test direction); in
+        //    collapsed mode the "block" is the donor dosage slab (m_pad rows)
         double* Gt = Gb;
-        if (idx_G) {
-            Gt = ctx->ws_Gt.as<double>();
-            CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, d_idxG, nullptr, nb, Gt, ldb, (int)ldb));
+        if (collapsed) {
+            CRM_TRY(launch_gather_block(st, panel->Gd.as<double>() + col0, panel->ld, mp, panel->m, nullptr, nullptr, nb, Gb, ldb, (int)ldb));
+        } else if (grouped) {
+            CRM_TRY(launch_expand_block(st, panel->Gd.as<double>() + col0, panel->ld, panel->group.as<int>(), np, n, nullptr, nb, Gb, ldb, (int)ldb));
+            if (idx_G) {
+                Gt = ctx->ws_Gt.as<double>();
+                CRM_TRY(launch_expand_block(st, panel->Gd.as<double>() + col0, panel->ld, panel->group.as<int>(), np, n, d_idxG, nb, Gt, ldb, (int)ldb));
+            }
+        } else {
+            CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, nullptr, nullptr, nb, Gb, ldb, (int)ldb));
+            if (idx_G) {
+                Gt = ctx->ws_Gt.as<double>();
+                CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, d_idxG, nullptr, nb, Gt, ldb, (int)ldb));
+            }
         }
         // 2. g'g, g'y, g'W
-        CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, CRM_MAX_COV));
+        if (collapsed)
+            CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, gene->dt_sums.as<double>(), c, d_gg, d_gy, d_gW, CRM_MAX_COV));
+        else
+            CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, CRM_MAX_COV));
         // 3. T(rho) = G' Q0(rho) for all grid points in one launch
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
             p.X = Gb; p.ldx = ldb;
-            p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.Y = collapsed ? gene->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
             p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
             p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, np, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, xrows, false, 0, 1, 0));
         // 4. null fits + rho*
         NullFitArgs fa{};
         fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0;
@@ -396,7 +560,7 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         CRM_HIP(hipMemcpyAsync(d_pos, h_pos.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
         CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
         double* Gs = ctx->ws_Gs.as<double>();
-        CRM_TRY(launch_gather_block(st, Gt, ldb, np, np, nullptr, d_ord, nb, Gs, ldb, (int)ldb));
+        CRM_TRY(launch_gather_block(st, Gt, ldb, xrows, xrows, nullptr, d_ord, nb, Gs, ldb, (int)ldb));
         // 6. A~ = KR(Gs, Ep)' Q0(rho*), one problem per non-empty rho* group
         int nz = 0, max_m = 0;
         double kr_flops = 0.0;
@@ -404,12 +568,20 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
             if (cnt[i] == 0) continue;
             GemmProblem p{};
             p.X = Gs + start[i]; p.ldx = ldb;
-            p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
-            p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-            p.C = ctx->ws_A.as<double>() + (size_t)start[i] * k0 * ldA; p.ldc = ldA;
-            p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            p.C = ctx->ws_A.as<double>() + (size_t)start[i] * k0 * ldA;
+            if (collapsed) {
+                // A~(b) = sum_d gamma_d,b * Bd(rho*)[d]: rows of Bd are (k0 x ldq) slabs per donor
+                p.Y = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
+                p.ldc = (long)k0 * ldA;
+                p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
+            } else {
+                p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
+                p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+                p.ldc = ldA;
+                p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            }
             max_m = std::max(max_m, p.M);
-            kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
+            if (!collapsed) kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             probs[nz++] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
@@ -422,7 +594,10 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
             }
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
-        CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, np, true, k0, 1, 0));
+        if (collapsed)
+            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
+        else
+            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, np, true, k0, 1, 0));
         if (ctx->timing) {
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
             ctx->timed_used++;
@@ -431,25 +606,26 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         // 7. elementwise products for the side contractions
         double* G2 = ctx->ws_G2.as<double>();
         double* GG = idx_G ? ctx->ws_GG.as<double>() : nullptr;
-        CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, np, (int)ldb, G2, GG, ldb));
+        CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
         if (!GG) GG = G2;
         // 8. Z1 = Gt' [y o E, W o E], Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
         {
             GemmProblem p{};
-            p.X = Gt; p.ldx = ldb; p.Y = gene->YE.as<double>(); p.ldy = gene->ld_ye;
+            p.X = Gt; p.ldx = ldb; p.Y = collapsed ? gene->dt_Z1.as<double>() : gene->YE.as<double>(); p.ldy = gene->ld_ye;
             p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
             probs[0] = p;
-            p.X = GG; p.Y = gene->Ep.as<double>(); p.ldy = gene->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
+            p.X = GG; p.Y = collapsed ? gene->dt_Z2.as<double>() : gene->Ep.as<double>(); p.ldy = gene->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
             probs[1] = p;
-            p.X = G2; p.Y = gene->EE.as<double>(); p.ldy = gene->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
+            p.X = G2; p.Y = collapsed ? gene->dt_Z3.as<double>() : gene->EE.as<double>(); p.ldy = gene->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
             probs[2] = p;
             CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * 3, hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_gemm_tn(st, d_probs + 0, 1, nb, k0 * (1 + c), np, false, 0, ks1, z1_sz));
-            CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, ks1, z1_sz));
-            CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, np, false, 0, ks2, z2_sz));
-            CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, ks2, z2_sz));
-            CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, np, false, 0, ks3, z3_sz));
-            CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, ks3, z3_sz));
+            const int s1 = collapsed ? 1 : ks1, s2 = collapsed ? 1 : ks2, s3 = collapsed ? 1 : ks3;
+            CRM_TRY(launch_gemm_tn(st, d_probs + 0, 1, nb, k0 * (1 + c), xrows, false, 0, s1, z1_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, s1, z1_sz));
+            CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, s2, z2_sz));
+            CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, xrows, false, 0, s3, z3_sz));
+            CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, s3, z3_sz));
         }
         // 9. Q and F
         AssembleArgs aa{};

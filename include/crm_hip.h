@@ -69,6 +69,15 @@ void crm_gene_destroy(crm_gene* gene);
 
 /* ---- genotype panel resident in HBM: G is n x p, row-major, leading dimension ldg ------ */
 int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out);
+/* Donor-constant panel ("Genotypes (expanded)", _cellregmap.py:488,561): cell i carries the genotypes
+ * of group[i] in [0, m); Gd is m x p (row-major, leading dimension ldg), one row per donor.  Scans of
+ * such a panel are exact collapses of the dense computation onto per-donor tables (every n-length
+ * contraction is linear in diag(g) or diag(g)^2); results agree with the dense path to rounding.  The
+ * genotype permutation hook (idx_G) falls back to the dense path by expanding blocks on the fly. */
+int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
+                             long p, crm_panel** out);
+/* on = 0 forces the dense path for grouped panels (default 1). */
+int crm_set_donor_collapse(crm_ctx* ctx, int on);
 void crm_panel_destroy(crm_panel* panel);
 
 /* ---- interaction scan: replaces the loop body of scan_interaction (_cellregmap.py:340-436)

@@ -79,3 +79,22 @@ def test_product_package_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libcrm_oracle" not in src, f
+
+
+def test_detect_groups_finds_exactly_the_donor_structure():
+    from cellregmap_amd import detect_groups
+
+    rng = np.random.default_rng(0)
+    Gd = rng.integers(0, 3, size=(7, 300)).astype(float)
+    donor = rng.integers(0, 7, size=90)
+    donor[:7] = np.arange(7)
+    G = Gd[donor]
+    group, reps = detect_groups(G)
+    assert group.dtype == np.int32 and len(reps) == 7
+    assert np.array_equal(G[reps][group], G)
+    # one cell deviating in one (unsampled) column breaks the structure -> no collapse
+    G2 = G.copy()
+    G2[50, 123] += 1.0
+    found = detect_groups(G2)
+    assert found is None or np.array_equal(G2[found[1]][found[0]], G2)
+    assert detect_groups(rng.normal(size=(40, 20))) is None

@@ -41,9 +41,10 @@ def _compare(pv, info, stats, opv, oinfo, ostats, tight=False):
     assert np.all(np.abs(pv - opv) <= rt * opv + P_ATOL), np.c_[pv, opv]
 
 
+@pytest.mark.parametrize("genotypes", ["dense", "donor-collapsed"])
 @pytest.mark.parametrize("mode", ["A", "B", "C", "C-eigh"])
-def test_interaction_matches_oracle(mode):
-    from cellregmap_amd import CellRegMap, _engine, _lib, get_L_values
+def test_interaction_matches_oracle(mode, genotypes):
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
     from oracle.crm import OracleCellRegMap, khatri_rao_halves
 
     if mode == "C-eigh":      # cols = k + k*donors >= n -> the reference's eigh branch
@@ -59,7 +60,9 @@ def test_interaction_matches_oracle(mode):
         kw["Ls"] = get_L_values(c.hK, c.E)
         okw["Ls"] = khatri_rao_halves(c.hK, c.E)
     crm = CellRegMap(c.y, c.E, W=c.W, **kw)
-    pv, info, stats = crm.scan_interaction(c.G, return_stats=True)
+    panel = GenotypePanel(c.G, groups=None if genotypes == "dense" else "auto")
+    assert (panel.n_groups is None) == (genotypes == "dense")
+    pv, info, stats = crm.scan_interaction(panel, return_stats=True)
     ocrm = OracleCellRegMap(c.y, c.E, W=c.W, **okw)
     opv, oinfo, ostats = ocrm.scan_interaction(c.G, return_stats=True)
     _compare(pv, info, stats, opv, oinfo, ostats)
@@ -70,7 +73,7 @@ def test_interaction_matches_oracle(mode):
     lib = _lib.load()
     _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 1))
     try:
-        pv, info, stats = crm.scan_interaction(c.G, return_stats=True)
+        pv, info, stats = crm.scan_interaction(panel, return_stats=True)
     finally:
         _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 0))
     pcrm = OracleCellRegMap(c.y, c.E, W=c.W, polish=True, **okw)
@@ -111,6 +114,38 @@ def test_permutation_hooks_and_extra_covariates():
         pv, info, stats = crm.scan_interaction(c.G, return_stats=True, **kw)
         opv, oinfo, ostats = ocrm.scan_interaction(c.G, return_stats=True, **kw)
         _compare(pv, info, stats, opv, oinfo, ostats)
+
+
+def test_collapsed_path_equals_dense_path():
+    """Donor-constant genotypes: the collapsed path is an exact rearrangement of the dense one
+    (also with the context permutation hook); the genotype permutation hook and general G run
+    dense."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, detect_groups
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(9, 30, 6, 40, seed=17)
+    rng = np.random.default_rng(3)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 1))], axis=1)
+    crm = CellRegMap(c.y, c.E, W=W, hK=c.hK)
+    dense = GenotypePanel(c.G, groups=None)
+    auto = GenotypePanel(c.G)
+    donors = GenotypePanel.from_donors(c.G[::30], c.donor_of_cell)
+    assert auto.n_groups == 9 and donors.n_groups == 9
+    idx_E = rng.permutation(c.y.size)
+    idx_G = rng.permutation(c.y.size)
+    for kw in ({}, {"idx_E": idx_E}, {"idx_G": idx_G}):
+        ref = crm.scan_interaction(dense, return_stats=True, **kw)
+        for panel in (auto, donors):
+            got = crm.scan_interaction(panel, return_stats=True, **kw)
+            assert np.array_equal(got[1]["rho1"], ref[1]["rho1"])
+            assert_allclose(got[2]["Q"], ref[2]["Q"], rtol=1e-7)
+            assert_allclose(got[2]["delta"], ref[2]["delta"], rtol=1e-6)
+            assert np.all(np.abs(got[0] - ref[0]) <= P_RTOL * ref[0] + P_ATOL)
+    # general (not donor-constant) genotypes are never collapsed
+    Gr = rng.normal(size=c.G.shape)
+    assert detect_groups(Gr) is None
+    pv_general, _ = crm.scan_interaction(Gr)
+    assert np.all(np.isfinite(pv_general))
 
 
 def test_blocks_and_ragged_tail():
