@@ -133,14 +133,25 @@ def test_collapsed_path_equals_dense_path():
     assert auto.n_groups == 9 and donors.n_groups == 9
     idx_E = rng.permutation(c.y.size)
     idx_G = rng.permutation(c.y.size)
-    for kw in ({}, {"idx_E": idx_E}, {"idx_G": idx_G}):
-        ref = crm.scan_interaction(dense, return_stats=True, **kw)
-        for panel in (auto, donors):
-            got = crm.scan_interaction(panel, return_stats=True, **kw)
-            assert np.array_equal(got[1]["rho1"], ref[1]["rho1"])
-            assert_allclose(got[2]["Q"], ref[2]["Q"], rtol=1e-7)
-            assert_allclose(got[2]["delta"], ref[2]["delta"], rtol=1e-6)
-            assert np.all(np.abs(got[0] - ref[0]) <= P_RTOL * ref[0] + P_ATOL)
+    from cellregmap_amd import _engine, _lib
+
+    lib = _lib.load()
+    for polish in (0, 1):
+        # polish = 1 pins the null-fit optimum, so the two summation orders must agree to ~1e-9;
+        # with the reference's Brent(1e-6) procedure they agree within its own tolerance
+        _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), polish))
+        try:
+            for kw in ({}, {"idx_E": idx_E}, {"idx_G": idx_G}):
+                ref = crm.scan_interaction(dense, return_stats=True, **kw)
+                for panel in (auto, donors):
+                    got = crm.scan_interaction(panel, return_stats=True, **kw)
+                    assert np.array_equal(got[1]["rho1"], ref[1]["rho1"])
+                    assert_allclose(got[2]["Q"], ref[2]["Q"], rtol=1e-8 if polish else Q_RTOL)
+                    assert_allclose(got[2]["delta"], ref[2]["delta"], rtol=1e-8 if polish else 5e-6)
+                    rt = 1e-7 if polish else P_RTOL
+                    assert np.all(np.abs(got[0] - ref[0]) <= rt * ref[0] + P_ATOL)
+        finally:
+            _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 0))
     # general (not donor-constant) genotypes are never collapsed
     Gr = rng.normal(size=c.G.shape)
     assert detect_groups(Gr) is None
