@@ -318,10 +318,20 @@ class CellRegMap:
         (:439-440); with ``return_stats=True`` additionally a dict holding Q, the eigenvalues
         of F, F itself and the null-fit scalars (for parity tests)."""
         lib = _lib.load()
+        k0 = self._E0.shape[1]
+        if not isinstance(G, GenotypePanel) and np.asarray(G).ndim == 2 and np.asarray(G).shape[1] == 0:
+            # no variants: the reference's loop body never runs (_cellregmap.py:340)
+            if np.asarray(G).shape[0] != self.n_samples:
+                raise ValueError(f"G must be {self.n_samples} x p, got {np.asarray(G).shape}")
+            empty = {key: np.empty(0) for key in ("rho1", "e2", "g2", "eps2")}
+            if return_stats:
+                return np.empty(0), empty, {"Q": np.empty(0), "lml": np.empty(0), "delta": np.empty(0),
+                                            "scale": np.empty(0), "lambda": np.empty((0, k0)),
+                                            "F": np.empty((0, k0, k0))}
+            return np.empty(0), empty
         panel = self._panel(G)
         n, p = panel.shape
         gene = self._bind_gene()
-        k0 = self._E0.shape[1]
 
         def _perm(idx):
             if idx is None:
@@ -355,8 +365,15 @@ class CellRegMap:
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False):
         lib = _lib.load()
+        p_user = None
+        if not isinstance(G, GenotypePanel) and np.asarray(G).ndim == 2 and np.asarray(G).shape[1] == 0:
+            # no SNPs: the null model is still fitted and reported (_cellregmap.py:250-266)
+            p_user = 0
+            G = np.zeros((np.asarray(G).shape[0], 1))
         panel = self._panel(G)
         n, p = panel.shape
+        if p_user is not None:
+            p = p_user
         gene = self._bind_gene()
         pv = np.empty(p)
         alt = np.empty(p)

@@ -1,0 +1,94 @@
+"""Edge cases of the interaction scan: empty and single-variant panels, one context (single
+eigenvalue -> Liu branch), genotypes inside span(W), rank-deficient covariates, non-finite input."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+P_RTOL, P_ATOL = 1e-5, 1e-13
+
+
+def _cohort(donors, cells, k, p, seed):
+    from cellregmap_amd.synth import make_cohort
+
+    return make_cohort(donors, cells, k, p, seed=seed)
+
+
+def test_empty_and_single_variant():
+    from cellregmap_amd import CellRegMap
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(6, 10, 3, 4, seed=31)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    pv, info = crm.scan_interaction(c.G[:, :0])
+    assert pv.shape == (0,) and all(v.shape == (0,) for v in info.values())
+    pv, info = crm.scan_interaction(c.G[:, [2]])
+    opv, oinfo = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G[:, [2]])
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL)
+
+
+def test_single_context_uses_the_liu_branch():
+    from cellregmap_amd import CellRegMap
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(8, 12, 1, 12, seed=32)
+    pv, info = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G)
+    opv, oinfo = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
+def test_genotype_inside_span_of_covariates_and_rank_deficient_W():
+    """A constant genotype column is collinear with the intercept; W with a duplicated column
+    is rank deficient.  The reference tolerates both (SVD-reduced covariates in glimix-core's
+    LMM, lstsq in PMat, _math.py:33-37)."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(8, 12, 3, 6, seed=33)
+    G = c.G.copy()
+    G[:, 1] = 1.0            # collinear with W = 1
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(c.y.size, 1))
+    W = np.concatenate([c.W, x, 2.0 * x], axis=1)  # rank 2, three columns
+    for Wc in (c.W, W):
+        crm = CellRegMap(c.y, c.E, W=Wc, hK=c.hK)
+        ocrm = OracleCellRegMap(c.y, c.E, W=Wc, hK=c.hK)
+        for groups in (None, "auto"):
+            pv, info = crm.scan_interaction(GenotypePanel(G, groups=groups))
+            opv, oinfo = ocrm.scan_interaction(G)
+            assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+            assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
+def test_zero_genotype_gives_nan_not_a_crash():
+    """g = 0 makes dK = 0: chiscore raises "No eigenvalue is bigger than 0" and the reference's whole
+    scan dies; the engine flags that variant with NaN and carries on."""
+    from cellregmap_amd import CellRegMap
+
+    c = _cohort(8, 12, 3, 6, seed=36)
+    G = c.G.copy()
+    G[:, 4] = 0.0
+    pv, info = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(G)
+    assert np.isnan(pv[4]) and np.all(np.isfinite(np.delete(pv, 4)))
+
+
+def test_non_finite_genotypes_raise():
+    from cellregmap_amd import CellRegMap
+
+    c = _cohort(6, 10, 3, 4, seed=34)
+    G = c.G.copy()
+    G[3, 1] = np.inf
+    with pytest.raises(ValueError):
+        CellRegMap(c.y, c.E, W=c.W).scan_interaction(G)
+
+
+def test_unsupported_sizes_fail_loudly():
+    from cellregmap_amd import CellRegMap, _lib
+
+    c = _cohort(6, 10, 3, 4, seed=35)
+    rng = np.random.default_rng(1)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 9))], axis=1)  # 10 covariates > 8
+    with pytest.raises(_lib.CrmError):
+        CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
