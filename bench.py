@@ -152,6 +152,18 @@ def main():
         "flops_per_launch": kr_fl.value / max(kr_n.value, 1),
         "share_of_step_time": round(kr_s / elapsed, 4),
     }
+    # HBM-side traffic of that kernel comes from separate rocprofv3 --pmc passes (profiles/), valid for
+    # the launch shape it was collected on
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        shape = pmc["launch_shape"]
+        if (args.config == shape["config"] and roofline["launches"] > 0
+                and abs(roofline["flops_per_launch"] / shape["flops_per_launch"] - 1.0) < 0.05):
+            roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+            roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, fabric side incl. Infinity Cache)"
+            roofline["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     rstar = float(np.mean([ranks[int(round(x * 10))] if len(ranks) > 1 else ranks[0] for x in rho1[: steps * batch]]))
     f_alg = algorithmic_flops(n, ranks, rstar, k0, cohort.W.shape[1])
     whole_path_tflops = f_alg * (steps * batch) / elapsed * 1e-12
