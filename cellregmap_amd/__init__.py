@@ -14,6 +14,8 @@ from ._engine import (
     run_association,
     run_association_fast,
     run_interaction,
+    run_interaction_many,
+    scan_interaction_many,
 )
 
 
@@ -34,6 +36,8 @@ __all__ = [
     "run_association",
     "run_association_fast",
     "run_interaction",
+    "run_interaction_many",
+    "scan_interaction_many",
     "estimate_betas",
     "get_L_values",
     "lrt_pvalues",

@@ -402,6 +402,63 @@ class CellRegMap:
         raise NotImplementedError("effect-size estimation is outside the score-test path")
 
 
+def scan_interaction_many(crms, G, idx_E=None, idx_G=None):
+    """Interaction scans of several phenotypes against one genotype panel in a single pass.
+
+    ``crms``: ``CellRegMap`` objects that share the background, ``W`` and ``E`` (e.g. built with
+    ``background=crms[0]._bg``).  Work that does not depend on the phenotype is done once per block
+    of variants (the reference redoes everything per gene).  Returns
+    ``(pvalues, info)`` with arrays of shape (len(crms), p); row i equals
+    ``crms[i].scan_interaction(G, idx_E, idx_G)``."""
+    lib = _lib.load()
+    crms = list(crms)
+    if not crms:
+        raise ValueError("no phenotypes given")
+    first = crms[0]
+    for c in crms[1:]:
+        if c._bg is not first._bg:
+            raise ValueError("all CellRegMap objects must share one background (pass background=...)")
+        if c._W.shape != first._W.shape or c._E0.shape != first._E0.shape:
+            raise ValueError("all CellRegMap objects must share W and E")
+    panel = first._panel(G)
+    n, p = panel.shape
+    genes = [c._bind_gene() for c in crms]
+    ng = len(genes)
+
+    def _perm(idx):
+        if idx is None:
+            return None
+        idx = np.ascontiguousarray(np.asarray(idx), dtype=np.int64)
+        if idx.shape != (n,):
+            raise ValueError("permutation index must have one entry per sample")
+        return np.ascontiguousarray(np.where(idx < 0, idx + n, idx), dtype=np.int32)
+
+    iE, iG = _perm(idx_E), _perm(idx_G)
+    handles = (ctypes.c_void_p * ng)(*[g.value for g in genes])
+    out = {k: np.empty((ng, p)) for k in ("pv", "rho1", "e2", "g2", "eps2")}
+    _lib.check(lib.crm_scan_interaction_multi(handles, ng, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),
+                                              _lib.ptr(out["pv"]), _lib.ptr(out["rho1"]), _lib.ptr(out["e2"]),
+                                              _lib.ptr(out["g2"]), _lib.ptr(out["eps2"]), None))
+    return out["pv"], {k: out[k] for k in ("rho1", "e2", "g2", "eps2")}
+
+
+def run_interaction_many(Y, E, G, W=None, E1=None, E2=None, hK=None, *, device=0):
+    """``run_interaction`` for the columns of ``Y`` (n x genes) with one background decomposition,
+    one genotype upload and shared per-variant work.  Returns arrays of shape (genes, p)."""
+    Y = np.asarray(Y, float)
+    if Y.ndim != 2:
+        raise ValueError("Y must be n x genes")
+    if E1 is None:
+        E1 = E
+    if E2 is None:
+        E2 = E
+    Ls = None if hK is None else get_L_values(hK, E2)
+    first = CellRegMap(y=Y[:, 0], E=E, W=W, E1=E1, Ls=Ls, device=device)
+    crms = [first] + [CellRegMap(y=Y[:, i], E=E, W=W, E1=E1, Ls=Ls, device=device, background=first._bg)
+                      for i in range(1, Y.shape[1])]
+    return scan_interaction_many(crms, G)
+
+
 def lrt_pvalues(null_lml, alt_lmls, dof=1):
     """Likelihood-ratio p-values with the reference's clips (_cellregmap.py:443-469)."""
     from scipy.stats import chi2

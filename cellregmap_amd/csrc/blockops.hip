@@ -164,7 +164,8 @@ __global__ void context_features_kernel(const double* __restrict__ E, long lde,
     const long si = live ? (row_index ? row_index[i] : i) : 0;
     for (int j = threadIdx.x; j < k0; j += blockDim.x) row[j] = live ? E[si * lde + j] : 0.0;
     __syncthreads();
-    for (int j = threadIdx.x; j < ld_ep; j += blockDim.x) Ep[i * ld_ep + j] = j < k0 ? row[j] : 0.0;
+    if (Ep)
+        for (int j = threadIdx.x; j < ld_ep; j += blockDim.x) Ep[i * ld_ep + j] = j < k0 ? row[j] : 0.0;
     const int nye = k0 * (1 + c);
     for (int q = threadIdx.x; q < ld_ye; q += blockDim.x) {
         double v = 0.0;
@@ -176,6 +177,7 @@ __global__ void context_features_kernel(const double* __restrict__ E, long lde,
     }
     // pairs (j, j'), j <= j', row-major over the upper triangle
     const int npair = k0 * (k0 + 1) / 2;
+    if (!EE) return;
     for (int q = threadIdx.x; q < ld_ee; q += blockDim.x) {
         double v = 0.0;
         if (q < npair) {

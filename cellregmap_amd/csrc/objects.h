@@ -36,6 +36,7 @@ struct crm_gene {
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
     const crm_panel* dt_panel = nullptr;
+    bool dt_full = false;  // also holds the phenotype-free tables (TZ, Bd, Z2, Z3)
     crm::DevBuf dt_TZ;    // [nrho][m_pad x ldq]          Z' Q0(rho)
     crm::DevBuf dt_Bd;    // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
     crm::DevBuf dt_Z1, dt_Z2, dt_Z3;  // [m_pad x ld]     Z'[y o E, W o E],  Z'E,  Z'(E (x) E)

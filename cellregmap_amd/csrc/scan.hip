@@ -278,7 +278,9 @@ __global__ void donor_sums_kernel(const int* __restrict__ group, long cells, int
 // Per-donor tables of the collapsed path: every n-length contraction of the scan is linear in
 // diag(g) (or diag(g)^2 = sum_d gamma_d^2 diag(z_d) for donor-constant g), so it is taken once per donor
 // indicator z_d with the same kernels and afterwards combined with the donor dosages gamma.
-static int build_donor_tables(crm_gene* gene, const crm_panel* panel) {
+static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full, const double* d_Ep,
+                              const double* d_EE) {
+    // full: also the phenotype-free tables (TZ, Bd, Z2, Z3), owned by the first gene of a call
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;
     hipStream_t st = ctx->stream;
@@ -287,43 +289,45 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel) {
     const long m = panel->m, mp = panel->m_pad;
     const int npair = k0 * (k0 + 1) / 2;
     const long ldZ1 = gene->ld_ye, ldZ2 = gene->ld_ep, ldZ3 = gene->ld_ee;
-    CRM_TRY(gene->dt_TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
-    CRM_TRY(gene->dt_Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
-    CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * 16));
-    CRM_HIP(hipMemsetAsync(gene->dt_TZ.ptr, 0, sizeof(double) * (size_t)nrho * mp * ldq, st));
-    CRM_HIP(hipMemsetAsync(gene->dt_Bd.ptr, 0, sizeof(double) * (size_t)nrho * mp * k0 * ldq, st));
-    CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * 16, st));
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
     const double* Z = panel->Z.as<double>();
-    for (int i = 0; i < nrho; i++) {
-        GemmProblem p{};
-        p.X = Z; p.ldx = panel->ldz; p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-        p.C = gene->dt_TZ.as<double>() + (size_t)i * mp * ldq; p.ldc = ldq;
-        p.M = (int)m; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-        probs[i] = p;
+    gene->dt_full = false;
+    if (full) {
+        CRM_TRY(gene->dt_TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
+        CRM_TRY(gene->dt_Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
+        CRM_HIP(hipMemsetAsync(gene->dt_TZ.ptr, 0, sizeof(double) * (size_t)nrho * mp * ldq, st));
+        CRM_HIP(hipMemsetAsync(gene->dt_Bd.ptr, 0, sizeof(double) * (size_t)nrho * mp * k0 * ldq, st));
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = Z; p.ldx = panel->ldz; p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.C = gene->dt_TZ.as<double>() + (size_t)i * mp * ldq; p.ldc = ldq;
+            p.M = (int)m; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            probs[i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m, (int)ldq, np, false, 0, 1, 0));
+        CRM_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = Z; p.ldx = panel->ldz; p.E = d_Ep; p.lde = gene->ld_ep; p.k0 = k0;
+            p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.C = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
+            p.M = (int)m * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            probs[i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m * k0, (int)ldq, np, true, k0, 1, 0));
+        CRM_HIP(hipStreamSynchronize(st));
     }
-    CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-    CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m, (int)ldq, np, false, 0, 1, 0));
-    CRM_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < nrho; i++) {
-        GemmProblem p{};
-        p.X = Z; p.ldx = panel->ldz; p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
-        p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-        p.C = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
-        p.M = (int)m * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-        probs[i] = p;
-    }
-    CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-    CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m * k0, (int)ldq, np, true, k0, 1, 0));
-    CRM_HIP(hipStreamSynchronize(st));
     // side tables (split over the cell axis: only one M tile)
-    struct { DevBuf* buf; const double* Y; long ldy; int N; long ld; } side[3] = {
-        {&gene->dt_Z1, gene->YE.as<double>(), gene->ld_ye, k0 * (1 + c), ldZ1},
-        {&gene->dt_Z2, gene->Ep.as<double>(), gene->ld_ep, k0, ldZ2},
-        {&gene->dt_Z3, gene->EE.as<double>(), gene->ld_ee, npair, ldZ3}};
+    struct Side { DevBuf* buf; const double* Y; long ldy; int N; long ld; bool needed; } side[3] = {
+        {&gene->dt_Z1, gene->YE.as<double>(), gene->ld_ye, k0 * (1 + c), ldZ1, true},
+        {&gene->dt_Z2, d_Ep, gene->ld_ep, k0, ldZ2, full},
+        {&gene->dt_Z3, d_EE, gene->ld_ee, npair, ldZ3, full}};
     for (auto& sd : side) {
+        if (!sd.needed) continue;
         const int ks = pick_split(np, sd.ld / GEMM_BN);
         const long sz = mp * sd.ld;
         CRM_TRY(sd.buf->ensure(sizeof(double) * (size_t)sz * ks));
@@ -336,11 +340,14 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel) {
         CRM_TRY(launch_reduce_splits(st, sd.buf->as<double>(), sz, ks, sz));
         CRM_HIP(hipStreamSynchronize(st));
     }
+    CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * 16));
+    CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * 16, st));
     hipLaunchKernelGGL(donor_sums_kernel, dim3((unsigned)((m + 63) / 64), c + 2), dim3(64), 0, st,
                        panel->group.as<int>(), n, (int)m, gene->yW.as<double>(), gene->ld_yw, c,
                        gene->dt_sums.as<double>());
     CRM_HIP(hipGetLastError());
     CRM_HIP(hipStreamSynchronize(st));
+    gene->dt_full = full;
     return CRM_OK;
 }
 
@@ -349,12 +356,24 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel) {
 extern "C" {
 
 // ---- the scan ---------------------------------------------------------------------------------
-int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
-                         const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
-                         double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
-                         double* out_delta, double* out_scale, double* out_lambda, double* out_F) {
-    if (!gene || !panel) return CRM_ERR_ARG;
-    crm_background* bg = gene->bg;
+}  // extern "C"
+
+namespace crm {
+
+struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: count*k0, F: count*k0*k0)
+    double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
+};
+
+// One pass over variants [first, first + count) for one or several genes that share the background,
+// the covariates W and the contexts E0 (several phenotypes against one panel).  What does not depend
+// on the phenotype is done once per block: the block copies, T(rho) = G'Q0(rho), the Khatri-Rao
+// contraction per (variant, rho) pair that at least one gene selected, and the y-free side
+// contractions.  Per gene: g'y, the null fits, E'(g o y), assembly, eigenvalues and Davies.
+static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
+                     const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs) {
+    const int ng = (int)genes.size();
+    crm_gene* g0 = genes[0];
+    crm_background* bg = g0->bg;
     crm_ctx* ctx = bg->ctx;
     if (panel->ctx != ctx) {
         set_error("scan: gene and panel live on different contexts");
@@ -372,61 +391,73 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         set_error("scan: variants [%ld, %ld) outside the panel (p = %ld)", first, first + count, panel->p);
         return CRM_ERR_ARG;
     }
+    for (crm_gene* g : genes) {
+        if (g->bg != bg || g->c != g0->c || g->k0 != g0->k0) {
+            set_error("scan: genes of one call must share the background, W and E0");
+            return CRM_ERR_ARG;
+        }
+    }
     if (count == 0) return CRM_OK;
-    if (gene->c > CRM_MAX_COV) {
-        set_error("interaction scan: %d covariate columns (supported 1..%d)", gene->c, CRM_MAX_COV);
+    if (g0->c > CRM_MAX_COV) {
+        set_error("interaction scan: %d covariate columns (supported 1..%d)", g0->c, CRM_MAX_COV);
         return CRM_ERR_UNSUPPORTED;
     }
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
-    const int nrho = bg->nrho, c = gene->c, k0 = gene->k0;
+    const int nrho = bg->nrho, c = g0->c, k0 = g0->k0;
     for (long i = 0; i < n; i++) {
         if ((idx_E && (idx_E[i] < 0 || idx_E[i] >= n)) || (idx_G && (idx_G[i] < 0 || idx_G[i] >= n))) {
             set_error("scan: permutation index out of range at position %ld", i);
             return CRM_ERR_ARG;
         }
     }
-    const int BLK = (int)std::min<long>(ctx->block_variants, round_up(count, 128));
-    const long ldb = BLK + 128;  // slack columns for the Khatri-Rao tile over-read
-    const long ldA = ldq;
-    const long ldT = ldq;
+    // several genes may ask for several rho* per variant: keep the (variant, rho) pair list bounded
+    int BLK = (int)std::min<long>(ctx->block_variants, round_up(count, 128));
+    if (ng > 1) BLK = std::min(BLK, 512);
+    const int max_pairs = ng > 1 ? std::min(nrho, ng) * BLK : BLK;
+    const long ldb = BLK + 128;              // slack columns for the Khatri-Rao tile over-read
+    const long ldp = max_pairs + 128;        // pair-ordered copy of the block
+    const long ldA = ldq, ldT = ldq;
     const int npair = k0 * (k0 + 1) / 2;
     const long ldZ1 = round_up((long)k0 * (1 + c), 128), ldZ2 = round_up(k0, 128), ldZ3 = round_up(npair, 128);
     const int KT = k0 + c + 2;
 
-    // ---- context features for this permutation ------------------------------------------------
-    gene->ld_ep = round_up(k0, 128);
-    gene->ld_ye = ldZ1;
-    gene->ld_ee = ldZ3;
-    CRM_TRY(gene->Ep.ensure(sizeof(double) * np * gene->ld_ep));
-    CRM_TRY(gene->YE.ensure(sizeof(double) * np * gene->ld_ye));
-    CRM_TRY(gene->EE.ensure(sizeof(double) * np * gene->ld_ee));
-    CRM_TRY(gene->idx.ensure(sizeof(int) * 2 * n));
+    // ---- context features for this permutation (E, E (x) E shared; y o E per gene) --------------
+    CRM_TRY(g0->idx.ensure(sizeof(int) * 2 * n));
     int* d_idxE = nullptr;
     int* d_idxG = nullptr;
     if (idx_E) {
-        d_idxE = gene->idx.as<int>();
+        d_idxE = g0->idx.as<int>();
         CRM_HIP(hipMemcpyAsync(d_idxE, idx_E, sizeof(int) * n, hipMemcpyHostToDevice, st));
     }
     if (idx_G) {
-        d_idxG = gene->idx.as<int>() + n;
+        d_idxG = g0->idx.as<int>() + n;
         CRM_HIP(hipMemcpyAsync(d_idxG, idx_G, sizeof(int) * n, hipMemcpyHostToDevice, st));
     }
-    const double* d_y = gene->yW.as<double>();          // column 0, ld ld_yw
-    const double* d_W = gene->yW.as<double>() + 1;      // columns 1..c
-    CRM_TRY(launch_context_features(st, gene->E0.as<double>(), gene->lde, d_idxE, n, np, k0, d_y, d_W,
-                                    gene->ld_yw, c, gene->Ep.as<double>(), gene->ld_ep,
-                                    gene->YE.as<double>(), gene->ld_ye, gene->EE.as<double>(),
-                                    gene->ld_ee));
-    // y with unit stride for the stats kernel: it reads y[i], W[i*ldw + q] -> pass strided views
-    // (the kernel takes explicit leading dimensions)
+    for (int gi = 0; gi < ng; gi++) {
+        crm_gene* g = genes[gi];
+        g->ld_ep = round_up(k0, 128);
+        g->ld_ye = ldZ1;
+        g->ld_ee = ldZ3;
+        CRM_TRY(g->YE.ensure(sizeof(double) * np * g->ld_ye));
+        if (gi == 0) {
+            CRM_TRY(g->Ep.ensure(sizeof(double) * np * g->ld_ep));
+            CRM_TRY(g->EE.ensure(sizeof(double) * np * g->ld_ee));
+        }
+        CRM_TRY(launch_context_features(st, g->E0.as<double>(), g->lde, d_idxE, n, np, k0, g->yW.as<double>(),
+                                        g->yW.as<double>() + 1, g->ld_yw, c,
+                                        gi == 0 ? g->Ep.as<double>() : nullptr, g->ld_ep, g->YE.as<double>(),
+                                        g->ld_ye, gi == 0 ? g->EE.as<double>() : nullptr, g->ld_ee));
+    }
+    const double* d_Ep = g0->Ep.as<double>();
+    const double* d_EE = g0->EE.as<double>();
 
     // ---- workspaces ----------------------------------------------------------------------------
     CRM_TRY(ctx->ws_T.ensure(sizeof(double) * (size_t)nrho * BLK * ldT));
-    CRM_TRY(ctx->ws_A.ensure(sizeof(double) * (size_t)BLK * k0 * ldA));
+    CRM_TRY(ctx->ws_A.ensure(sizeof(double) * (size_t)max_pairs * k0 * ldA));
     CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
-    CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldb));
+    CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldp));
     CRM_TRY(ctx->ws_G2.ensure(sizeof(double) * (size_t)np * ldb));
     if (idx_G) {
         CRM_TRY(ctx->ws_Gt.ensure(sizeof(double) * (size_t)np * ldb));
@@ -443,25 +474,24 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     double* dZ3 = dZ2 + z2_sz * ks2;
     CRM_TRY(ctx->ws_F.ensure(sizeof(double) * (size_t)BLK * k0 * k0));
     CRM_TRY(ctx->ws_Gext.ensure(sizeof(double) * (size_t)BLK * KT * KT));
-    // small arrays carved out of one buffer
     const size_t stats_ws = variant_stats_workspace(BLK, c);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t o_gg = carve(sizeof(double) * BLK), o_gy = carve(sizeof(double) * BLK),
+    const size_t o_gg = carve(sizeof(double) * BLK), o_gy = carve(sizeof(double) * BLK * ng),
                  o_gW = carve(sizeof(double) * BLK * CRM_MAX_COV), o_trial = carve(sizeof(NullFitTrial) * BLK * nrho),
-                 o_fit = carve(sizeof(NullFitOut) * BLK), o_pos = carve(sizeof(int) * BLK),
-                 o_ord = carve(sizeof(int) * BLK), o_Q = carve(sizeof(double) * BLK),
+                 o_fit = carve(sizeof(NullFitOut) * BLK * ng), o_pos = carve(sizeof(int) * BLK * ng),
+                 o_ord = carve(sizeof(int) * max_pairs), o_Q = carve(sizeof(double) * BLK),
                  o_pv = carve(sizeof(double) * BLK), o_lam = carve(sizeof(double) * BLK * k0),
                  o_if = carve(sizeof(int) * BLK), o_liu = carve(sizeof(double) * BLK),
                  o_part = carve(stats_ws);
     CRM_TRY(ctx->ws_small.ensure(off));
     char* sm = ctx->ws_small.as<char>();
     double* d_gg = (double*)(sm + o_gg);
-    double* d_gy = (double*)(sm + o_gy);
+    double* d_gy = (double*)(sm + o_gy);          // [ng][BLK]
     double* d_gW = (double*)(sm + o_gW);
     NullFitTrial* d_trial = (NullFitTrial*)(sm + o_trial);
-    NullFitOut* d_fit = (NullFitOut*)(sm + o_fit);
-    int* d_pos = (int*)(sm + o_pos);
+    NullFitOut* d_fit = (NullFitOut*)(sm + o_fit);  // [ng][BLK]
+    int* d_pos = (int*)(sm + o_pos);               // [ng][BLK]
     int* d_ord = (int*)(sm + o_ord);
     double* d_Q = (double*)(sm + o_Q);
     double* d_pv = (double*)(sm + o_pv);
@@ -479,15 +509,22 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     const size_t bd_bytes = grouped ? sizeof(double) * (size_t)nrho * panel->m_pad * k0 * ldq : 0;
     const bool collapsed = grouped && !idx_G && ctx->collapse && bd_bytes <= ((size_t)48 << 30);
     const long mp = grouped ? panel->m_pad : 0;
-    if (collapsed && (gene->dt_panel != panel || idx_E)) {
-        gene->dt_panel = nullptr;
-        CRM_TRY(build_donor_tables(gene, panel));
-        if (!idx_E) gene->dt_panel = panel;
+    if (collapsed) {
+        for (int gi = 0; gi < ng; gi++) {
+            crm_gene* g = genes[gi];
+            const bool have = g->dt_panel == panel && !idx_E && (gi > 0 || g->dt_full);
+            if (!have) {
+                g->dt_panel = nullptr;
+                CRM_TRY(build_donor_tables(g, panel, gi == 0, d_Ep, d_EE));
+                if (!idx_E) g->dt_panel = panel;
+            }
+        }
     }
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
-    std::vector<NullFitOut> h_fit(BLK);
-    std::vector<int> h_pos(BLK), h_ord(BLK);
+    std::vector<NullFitOut> h_fit((size_t)BLK * ng);
+    std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
+    std::vector<int> pair_of((size_t)nrho * BLK);
 
     for (long done = 0; done < count; done += BLK) {
         const int nb = (int)std::min<long>(BLK, count - done);
@@ -511,77 +548,90 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                 CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, d_idxG, nullptr, nb, Gt, ldb, (int)ldb));
             }
         }
-        // 2. g'g, g'y, g'W
-        if (collapsed)
-            CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, gene->dt_sums.as<double>(), c, d_gg, d_gy, d_gW, CRM_MAX_COV));
-        else
-            CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, CRM_MAX_COV));
+        // 2. g'g, g'W (shared) and g'y per gene
+        for (int gi = 0; gi < ng; gi++) {
+            crm_gene* g = genes[gi];
+            if (collapsed)
+                CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, g->dt_sums.as<double>(), c, d_gg, d_gy + (size_t)gi * BLK, d_gW, CRM_MAX_COV));
+            else
+                CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, CRM_MAX_COV));
+        }
         // 3. T(rho) = G' Q0(rho) for all grid points in one launch
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
             p.X = Gb; p.ldx = ldb;
-            p.Y = collapsed ? gene->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
+            p.Y = collapsed ? g0->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
             p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
             p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, xrows, false, 0, 1, 0));
-        // 4. null fits + rho*
-        NullFitArgs fa{};
-        fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0;
-        for (int i = 0; i < nrho; i++) {
-            NullFitRho& R = fa.rho[i];
-            R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
-            R.ty = gene->rot.as<double>() + (long)i * slab;
-            R.tW = R.ty + ldq; R.ldW = ldq;
-            R.S0 = bg->S0[i].as<double>();
-            R.r = bg->r[i];
-        }
-        fa.WW = gene->WW.as<double>(); fa.Wy = gene->Wy.as<double>(); fa.yy = gene->yy;
-        fa.gg = d_gg; fa.gy = d_gy; fa.gW = d_gW; fa.ld_gW = CRM_MAX_COV;
-        fa.trial = d_trial; fa.out = d_fit;
-        CRM_TRY(launch_nullfit(st, fa, nb));
-        // 5. order the block by rho* (host counting sort; nb * 48 bytes cross PCIe)
-        CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * nb, hipMemcpyDeviceToHost, st));
-        CRM_HIP(hipStreamSynchronize(st));
-        int cnt[CRM_MAX_RHO] = {0}, start[CRM_MAX_RHO + 1] = {0};
-        for (int b = 0; b < nb; b++) cnt[h_fit[b].rho_index]++;
-        for (int i = 0; i < nrho; i++) start[i + 1] = start[i] + cnt[i];
-        {
-            int fill[CRM_MAX_RHO];
-            for (int i = 0; i < nrho; i++) fill[i] = start[i];
-            for (int b = 0; b < nb; b++) {
-                const int pos = fill[h_fit[b].rho_index]++;
-                h_pos[b] = pos;
-                h_ord[pos] = b;
+        // 4. null fits + rho* per gene
+        for (int gi = 0; gi < ng; gi++) {
+            crm_gene* g = genes[gi];
+            NullFitArgs fa{};
+            fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0;
+            for (int i = 0; i < nrho; i++) {
+                NullFitRho& R = fa.rho[i];
+                R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
+                R.ty = g->rot.as<double>() + (long)i * slab;
+                R.tW = R.ty + ldq; R.ldW = ldq;
+                R.S0 = bg->S0[i].as<double>();
+                R.r = bg->r[i];
             }
+            fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
+            fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = CRM_MAX_COV;
+            fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
+            CRM_TRY(launch_nullfit(st, fa, nb));
         }
-        CRM_HIP(hipMemcpyAsync(d_pos, h_pos.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
-        CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st));
+        // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
+        CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
+        CRM_HIP(hipStreamSynchronize(st));
+        std::fill(pair_of.begin(), pair_of.end(), -1);
+        for (int gi = 0; gi < ng; gi++)
+            for (int b = 0; b < nb; b++) pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b] = 0;
+        int cnt[CRM_MAX_RHO] = {0}, start[CRM_MAX_RHO + 1] = {0};
+        int npairs = 0;
+        for (int i = 0; i < nrho; i++) {
+            start[i] = npairs;
+            for (int b = 0; b < nb; b++) {
+                if (pair_of[(size_t)i * BLK + b] == 0) {
+                    pair_of[(size_t)i * BLK + b] = npairs;
+                    h_ord[npairs++] = b;
+                }
+            }
+            cnt[i] = npairs - start[i];
+        }
+        start[nrho] = npairs;
+        for (int gi = 0; gi < ng; gi++)
+            for (int b = 0; b < nb; b++)
+                h_pos[(size_t)gi * BLK + b] = pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b];
+        CRM_HIP(hipMemcpyAsync(d_pos, h_pos.data(), sizeof(int) * (size_t)BLK * ng, hipMemcpyHostToDevice, st));
+        CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * npairs, hipMemcpyHostToDevice, st));
         double* Gs = ctx->ws_Gs.as<double>();
-        CRM_TRY(launch_gather_block(st, Gt, ldb, xrows, xrows, nullptr, d_ord, nb, Gs, ldb, (int)ldb));
-        // 6. A~ = KR(Gs, Ep)' Q0(rho*), one problem per non-empty rho* group
+        CRM_TRY(launch_gather_block(st, Gt, ldb, xrows, xrows, nullptr, d_ord, npairs, Gs, ldp, (int)ldp));
+        // 6. A~ = KR(Gs, Ep)' Q0(rho), one problem per non-empty rho group of pairs
         int nz = 0, max_m = 0;
         double kr_flops = 0.0;
         for (int i = 0; i < nrho; i++) {
             if (cnt[i] == 0) continue;
             GemmProblem p{};
-            p.X = Gs + start[i]; p.ldx = ldb;
+            p.X = Gs + start[i]; p.ldx = ldp;
             p.C = ctx->ws_A.as<double>() + (size_t)start[i] * k0 * ldA;
             if (collapsed) {
-                // A~(b) = sum_d gamma_d,b * Bd(rho*)[d]: rows of Bd are (k0 x ldq) slabs per donor
-                p.Y = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
+                // A~(b) = sum_d gamma_d,b * Bd(rho)[d]: rows of Bd are (k0 x ldq) slabs per donor
+                p.Y = g0->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
                 p.ldc = (long)k0 * ldA;
                 p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
             } else {
-                p.E = gene->Ep.as<double>(); p.lde = gene->ld_ep; p.k0 = k0;
+                p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;
                 p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
                 p.ldc = ldA;
                 p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+                kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             }
             max_m = std::max(max_m, p.M);
-            if (!collapsed) kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             probs[nz++] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
@@ -608,63 +658,101 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
         double* GG = idx_G ? ctx->ws_GG.as<double>() : nullptr;
         CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
         if (!GG) GG = G2;
-        // 8. Z1 = Gt' [y o E, W o E], Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
+        // 8. y-free side contractions: Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
+        const int s1 = collapsed ? 1 : ks1, s2 = collapsed ? 1 : ks2, s3 = collapsed ? 1 : ks3;
         {
             GemmProblem p{};
-            p.X = Gt; p.ldx = ldb; p.Y = collapsed ? gene->dt_Z1.as<double>() : gene->YE.as<double>(); p.ldy = gene->ld_ye;
-            p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
-            probs[0] = p;
-            p.X = GG; p.Y = collapsed ? gene->dt_Z2.as<double>() : gene->Ep.as<double>(); p.ldy = gene->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
+            p.ldx = ldb; p.M = nb;
+            p.X = GG; p.Y = collapsed ? g0->dt_Z2.as<double>() : d_Ep; p.ldy = g0->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
             probs[1] = p;
-            p.X = G2; p.Y = collapsed ? gene->dt_Z3.as<double>() : gene->EE.as<double>(); p.ldy = gene->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
+            p.X = G2; p.Y = collapsed ? g0->dt_Z3.as<double>() : d_EE; p.ldy = g0->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
             probs[2] = p;
-            CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * 3, hipMemcpyHostToDevice, st));
-            const int s1 = collapsed ? 1 : ks1, s2 = collapsed ? 1 : ks2, s3 = collapsed ? 1 : ks3;
-            CRM_TRY(launch_gemm_tn(st, d_probs + 0, 1, nb, k0 * (1 + c), xrows, false, 0, s1, z1_sz));
-            CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, s1, z1_sz));
+            CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data() + 1, sizeof(GemmProblem) * 2, hipMemcpyHostToDevice, st));
             CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
             CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, s2, z2_sz));
             CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, xrows, false, 0, s3, z3_sz));
             CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, s3, z3_sz));
         }
-        // 9. Q and F
-        AssembleArgs aa{};
-        for (int i = 0; i < nrho; i++) {
-            AssembleRho& R = aa.rho[i];
-            R.ty = gene->rot.as<double>() + (long)i * slab;
-            R.tW = R.ty + ldq; R.ldW = ldq;
-            R.S0 = bg->S0[i].as<double>();
-            R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
-            R.r = bg->r[i];
+        // 9.-11. per gene: Z1 = Gt' [y o E, W o E], Q and F, eigenvalues + Davies, results
+        for (int gi = 0; gi < ng; gi++) {
+            crm_gene* g = genes[gi];
+            const ScanOut& o = outs[gi];
+            {
+                GemmProblem p{};
+                p.X = Gt; p.ldx = ldb; p.Y = collapsed ? g->dt_Z1.as<double>() : g->YE.as<double>(); p.ldy = g->ld_ye;
+                p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
+                CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
+                CRM_TRY(launch_gemm_tn(st, d_probs, 1, nb, k0 * (1 + c), xrows, false, 0, s1, z1_sz));
+                CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, s1, z1_sz));
+            }
+            AssembleArgs aa{};
+            for (int i = 0; i < nrho; i++) {
+                AssembleRho& R = aa.rho[i];
+                R.ty = g->rot.as<double>() + (long)i * slab;
+                R.tW = R.ty + ldq; R.ldW = ldq;
+                R.S0 = bg->S0[i].as<double>();
+                R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
+                R.r = bg->r[i];
+            }
+            aa.fit = d_fit + (size_t)gi * BLK; aa.sorted_pos = d_pos + (size_t)gi * BLK;
+            aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
+            aa.Z1 = dZ1; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
+            aa.WW = g->WW.as<double>(); aa.Wy = g->Wy.as<double>(); aa.yy = g->yy;
+            aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = CRM_MAX_COV;
+            aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
+            CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
+            CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));
+            if (o.pv) CRM_HIP(hipMemcpyAsync(o.pv + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+            if (o.Q) CRM_HIP(hipMemcpyAsync(o.Q + done, d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+            if (o.lambda) CRM_HIP(hipMemcpyAsync(o.lambda + done * k0, d_lam, sizeof(double) * nb * k0, hipMemcpyDeviceToHost, st));
+            if (o.F) CRM_HIP(hipMemcpyAsync(o.F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
+            for (int b = 0; b < nb; b++) {
+                const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
+                const double rho = bg->rho[f.rho_index];
+                if (o.rho1) o.rho1[done + b] = rho;
+                if (o.e2) o.e2[done + b] = f.v0 * rho;
+                if (o.g2) o.g2[done + b] = f.v0 * (1 - rho);
+                if (o.eps2) o.eps2[done + b] = f.v1;
+                if (o.lml) o.lml[done + b] = f.lml;
+                if (o.delta) o.delta[done + b] = f.delta;
+                if (o.scale) o.scale[done + b] = f.scale;
+            }
+            // the per-gene device buffers (Z1, Q, F, pv) are reused by the next gene
+            CRM_HIP(hipStreamSynchronize(st));
         }
-        aa.fit = d_fit; aa.sorted_pos = d_pos;
-        aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
-        aa.Z1 = dZ1; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
-        aa.WW = gene->WW.as<double>(); aa.Wy = gene->Wy.as<double>(); aa.yy = gene->yy;
-        aa.gg = d_gg; aa.gy = d_gy; aa.gW = d_gW; aa.ld_gW = CRM_MAX_COV;
-        aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
-        CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
-        // 10. eigenvalues + Davies
-        CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));
-        // 11. results
-        if (out_pvalue) CRM_HIP(hipMemcpyAsync(out_pvalue + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
-        if (out_Q) CRM_HIP(hipMemcpyAsync(out_Q + done, d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
-        if (out_lambda) CRM_HIP(hipMemcpyAsync(out_lambda + done * k0, d_lam, sizeof(double) * nb * k0, hipMemcpyDeviceToHost, st));
-        if (out_F) CRM_HIP(hipMemcpyAsync(out_F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
-        for (int b = 0; b < nb; b++) {
-            const NullFitOut& f = h_fit[b];
-            const double rho = bg->rho[f.rho_index];
-            if (out_rho1) out_rho1[done + b] = rho;
-            if (out_e2) out_e2[done + b] = f.v0 * rho;
-            if (out_g2) out_g2[done + b] = f.v0 * (1 - rho);
-            if (out_eps2) out_eps2[done + b] = f.v1;
-            if (out_lml) out_lml[done + b] = f.lml;
-            if (out_delta) out_delta[done + b] = f.delta;
-            if (out_scale) out_scale[done + b] = f.scale;
-        }
-        CRM_HIP(hipStreamSynchronize(st));
     }
     return CRM_OK;
+}
+
+}  // namespace crm
+
+extern "C" {
+
+int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
+                         const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
+                         double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
+                         double* out_delta, double* out_scale, double* out_lambda, double* out_F) {
+    if (!gene || !panel) return CRM_ERR_ARG;
+    std::vector<crm_gene*> genes{gene};
+    std::vector<ScanOut> outs{{out_pvalue, out_rho1, out_e2, out_g2, out_eps2, out_Q, out_lml, out_delta,
+                               out_scale, out_lambda, out_F}};
+    return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+}
+
+int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* panel, long first, long count,
+                               const int* idx_E, const int* idx_G, double* out_pvalue, double* out_rho1,
+                               double* out_e2, double* out_g2, double* out_eps2, double* out_Q) {
+    if (!genes || ngenes < 1 || !panel) return CRM_ERR_ARG;
+    std::vector<crm_gene*> gs(genes, genes + ngenes);
+    for (crm_gene* g : gs)
+        if (!g) return CRM_ERR_ARG;
+    std::vector<ScanOut> outs(ngenes);
+    for (int i = 0; i < ngenes; i++) {
+        auto at = [&](double* base) { return base ? base + (size_t)i * count : nullptr; };
+        outs[i] = ScanOut{at(out_pvalue), at(out_rho1), at(out_e2), at(out_g2), at(out_eps2), at(out_Q),
+                          nullptr, nullptr, nullptr, nullptr, nullptr};
+    }
+    return scan_core(gs, panel, first, count, idx_E, idx_G, outs);
 }
 
 }  // extern "C"

@@ -90,6 +90,15 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
                          double* out_delta, double* out_scale, double* out_lambda, double* out_F);
 
+/* Several phenotypes against one panel in one pass ("genes" that share the background, W and E0):
+ * everything that does not depend on y -- G'Q0(rho), the Khatri-Rao contraction per (variant, rho)
+ * pair selected by at least one gene, the y-free side contractions -- is computed once per block.
+ * Outputs are ngenes x count, row-major (gene-major); optional ones may be NULL.  Results per gene
+ * are those of crm_scan_interaction. */
+int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* panel, long first, long count,
+                               const int* idx_E, const int* idx_G, double* out_pvalue, double* out_rho1,
+                               double* out_e2, double* out_g2, double* out_eps2, double* out_Q);
+
 /* ---- association scans: replace scan_association (fast = 0, _cellregmap.py:246-281: ML refit per
  * SNP at the null model's rho) and scan_association_fast (fast = 1, :284-314: glimix-core
  * FastScanner, delta frozen at the null) including lrt_pvalues (:443-469).  The null model (ML,

@@ -190,3 +190,30 @@ def test_errors_are_loud():
         CellRegMap(y, c.E, W=c.W).scan_interaction(c.G)
     with pytest.raises(ValueError):
         CellRegMap(c.y, c.E, W=c.W).scan_interaction(c.G[:-1])
+
+
+@pytest.mark.parametrize("genotypes", ["dense", "donor-collapsed"])
+def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
+    """BASELINE config 4 in miniature: several genes x one panel.  The shared pass must return, per
+    gene, exactly what the single-gene scan returns (same kernels on the same operands)."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, run_interaction_many, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 25, 4, 70, seed=41)
+    rng = np.random.default_rng(7)
+    Y = np.stack([c.y, c.y[rng.permutation(c.y.size)], rng.normal(size=c.y.size), c.y + rng.normal(size=c.y.size)], axis=1)
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(Y[:, 0], c.E, W=c.W, Ls=Ls)
+    crms = [first] + [CellRegMap(Y[:, i], c.E, W=c.W, Ls=Ls, background=first._bg) for i in range(1, 4)]
+    panel = GenotypePanel(c.G, groups=None if genotypes == "dense" else "auto")
+    for kw in ({}, {"idx_E": rng.permutation(c.y.size)}):
+        pv, info = scan_interaction_many(crms, panel, **kw)
+        assert pv.shape == (4, 70)
+        assert len(set(np.unique(info["rho1"]))) > 1  # the genes do not all agree on rho*
+        for i, crm in enumerate(crms):
+            spv, sinfo = crm.scan_interaction(panel, **kw)
+            assert np.array_equal(pv[i], spv)
+            for k in sinfo:
+                assert np.array_equal(info[k][i], sinfo[k])
+    pv2, _ = run_interaction_many(Y, c.E, c.G, W=c.W, hK=c.hK)
+    assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
