@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-variants", type=int, default=8, help="variants of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--polish", type=int, default=0)
     ap.add_argument("--collapsed", type=int, default=1, help="also time the donor-collapsed path (N=1)")
+    ap.add_argument("--genes", type=int, default=16, help="phenotypes of the shared multi-gene leg (0 = skip, N=1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,6 +197,37 @@ def main():
                      "note": "exact rearrangement onto per-donor tables; general G uses the dense path"}
         pv[:] = pv_dense
 
+    # ---- several phenotypes against the same (dense) panel in one pass: BASELINE config 4's shape ----
+    multi = None
+    if args.genes > 1 and world == 1:
+        from cellregmap_amd import scan_interaction_many
+
+        rng = np.random.default_rng(99)
+        crms = [crm]
+        for i in range(1, args.genes):
+            yi = cohort.y[rng.permutation(n)] if i % 2 else cohort.y + rng.normal(size=n)
+            ci = CellRegMap(yi, cohort.E, W=cohort.W, Ls=Ls, device=local_rank, background=crm._bg)
+            ci._bind_gene()
+            crms.append(ci)
+        handles = (ctypes.c_void_p * len(crms))(*[c._gene.value for c in crms])
+        mb = min(batch, 1024)
+        mpv = np.empty((len(crms), mb)); mrho = np.empty((len(crms), mb))
+
+        def run_multi():
+            _lib.check(lib.crm_scan_interaction_multi(handles, len(crms), panel.handle, 0, mb, None, None,
+                                                      _lib.ptr(mpv), _lib.ptr(mrho), None, None, None, None))
+            _lib.check(lib.crm_ctx_synchronize(ctx))
+
+        run_multi()
+        t0 = time.perf_counter()
+        run_multi()
+        t_multi = time.perf_counter() - t0
+        multi = {"value": round(len(crms) * mb / t_multi, 1), "unit": "variant-tests/s", "genes": len(crms),
+                 "variants": mb, "distinct_rho_per_variant": float(np.mean([len(set(mrho[:, j])) for j in range(mb)])),
+                 "gene0_matches_single_gene_scan": bool(np.array_equal(mpv[0], pv_dense[:mb])),
+                 "note": "dense path; G'Q0(rho) and the Khatri-Rao contraction shared by the genes of a variant"}
+        del crms[1:]
+
     # ---- CPU baseline: the oracle (reference-shaped per-variant loop) on this host -------------
     cpu = None
     if args.cpu_variants > 0 and world == 1:
@@ -247,6 +279,7 @@ def main():
                     "panel_upload": round(t_upload, 2)},
         "speedup_vs_cpu_baseline": None if not cpu else round(value / cpu["value"], 1),
         "donor_collapsed": collapsed,
+        "multi_gene": multi,
     }
     print(json.dumps(out))
     if dist is not None:
