@@ -169,32 +169,46 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
         lsum = 0.0;
         lsum2 = 0.0;
         const double omd = 1.0 - delta;
-        for (int j = lane; j < r; j += 64) {
-            double t[U];
+        // UNR spectrum entries per lane and trip, all loads issued before the arithmetic: the loop is
+        // bound by L2 latency otherwise (two wavefronts per SIMD at this register count)
+        constexpr int UNR = C <= 2 ? 4 : 2;
+        for (int j0 = lane; j0 < r; j0 += 64 * UNR) {
+            double t[UNR][U], s0[UNR];
+            bool ok[UNR];
 #pragma unroll
-            for (int i = 0; i < C; i++) t[i] = R.tW[(long)i * R.ldW + j];
-            t[C] = tg[j];
-            t[C + 1] = R.ty[j];
-            double wgt = 1.0, wgt2 = 0.0;
-            if (weighted) {
-                const double s0 = R.S0[j];
-                const double D = omd * s0 + delta;
-                wgt = 1.0 / D;
-                lsum += log(D);
-                if (grad) {
-                    const double oms = 1.0 - s0;
-                    lsum2 += oms * wgt;
-                    wgt2 = oms * wgt * wgt;
-                }
+            for (int q = 0; q < UNR; q++) {
+                const int j = j0 + 64 * q;
+                ok[q] = j < r;
+                const int jj = ok[q] ? j : r - 1;
+#pragma unroll
+                for (int i = 0; i < C; i++) t[q][i] = R.tW[(long)i * R.ldW + jj];
+                t[q][C] = tg[jj];
+                t[q][C + 1] = R.ty[jj];
+                s0[q] = weighted ? R.S0[jj] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const double tw = t[u] * wgt;
-                const double tw2 = t[u] * wgt2;
+            for (int q = 0; q < UNR; q++) {
+                double wgt = ok[q] ? 1.0 : 0.0, wgt2 = 0.0;
+                if (weighted) {
+                    const double D = omd * s0[q] + delta;
+                    const double inv = 1.0 / D;
+                    wgt = ok[q] ? inv : 0.0;
+                    lsum += ok[q] ? log(D) : 0.0;
+                    if (grad) {
+                        const double oms = 1.0 - s0[q];
+                        lsum2 += ok[q] ? oms * inv : 0.0;
+                        wgt2 = ok[q] ? oms * inv * inv : 0.0;
+                    }
+                }
 #pragma unroll
-                for (int v = u; v < U; v++) {
-                    S[pair_index(u, v, U)] += tw * t[v];
-                    if (grad) S2[pair_index(u, v, U)] += tw2 * t[v];
+                for (int u = 0; u < U; u++) {
+                    const double tw = t[q][u] * wgt;
+                    const double tw2 = t[q][u] * wgt2;
+#pragma unroll
+                    for (int v = u; v < U; v++) {
+                        S[pair_index(u, v, U)] += tw * t[q][v];
+                        if (grad) S2[pair_index(u, v, U)] += tw2 * t[q][v];
+                    }
                 }
             }
         }

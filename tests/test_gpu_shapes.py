@@ -1,0 +1,74 @@
+"""Odd shapes through the whole scan vs the oracle: cell counts that are not multiples of any
+tile size, many covariates, many contexts, ragged donors, sub-ranges of a panel."""
+import ctypes
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+P_RTOL, P_ATOL = 1e-5, 1e-13
+
+
+def _random_problem(n, k0, c, p, donors, seed, mode):
+    rng = np.random.default_rng(seed)
+    donor = np.sort(rng.integers(0, donors, size=n))
+    donor[:donors] = np.arange(donors)
+    donor = np.sort(donor)
+    Gd = rng.normal(size=(donors, p))
+    G = Gd[donor]
+    E = rng.normal(size=(n, k0))
+    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, c - 1))], axis=1) if c > 1 else np.ones((n, 1))
+    hK = np.zeros((n, donors))
+    hK[np.arange(n), donor] = 1.0
+    y = 0.4 * G[:, 0] + 0.5 * (G[:, 1 % p] * E[:, 0]) + E @ rng.normal(size=k0) * 0.3 + rng.normal(size=n)
+    kw = {}
+    if mode == "B":
+        kw["hK"] = hK
+    elif mode == "C":
+        kw["Ls"] = [E[:, [i]] * hK for i in range(k0)]
+    return y, E, W, G, kw
+
+
+@pytest.mark.parametrize("n,k0,c,p,donors,mode", [
+    (257, 7, 3, 5, 11, "B"),
+    (131, 2, 8, 9, 6, "B"),
+    (300, 33, 2, 6, 5, "A"),
+    (199, 3, 1, 130, 9, "C"),
+    (150, 70, 1, 3, 4, "A"),
+])
+def test_odd_shapes_match_oracle(n, k0, c, p, donors, mode):
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    y, E, W, G, kw = _random_problem(n, k0, c, p, donors, seed=n + k0, mode=mode)
+    crm = CellRegMap(y, E, W=W, **kw)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, **kw).scan_interaction(G, return_stats=True)
+    for groups in (None, "auto"):
+        pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True)
+        assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+        assert_allclose(st["Q"], ost["Q"], rtol=1e-6)
+        assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
+def test_sub_range_of_a_panel_through_the_c_abi():
+    """crm_scan_interaction(first, count) on an odd, unaligned sub-range equals the full scan."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _lib
+
+    y, E, W, G, kw = _random_problem(180, 4, 2, 77, 8, seed=5, mode="B")
+    crm = CellRegMap(y, E, W=W, **kw)
+    lib = _lib.load()
+    for groups in (None, "auto"):
+        panel = GenotypePanel(G, groups=groups)
+        full, _ = crm.scan_interaction(panel)
+        gene = crm._bind_gene()
+        first, count = 13, 51
+        pv = np.empty(count)
+        rho = np.empty(count)
+        _lib.check(lib.crm_scan_interaction(gene, panel.handle, first, count, None, None, _lib.ptr(pv), _lib.ptr(rho),
+                                            None, None, None, None, None, None, None, None, None))
+        assert np.array_equal(pv, full[first:first + count])
+        rc = lib.crm_scan_interaction(gene, panel.handle, 70, 20, None, None, _lib.ptr(pv), None, None, None, None,
+                                      None, None, None, None, None, None)
+        assert rc != 0 and b"outside the panel" in lib.crm_last_error()
