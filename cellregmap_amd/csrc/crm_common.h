@@ -56,6 +56,7 @@ constexpr int GEMM_BK = 16;
 // C + s * split_stride; reduce with reduce_splits).
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
+extern int g_contraction_bn;
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
 
 }  // namespace crm

@@ -40,8 +40,8 @@ typedef const double __attribute__((address_space(1))) * gptr_t;   // global (no
 typedef const v2d __attribute__((address_space(1))) * gptr2_t;
 
 // KRQ: 8-byte prefetch slots per thread for the G tile of the Khatri-Rao operand
-template <bool KR, int KRQ>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
+template <bool KR, int KRQ, int BN>
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
                                                           int mtiles_max, long cells_per_split,
                                                           long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     const int mtile = blockIdx.x % mtiles_max;
     const int ntile = blockIdx.x / mtiles_max;
     const int m0 = mtile * GEMM_BM;
-    const int n0 = ntile * GEMM_BN;
+    const int n0 = ntile * BN;
+    constexpr int NT = BN / 32;          // 16-wide B fragments per wavefront (wave tile 64 x BN/2)
+    constexpr int LDY = BN + 16;         // LDS row stride of the Y tile
     if (m0 >= P.M || n0 >= P.N) return;
 
     const int tid = threadIdx.x;
@@ -64,17 +66,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     // ---- LDS carve-up (two stages of every tile) --------------------------------------
     const int nb = KR ? kr_variants_per_tile(k0) : 0;
     const int lde_s = KR ? kr_e_stride(k0) : 0;
-    double* Ys = smem;                                  // [2][BK][LDT]
-    double* Xs = Ys + 2 * GEMM_BK * LDT;                // plain: [2][BK][LDT]
+    double* Ys = smem;                                  // [2][BK][LDY]
+    double* Xs = Ys + 2 * GEMM_BK * LDY;                // plain: [2][BK][LDT]
     double* Et = Xs;                                    // KR: [2][BK][lde_s]
     double* Gt = Et + 2 * GEMM_BK * lde_s;              // KR: [2][BK][nb]
 
     // ---- global -> register prefetch ----------------------------------------------------
     // plain tiles: BK x 128 doubles = BK*64 16-byte pieces, 256 threads -> BK/4 pieces each
-    constexpr int NPF = GEMM_BK / 4;
+    constexpr int NPF = GEMM_BK / 4;                 // X tile: 64 pieces per row, 4 rows per pass
+    constexpr int NPY = GEMM_BK * BN / 512;          // Y tile: BN/2 pieces per row
+    constexpr int YROWS = 512 / BN;                  // rows covered per pass (4 or 8)
     const int ld_row = tid >> 6;        // + 4 per piece
     const int ld_col = (tid & 63) * 2;
-    v2d ry[NPF], rx[NPF];
+    const int ly_row = tid / (BN / 2);
+    const int ly_col = (tid % (BN / 2)) * 2;
+    v2d ry[NPY], rx[NPF];
     // KR context tile: BK rows x round32(k0) columns (P.lde >= that, zero padded), 16-byte pieces
     const int e_pieces_row = KR ? ((k0 + 31) / 32 * 16) : 1;  // 16-byte pieces per row (k0 rounded to 32)
     constexpr int NPE = GEMM_BK / 4;                        // pieces per thread (lde <= 128)
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     double rg[KRQ];
     const int b0 = KR ? (m0 / k0) : 0;
 
-    gptr_t Yp = (gptr_t)P.Y + (cell_begin + ld_row) * P.ldy + n0 + ld_col;
+    gptr_t Yp = (gptr_t)P.Y + (cell_begin + ly_row) * P.ldy + n0 + ly_col;
     gptr_t Xp = KR ? (gptr_t)P.X + cell_begin * P.ldx + b0
                    : (gptr_t)P.X + (cell_begin + ld_row) * P.ldx + m0 + ld_col;
     gptr_t Ep = KR ? (gptr_t)P.E + cell_begin * P.lde : nullptr;
@@ -90,9 +96,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     auto fetch = [&](int s) {
         const long roff = (long)s * GEMM_BK;
 #pragma unroll
-        for (int q = 0; q < NPF; q++) {
-            ry[q] = *(gptr2_t)(Yp + (roff + 4 * q) * P.ldy);
-            if (!KR) rx[q] = *(gptr2_t)(Xp + (roff + 4 * q) * P.ldx);
+        for (int q = 0; q < NPY; q++) ry[q] = *(gptr2_t)(Yp + (roff + YROWS * q) * P.ldy);
+        if (!KR) {
+#pragma unroll
+            for (int q = 0; q < NPF; q++) rx[q] = *(gptr2_t)(Xp + (roff + 4 * q) * P.ldx);
         }
         if (KR) {
 #pragma unroll
@@ -111,9 +118,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NPF; q++) {
-            *reinterpret_cast<v2d*>(Ys + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = ry[q];
-            if (!KR)
+        for (int q = 0; q < NPY; q++)
+            *reinterpret_cast<v2d*>(Ys + (buf * GEMM_BK + ly_row + YROWS * q) * LDY + ly_col) = ry[q];
+        if (!KR) {
+#pragma unroll
+            for (int q = 0; q < NPF; q++)
                 *reinterpret_cast<v2d*>(Xs + (buf * GEMM_BK + ld_row + 4 * q) * LDT + ld_col) = rx[q];
         }
         if (KR) {
@@ -147,13 +156,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
             xe[t] = j;
         }
     }
-    const int yb = wn * 64 + l15;
+    const int yb = wn * (BN / 2) + l15;
 
-    auto load_frags = [&](int buf, int ks, double (&a)[4], double (&b)[4]) {
+    auto load_frags = [&](int buf, int ks, double (&a)[4], double (&b)[NT]) {
         const int row = buf * GEMM_BK + ks * 4 + lq;
 #pragma unroll
+        for (int t = 0; t < NT; t++) b[t] = Ys[row * LDY + yb + t * 16];
+#pragma unroll
         for (int t = 0; t < 4; t++) {
-            b[t] = Ys[row * LDT + yb + t * 16];
             if (KR)
                 a[t] = Gt[row * nb + xg[t]] * Et[row * lde_s + xe[t]];
             else
@@ -161,17 +171,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
         }
     };
 
-    v4d acc[4][4];
+    v4d acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NT; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    auto mma = [&](const double (&a)[4], const double (&b)[4]) {
+    auto mma = [&](const double (&a)[4], const double (&b)[NT]) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NT; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     };
 
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
     constexpr int KS = GEMM_BK / 4;  // k-steps per stage
     constexpr int STASH_AFTER = KS - 2;  // latest point that still precedes the stage's barrier
     static_assert(KS >= 2, "pipeline needs at least two k-steps per stage");
-    double fa[2][4], fb[2][4];
+    double fa[2][4], fb[2][NT];
     fetch(0);
     stash(0);
     __syncthreads();
@@ -214,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmProblem* __re
             const int m = m0 + wm * 64 + i * 16 + lq + 4 * reg;
             if (m < P.M) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int n = n0 + wn * 64 + j * 16 + l15;
+                for (int j = 0; j < NT; j++) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + l15;
                     if (n < P.N) Cb[(long)m * P.ldc + n] = acc[i][j][reg];
                 }
             }
@@ -231,6 +241,8 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
     C[i] = s;
 }
 
+int g_contraction_bn = 0;  // output-tile width override: 0 = choose per launch, else 64 or 128
+
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
@@ -240,25 +252,48 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
         return CRM_ERR_ARG;
     }
     const int mt = (max_m + GEMM_BM - 1) / GEMM_BM;
-    const int nt = (max_n + GEMM_BN - 1) / GEMM_BN;
+    // 128-wide tiles (two workgroups per CU) give the Khatri-Rao operand the most MFMAs per LDS read
+    // (62.2 vs 60.1 TFLOP/s at config 3); 64-wide tiles (three per CU) fill the chip better when a
+    // launch has few tiles (skinny side contractions: 50.5 vs 42.1 TFLOP/s at M = 1024, N = 5120)
+    int bn = g_contraction_bn;
+    if (bn != 64 && bn != 128) {
+        const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
+        bn = tiles128 < 1024 ? 64 : 128;
+    }
+    const int nt = (max_n + bn - 1) / bn;
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
-    size_t lds = (size_t)2 * GEMM_BK * LDT * sizeof(double);
+    size_t lds = (size_t)2 * GEMM_BK * (bn + 16) * sizeof(double);
     if (khatri_rao) {
         if (k0 < 1 || k0 > 128) {
             set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
             return CRM_ERR_UNSUPPORTED;
         }
         lds += (size_t)2 * GEMM_BK * (kr_variants_per_tile(k0) + kr_e_stride(k0)) * sizeof(double);
-        if (GEMM_BK * kr_variants_per_tile(k0) <= 256)
-            hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cells / ksplit, split_stride, k0);
-        else
-            hipLaunchKernelGGL((gemm_tn_kernel<true, (GEMM_BK * GEMM_BM + 255) / 256>), grid, dim3(256), lds,
-                               st, probs_dev, mt, cells / ksplit, split_stride, k0);
+        constexpr int KRQ_BIG = (GEMM_BK * GEMM_BM + 255) / 256;
+        const bool small = GEMM_BK * kr_variants_per_tile(k0) <= 256;
+        if (bn == 64) {
+            if (small)
+                hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
+                                   cells / ksplit, split_stride, k0);
+            else
+                hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 64>), grid, dim3(256), lds, st, probs_dev, mt,
+                                   cells / ksplit, split_stride, k0);
+        } else {
+            if (small)
+                hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
+                                   cells / ksplit, split_stride, k0);
+            else
+                hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 128>), grid, dim3(256), lds, st, probs_dev, mt,
+                                   cells / ksplit, split_stride, k0);
+        }
     } else {
         lds += (size_t)2 * GEMM_BK * LDT * sizeof(double);
-        hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, dim3(256), lds, st, probs_dev, mt,
-                           cells / ksplit, split_stride, 0);
+        if (bn == 64)
+            hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
+                               cells / ksplit, split_stride, 0);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
+                               cells / ksplit, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());
     return CRM_OK;

@@ -67,6 +67,8 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill, dim3((cells * 64 + 255) / 256), dim3(256), 0, st, E, cells * 64, 3u);
     crm::GemmProblem* pd;
     CK(hipMalloc(&pd, sizeof(crm::GemmProblem)));
+    if (argc > 1) crm::g_contraction_bn = atoi(argv[1]);
+    printf("tile width %d\n", crm::g_contraction_bn);
     for (int B : Bs) {
         // plain: T = G' Q0  (M = B, N = r)
         crm::GemmProblem p{};
