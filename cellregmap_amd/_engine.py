@@ -9,6 +9,7 @@ import ctypes
 import hashlib
 import weakref
 from collections import OrderedDict
+from collections.abc import Sequence
 from typing import Optional
 
 import numpy as np
@@ -39,13 +40,29 @@ def _economic_svd(X):
     return U[:, ok], s[ok], Vt[ok, :]
 
 
+class HadamardHalves(Sequence):
+    """The list ``[diag(us[:, i]) @ hK for i]`` that ``get_L_values`` returns, kept in factored form:
+    indexing / iterating yields the same arrays as the reference's list, but ``CellRegMap`` hands the
+    two factors to the device and never materialises the n x (k*m) concatenation on the host."""
+
+    def __init__(self, us, hK):
+        self.us = np.ascontiguousarray(us, dtype=float)
+        self.hK = np.ascontiguousarray(hK, dtype=float)
+
+    def __len__(self):
+        return self.us.shape[1]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        return self.us[:, [i]] * self.hK
+
+
 def get_L_values(hK, E):
     """L_i = diag((U S)[:, i]) hK with U, S from the economic SVD of E
     (_cellregmap.py:533-545); sum_i L_i L_i' = K o EE' (proof.md)."""
     U, S, _ = _economic_svd(E)
-    us = U * S
-    hK = np.asarray(hK, float)
-    return [us[:, [i]] * hK for i in range(us.shape[1])]
+    return HadamardHalves(U * S, np.asarray(hK, float))
 
 
 class _Background:
@@ -84,6 +101,32 @@ def _digest(*arrays):
 
 
 def _make_background(E1, B, rho, device, rel_tol=0.0, cache=True):
+    if isinstance(B, HadamardHalves):
+        return _make_background_hadamard(E1, B, rho, device, rel_tol, cache)
+    return _make_background_dense(E1, B, rho, device, rel_tol, cache)
+
+
+def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
+    lib = _lib.load()
+    key = (device, "hadamard", _digest(E1, halves.us, halves.hK), tuple(np.asarray(rho, float)), rel_tol)
+    if cache and key in _bg_cache:
+        _bg_cache.move_to_end(key)
+        return _bg_cache[key]
+    ctx = _context(device)
+    E1c, us, hK, rho = _lib.f64(E1), halves.us, halves.hK, _lib.f64(rho)
+    h = ctypes.c_void_p()
+    _lib.check(lib.crm_background_create_hadamard(ctx, E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(us),
+                                                  us.shape[1], _lib.ptr(hK), hK.shape[1], rho.shape[0],
+                                                  _lib.ptr(rho), float(rel_tol), ctypes.byref(h)))
+    bg = _Background(h, rho, device)
+    if cache:
+        _bg_cache[key] = bg
+        while len(_bg_cache) > BACKGROUND_CACHE_SIZE:
+            _bg_cache.popitem(last=False)
+    return bg
+
+
+def _make_background_dense(E1, B, rho, device, rel_tol=0.0, cache=True):
     """hS(rho) = [sqrt(rho) E1, sqrt(1-rho) B] -> economic eigendecompositions on the device.
     Re-used across objects with identical (E1, B, rho): the reference redoes the 11
     decompositions per ``CellRegMap(...)``, i.e. per gene."""
@@ -230,7 +273,10 @@ class CellRegMap:
             self._E1 = np.asarray(E1, float)
         else:
             self._E1 = np.asarray(E, float)
-        self._Ls = list(np.asarray(L, float) for L in Ls)
+        if isinstance(Ls, HadamardHalves):
+            self._Ls = Ls  # factored; elements are formed on demand
+        else:
+            self._Ls = list(np.asarray(L, float) for L in Ls)
 
         assert self._W.ndim == 2
         assert self._E0.ndim == 2
@@ -238,9 +284,12 @@ class CellRegMap:
         assert self._y.shape[0] == self._W.shape[0]
         assert self._y.shape[0] == self._E0.shape[0]
         assert self._y.shape[0] == self._E1.shape[0]
-        for L in Ls:
-            assert self._y.shape[0] == L.shape[0]
-            assert L.ndim == 2
+        if isinstance(Ls, HadamardHalves):
+            assert self._y.shape[0] == Ls.us.shape[0] == Ls.hK.shape[0]
+        else:
+            for L in Ls:
+                assert self._y.shape[0] == L.shape[0]
+                assert L.ndim == 2
 
         self._device = device
         # background modes of _cellregmap.py:101-131
@@ -253,7 +302,7 @@ class CellRegMap:
                 B = np.asarray(hK, float)
         else:
             self._rho1 = _RHO_GRID
-            B = np.concatenate(self._Ls, axis=1)
+            B = self._Ls if isinstance(self._Ls, HadamardHalves) else np.concatenate(self._Ls, axis=1)
         if background is not None:
             self._bg = background
         else:

@@ -27,6 +27,9 @@ SIGNATURES = {
                                                 ctypes.POINTER(vp)]),
     "crm_background_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long,
                                              ctypes.c_int, vp, ctypes.c_double, ctypes.POINTER(vp)]),
+    "crm_background_create_hadamard": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_int, vp,
+                                                      ctypes.c_int, ctypes.c_int, vp, ctypes.c_double,
+                                                      ctypes.POINTER(vp)]),
     "crm_background_destroy": (None, [vp]),
     "crm_background_rank": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_background_read": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),

@@ -139,10 +139,27 @@ int transpose(hipStream_t st, const double* src, long ld_src, long rows, long co
 }  // namespace
 }  // namespace crm
 
-extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B,
-                                     long kb, int nrho, const double* rho, double rel_tol,
-                                     crm_background** out) {
-    if (!ctx || !out || n <= 0 || !E1 || k1 < 1 || kb < 0 || (kb > 0 && !B) || nrho < 1 || !rho)
+namespace crm {
+namespace {
+// B[i, j * m + d] = U[i, j] * hK[i, d]: the halves L_j = diag(U[:, j]) hK of K o E2E2' (proof.md,
+// get_L_values _cellregmap.py:533-545) written straight into H = [E1, B]
+__global__ void hadamard_halves_kernel(const double* __restrict__ U, int k2, const double* __restrict__ hK, int m,
+                                       long n, double* __restrict__ H, long ldh, int col0) {
+    const long i = blockIdx.x;
+    if (i >= n) return;
+    for (int e = threadIdx.x; e < k2 * m; e += blockDim.x) {
+        const int j = e / m, d = e - j * m;
+        H[i * ldh + col0 + e] = U[i * k2 + j] * hK[i * m + d];
+    }
+}
+}  // namespace
+}  // namespace crm
+
+// B given explicitly (kb columns), or as Hadamard factors U (n x k2) and hK (n x m) with kb = k2 * m
+static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
+                                  const double* U, int k2, const double* hK, int m, int nrho,
+                                  const double* rho, double rel_tol, crm_background** out) {
+    if (!ctx || !out || n <= 0 || !E1 || k1 < 1 || kb < 0 || (kb > 0 && !B && !(U && hK)) || nrho < 1 || !rho)
         return CRM_ERR_ARG;
     if (nrho > CRM_MAX_RHO) {
         set_error("background: %d grid points (supported up to %d)", nrho, CRM_MAX_RHO);
@@ -174,9 +191,22 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
     CRM_HIP(hipMemsetAsync(dH.ptr, 0, sizeof(double) * np * cp, st));
     CRM_HIP(hipMemcpy2DAsync(dH.ptr, cp * sizeof(double), E1, k1 * sizeof(double), k1 * sizeof(double), n,
                              hipMemcpyHostToDevice, st));
-    if (kb > 0)
+    if (kb > 0 && B) {
         CRM_HIP(hipMemcpy2DAsync(dH.as<double>() + k1, cp * sizeof(double), B, kb * sizeof(double),
                                  kb * sizeof(double), n, hipMemcpyHostToDevice, st));
+    } else if (kb > 0) {
+        DevBuf dU, dK;
+        CRM_TRY(dU.ensure(sizeof(double) * n * k2));
+        CRM_TRY(dK.ensure(sizeof(double) * n * m));
+        CRM_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
+        CRM_HIP(hipMemcpyAsync(dK.ptr, hK, sizeof(double) * n * m, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(hadamard_halves_kernel, dim3((unsigned)n), dim3(256), 0, st, dU.as<double>(), k2,
+                           dK.as<double>(), m, n, dH.as<double>(), cp, k1);
+        CRM_HIP(hipGetLastError());
+        CRM_HIP(hipStreamSynchronize(st));
+        dU.release();
+        dK.release();
+    }
     CRM_TRY(dHt.ensure(sizeof(double) * cp * np));
     CRM_HIP(hipMemsetAsync(dHt.ptr, 0, sizeof(double) * cp * np, st));
     CRM_TRY(transpose(st, dH.as<double>(), cp, n, cols, dHt.as<double>(), np));
@@ -378,4 +408,18 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
 #undef CRM_BG_HIP
     *out = bg;
     return CRM_OK;
+}
+
+extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B,
+                                     long kb, int nrho, const double* rho, double rel_tol,
+                                     crm_background** out) {
+    if (kb > 0 && !B) return CRM_ERR_ARG;
+    return background_create_core(ctx, n, E1, k1, B, kb, nullptr, 0, nullptr, 0, nrho, rho, rel_tol, out);
+}
+
+extern "C" int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k1, const double* U,
+                                              int k2, const double* hK, int m, int nrho, const double* rho,
+                                              double rel_tol, crm_background** out) {
+    if (!U || !hK || k2 < 1 || m < 1) return CRM_ERR_ARG;
+    return background_create_core(ctx, n, E1, k1, nullptr, (long)k2 * m, U, k2, hK, m, nrho, rho, rel_tol, out);
 }

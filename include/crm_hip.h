@@ -56,6 +56,12 @@ int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, 
  * inert in every quantity of the path); rel_tol <= 0 selects the default 1e-12. */
 int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
                           int nrho, const double* rho, double rel_tol, crm_background** out);
+/* Mode C without materialising the halves on the host: B = [L_1 ... L_k2], L_j = diag(U[:, j]) hK
+ * (get_L_values, _cellregmap.py:533-545; U = left singular vectors of E2 times the singular values,
+ * n x k2; hK n x m) is formed on the device.  Same result as crm_background_create with B given. */
+int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k1, const double* U, int k2,
+                                   const double* hK, int m, int nrho, const double* rho, double rel_tol,
+                                   crm_background** out);
 void crm_background_destroy(crm_background* bg);
 /* Introspection / read-back (tests): rank at grid point i; copy of S0 / Q0 (n x r, ld r). */
 int crm_background_rank(const crm_background* bg, int i);
