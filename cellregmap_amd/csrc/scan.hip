@@ -184,7 +184,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipSetDevice(g->bg->ctx->device);
     (void)hipStreamSynchronize(g->bg->ctx->stream);
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_TZ, &g->dt_Bd,
-                    &g->dt_Z1, &g->dt_Z2, &g->dt_Z3, &g->dt_sums})
+                    &g->dt_Z1, &g->dt_Z2, &g->dt_Z3, &g->dt_sums, &g->dt_Zt})
         b->release();
     delete g;
 }
@@ -275,12 +275,43 @@ __global__ void donor_sums_kernel(const int* __restrict__ group, long cells, int
     sums[d * 16 + q] = acc;
 }
 
+__global__ void permute_group_kernel(const int* __restrict__ group, const int* __restrict__ idx, long n,
+                                     int* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = group[idx[i]];
+}
+
+// Z2[b, j] = sum_{d, d'} gamma_{d,b} gamma_{d',b} C[(d, d'), j]  with  C[(d, d'), :] = sum_i z'_d[i] z_d'[i] E[i, :]
+// (test direction carried by the permuted indicators z', fixed effect by the unpermuted ones)
+__global__ __launch_bounds__(128) void donor_cross_kernel(const double* __restrict__ Gam, long ld_gam, int m,
+                                                           const double* __restrict__ C, long ldc, int k0,
+                                                           double* __restrict__ Z2, long ldz2) {
+    __shared__ double gam[BLOCK_SLACK_MAX > 256 ? 256 : BLOCK_SLACK_MAX];
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < m; d += blockDim.x) gam[d] = Gam[(long)d * ld_gam + b];
+    __syncthreads();
+    for (int j = threadIdx.x; j < k0; j += blockDim.x) {
+        double acc = 0.0;
+        for (int d = 0; d < m; d++) {
+            const double gd = gam[d];
+            if (gd == 0.0) continue;
+            double inner = 0.0;
+            const double* row = C + (long)d * m * ldc + j;
+            for (int e = 0; e < m; e++) inner += gam[e] * row[(long)e * ldc];
+            acc += gd * inner;
+        }
+        Z2[(long)b * ldz2 + j] = acc;
+    }
+}
+
 // Per-donor tables of the collapsed path: every n-length contraction of the scan is linear in
 // diag(g) (or diag(g)^2 = sum_d gamma_d^2 diag(z_d) for donor-constant g), so it is taken once per donor
 // indicator z_d with the same kernels and afterwards combined with the donor dosages gamma.
 static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full, const double* d_Ep,
-                              const double* d_EE) {
-    // full: also the phenotype-free tables (TZ, Bd, Z2, Z3), owned by the first gene of a call
+                              const double* d_EE, const double* Zt, bool cross) {
+    // full: also the phenotype-free tables (TZ, Bd, Z2, Z3), owned by the first gene of a call.
+    // Zt: indicators of the test direction (rows permuted by idx_G, else the panel's own);
+    // cross: Z2 becomes the m*m-row table of the mixed products z'_d o z_d'.
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;
     hipStream_t st = ctx->stream;
@@ -311,7 +342,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
         CRM_HIP(hipStreamSynchronize(st));
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
-            p.X = Z; p.ldx = panel->ldz; p.E = d_Ep; p.lde = gene->ld_ep; p.k0 = k0;
+            p.X = Zt; p.ldx = panel->ldz; p.E = d_Ep; p.lde = gene->ld_ep; p.k0 = k0;
             p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
             p.C = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
             p.M = (int)m * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
@@ -326,6 +357,20 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
         {&gene->dt_Z1, gene->YE.as<double>(), gene->ld_ye, k0 * (1 + c), ldZ1, true},
         {&gene->dt_Z2, d_Ep, gene->ld_ep, k0, ldZ2, full},
         {&gene->dt_Z3, d_EE, gene->ld_ee, npair, ldZ3, full}};
+    if (full && cross) {
+        // C[(d*m + d'), :] = KR(Zt, Z)' Ep : the Khatri-Rao contraction with the indicators as "contexts"
+        side[1].needed = false;
+        const long rows = m * m;
+        CRM_TRY(gene->dt_Z2.ensure(sizeof(double) * (size_t)rows * ldZ2));
+        CRM_HIP(hipMemsetAsync(gene->dt_Z2.ptr, 0, sizeof(double) * (size_t)rows * ldZ2, st));
+        GemmProblem p{};
+        p.X = Zt; p.ldx = panel->ldz; p.E = Z; p.lde = panel->ldz; p.k0 = (int)m;
+        p.Y = d_Ep; p.ldy = gene->ld_ep; p.C = gene->dt_Z2.as<double>(); p.ldc = ldZ2;
+        p.M = (int)rows; p.N = k0;
+        CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)rows, k0, np, true, (int)m, 1, 0));
+        CRM_HIP(hipStreamSynchronize(st));
+    }
     for (auto& sd : side) {
         if (!sd.needed) continue;
         const int ks = pick_split(np, sd.ld / GEMM_BN);
@@ -333,7 +378,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
         CRM_TRY(sd.buf->ensure(sizeof(double) * (size_t)sz * ks));
         CRM_HIP(hipMemsetAsync(sd.buf->ptr, 0, sizeof(double) * (size_t)sz * ks, st));
         GemmProblem p{};
-        p.X = Z; p.ldx = panel->ldz; p.Y = sd.Y; p.ldy = sd.ldy; p.C = sd.buf->as<double>(); p.ldc = sd.ld;
+        p.X = Zt; p.ldx = panel->ldz; p.Y = sd.Y; p.ldy = sd.ldy; p.C = sd.buf->as<double>(); p.ldc = sd.ld;
         p.M = (int)m; p.N = sd.N;
         CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)m, sd.N, np, false, 0, ks, sz));
@@ -459,7 +504,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
     CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldp));
     CRM_TRY(ctx->ws_G2.ensure(sizeof(double) * (size_t)np * ldb));
-    if (idx_G) {
+    if (idx_G) {  // (unused when the scan ends up on the collapsed path)
         CRM_TRY(ctx->ws_Gt.ensure(sizeof(double) * (size_t)np * ldb));
         CRM_TRY(ctx->ws_GG.ensure(sizeof(double) * (size_t)np * ldb));
     }
@@ -507,16 +552,30 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // genotype permutation hook is not in use
     const bool grouped = panel->grouped;
     const size_t bd_bytes = grouped ? sizeof(double) * (size_t)nrho * panel->m_pad * k0 * ldq : 0;
-    const bool collapsed = grouped && !idx_G && ctx->collapse && bd_bytes <= ((size_t)48 << 30);
+    // (with the genotype permutation hook the test direction is constant within the permuted groups;
+    // its mixed table needs the indicators as Khatri-Rao "contexts": m <= 128)
+    const bool collapsed = grouped && ctx->collapse && bd_bytes <= ((size_t)48 << 30) && (!idx_G || panel->m <= 128);
+    const bool cross = collapsed && idx_G;
     const long mp = grouped ? panel->m_pad : 0;
     if (collapsed) {
+        const double* Zt = panel->Z.as<double>();
+        if (cross) {
+            CRM_TRY(g0->dt_Zt.ensure(sizeof(double) * (size_t)np * panel->ldz + sizeof(int) * n));
+            int* gperm = reinterpret_cast<int*>(g0->dt_Zt.as<double>() + (size_t)np * panel->ldz);
+            hipLaunchKernelGGL(permute_group_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               panel->group.as<int>(), d_idxG, n, gperm);
+            CRM_HIP(hipGetLastError());
+            CRM_TRY(launch_indicator(st, gperm, n, np, (int)panel->m, g0->dt_Zt.as<double>(), panel->ldz));
+            Zt = g0->dt_Zt.as<double>();
+        }
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
-            const bool have = g->dt_panel == panel && !idx_E && (gi > 0 || g->dt_full);
+            const bool reusable = !idx_E && !idx_G;
+            const bool have = g->dt_panel == panel && reusable && (gi > 0 || g->dt_full);
             if (!have) {
                 g->dt_panel = nullptr;
-                CRM_TRY(build_donor_tables(g, panel, gi == 0, d_Ep, d_EE));
-                if (!idx_E) g->dt_panel = panel;
+                CRM_TRY(build_donor_tables(g, panel, gi == 0, d_Ep, d_EE, Zt, cross));
+                if (reusable) g->dt_panel = panel;
             }
         }
     }
@@ -655,7 +714,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         // 7. elementwise products for the side contractions
         double* G2 = ctx->ws_G2.as<double>();
-        double* GG = idx_G ? ctx->ws_GG.as<double>() : nullptr;
+        double* GG = (idx_G && !collapsed) ? ctx->ws_GG.as<double>() : nullptr;
         CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
         if (!GG) GG = G2;
         // 8. y-free side contractions: Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
@@ -668,8 +727,14 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.X = G2; p.Y = collapsed ? g0->dt_Z3.as<double>() : d_EE; p.ldy = g0->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
             probs[2] = p;
             CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data() + 1, sizeof(GemmProblem) * 2, hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
-            CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, s2, z2_sz));
+            if (cross) {
+                hipLaunchKernelGGL(donor_cross_kernel, dim3(nb), dim3(128), 0, st, Gb, ldb, (int)panel->m,
+                                   g0->dt_Z2.as<double>(), ldZ2, k0, dZ2, ldZ2);
+                CRM_HIP(hipGetLastError());
+            } else {
+                CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
+                CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, s2, z2_sz));
+            }
             CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, xrows, false, 0, s3, z3_sz));
             CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, s3, z3_sz));
         }

@@ -206,7 +206,7 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     first = CellRegMap(Y[:, 0], c.E, W=c.W, Ls=Ls)
     crms = [first] + [CellRegMap(Y[:, i], c.E, W=c.W, Ls=Ls, background=first._bg) for i in range(1, 4)]
     panel = GenotypePanel(c.G, groups=None if genotypes == "dense" else "auto")
-    for kw in ({}, {"idx_E": rng.permutation(c.y.size)}):
+    for kw in ({}, {"idx_E": rng.permutation(c.y.size)}, {"idx_G": rng.permutation(c.y.size)}):
         pv, info = scan_interaction_many(crms, panel, **kw)
         assert pv.shape == (4, 70)
         assert len(set(np.unique(info["rho1"]))) > 1  # the genes do not all agree on rho*
