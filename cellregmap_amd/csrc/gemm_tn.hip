@@ -158,16 +158,27 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
     }
     const int yb = wn * (BN / 2) + l15;
 
-    auto load_frags = [&](int buf, int ks, double (&a)[4], double (&b)[NT]) {
+    // Fragment loads are split in two so that the LDS reads of k-step ks+1 can be issued before the
+    // MFMAs of k-step ks and the Khatri-Rao products taken after them (the products would otherwise
+    // sit, with their LDS latency, in front of the matrix instructions).
+    auto load_raw = [&](int buf, int ks, double (&a)[4], double (&e)[4], double (&b)[NT]) {
         const int row = buf * GEMM_BK + ks * 4 + lq;
 #pragma unroll
         for (int t = 0; t < NT; t++) b[t] = Ys[row * LDY + yb + t * 16];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (KR)
-                a[t] = Gt[row * nb + xg[t]] * Et[row * lde_s + xe[t]];
-            else
+            if (KR) {
+                a[t] = Gt[row * nb + xg[t]];
+                e[t] = Et[row * lde_s + xe[t]];
+            } else {
                 a[t] = Xs[row * LDT + xa[t]];
+            }
+        }
+    };
+    auto finish = [&](double (&a)[4], const double (&e)[4]) {
+        if (KR) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) a[t] *= e[t];
         }
     };
 
@@ -191,11 +202,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
     constexpr int KS = GEMM_BK / 4;  // k-steps per stage
     constexpr int STASH_AFTER = KS - 2;  // latest point that still precedes the stage's barrier
     static_assert(KS >= 2, "pipeline needs at least two k-steps per stage");
-    double fa[2][4], fb[2][NT];
+    double fa[2][4], fb[2][NT], fe[4];
     fetch(0);
     stash(0);
     __syncthreads();
-    load_frags(0, 0, fa[0], fb[0]);
+    load_raw(0, 0, fa[0], fe, fb[0]);
+    finish(fa[0], fe);
 
     for (int s = 0; s < stages; s++) {
         const int buf = s & 1;
@@ -204,13 +216,15 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const int cur = ks & 1, nxt = cur ^ 1;
+            const bool have_next = ks + 1 < KS || more;
             if (ks + 1 < KS) {
-                load_frags(buf, ks + 1, fa[nxt], fb[nxt]);
+                load_raw(buf, ks + 1, fa[nxt], fe, fb[nxt]);
             } else {
                 __syncthreads();  // every wave has stashed stage s+1 and is done reading `buf^1`
-                if (more) load_frags(buf ^ 1, 0, fa[nxt], fb[nxt]);
+                if (more) load_raw(buf ^ 1, 0, fa[nxt], fe, fb[nxt]);
             }
             mma(fa[cur], fb[cur]);
+            if (have_next) finish(fa[nxt], fe);
             if (ks == STASH_AFTER && more) stash(buf ^ 1);
         }
     }
