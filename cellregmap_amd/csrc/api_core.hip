@@ -137,6 +137,13 @@ int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* 
 }
 
 // ---- single-kernel hooks -------------------------------------------------------------
+int crm_test_set_contraction(int tile_width, int lds_dma) {
+    if (tile_width != 0 && tile_width != 64 && tile_width != 128) return CRM_ERR_ARG;
+    g_contraction_bn = tile_width;
+    g_contraction_glds = lds_dma ? 1 : 0;
+    return CRM_OK;
+}
+
 int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit) {
     if (!c || cells <= 0 || M <= 0 || N <= 0 || !X || !Y || !C || ksplit < 1) return CRM_ERR_ARG;

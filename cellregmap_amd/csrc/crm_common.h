@@ -57,6 +57,9 @@ constexpr int GEMM_BK = 16;
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
 extern int g_contraction_bn;
+extern int g_contraction_glds;
+int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
+                        bool khatri_rao, int k0, int ksplit, long split_stride);
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
 
 }  // namespace crm

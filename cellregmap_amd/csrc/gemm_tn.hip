@@ -255,6 +255,7 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
     C[i] = s;
 }
 
+int g_contraction_glds = 1;  // 128-wide tiles through the LDS-DMA kernel (gemm_tn_glds.hip)
 int g_contraction_bn = 0;  // output-tile width override: 0 = choose per launch, else 64 or 128
 
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
@@ -275,6 +276,13 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
         bn = tiles128 < 1024 ? 64 : 128;
     }
     const int nt = (max_n + bn - 1) / bn;
+    if (bn == 128 && g_contraction_glds) {
+        if (khatri_rao && (k0 < 1 || k0 > 128)) {
+            set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
+            return CRM_ERR_UNSUPPORTED;
+        }
+        return launch_gemm_tn_glds(st, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride);
+    }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
     size_t lds = (size_t)2 * GEMM_BK * (bn + 16) * sizeof(double);
     if (khatri_rao) {

@@ -131,7 +131,10 @@ int crm_kernel_timer_read(crm_ctx* ctx, double* kr_ms, long* kr_launches, double
                           double* total_ms);
 
 /* ---- unit-test hooks (exercise single kernels through the same ABI) --------------------
- * C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
+ * Contraction kernel variant for subsequent launches (process-wide): tile_width 0 = chosen per
+ * launch, 64 or 128 forced; lds_dma = 1 lets 128-wide launches use the direct-to-LDS kernel. */
+int crm_test_set_contraction(int tile_width, int lds_dma);
+/* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
 int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit);
 /* C ((B*k0) x N) = KR(G, E)' Y with G: cells x B, E: cells x k0, Y: cells x N. */

@@ -19,6 +19,19 @@ def ctx():
     lib.crm_ctx_destroy(h)
 
 
+VARIANTS = [(0, 1), (64, 0), (128, 0), (128, 1)]  # (tile width, LDS-DMA): auto, 3 per CU, register-staged, LDS-DMA
+
+
+@pytest.fixture(params=VARIANTS, ids=lambda v: f"tile{v[0]}-dma{v[1]}")
+def variant(request, ctx):
+    from cellregmap_amd import _lib
+
+    lib, _ = ctx
+    _lib.check(lib.crm_test_set_contraction(*request.param))
+    yield request.param
+    _lib.check(lib.crm_test_set_contraction(0, 1))
+
+
 def _contract(ctx, X, Y, ksplit=1):
     from cellregmap_amd import _lib
 
@@ -30,7 +43,7 @@ def _contract(ctx, X, Y, ksplit=1):
     return C
 
 
-def test_contract_layout_with_integer_data(ctx):
+def test_contract_layout_with_integer_data(ctx, variant):
     # exact small integers + asymmetric operands: catches any row/column swap of the
     # v_mfma_f64_16x16x4_f64 fragment maps
     rng = np.random.default_rng(0)
@@ -43,7 +56,7 @@ def test_contract_layout_with_integer_data(ctx):
 
 @pytest.mark.parametrize("cells,M,N,ksplit", [(1000, 130, 257, 1), (4096, 256, 128, 4), (777, 16, 16, 1),
                                                (20000, 200, 1275, 5)])
-def test_contract_random(ctx, cells, M, N, ksplit):
+def test_contract_random(ctx, variant, cells, M, N, ksplit):
     rng = np.random.default_rng(cells + M)
     X = rng.normal(size=(cells, M))
     Y = rng.normal(size=(cells, N))
@@ -53,7 +66,7 @@ def test_contract_random(ctx, cells, M, N, ksplit):
 
 @pytest.mark.parametrize("cells,B,k0,N", [(500, 7, 10, 140), (2048, 20, 50, 300), (333, 40, 3, 64),
                                            (1024, 5, 128, 130), (640, 300, 1, 128)])
-def test_contract_khatri_rao(ctx, cells, B, k0, N):
+def test_contract_khatri_rao(ctx, variant, cells, B, k0, N):
     from cellregmap_amd import _lib
 
     lib, h = ctx
