@@ -46,6 +46,7 @@ SIGNATURES = {
     "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
     "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_set_null_fit_polish": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_set_fast_rotation": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
     "crm_test_set_contraction": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

@@ -108,6 +108,12 @@ int crm_set_null_fit_polish(crm_ctx* c, int on) {
     return CRM_OK;
 }
 
+int crm_set_fast_rotation(crm_ctx* c, int on) {
+    if (!c) return CRM_ERR_ARG;
+    c->fast_T = on != 0;
+    return CRM_OK;
+}
+
 int crm_kernel_timer_reset(crm_ctx* c) {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));

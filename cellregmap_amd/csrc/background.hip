@@ -351,7 +351,15 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     dMt.release();
     dC.release();
     dCr.release();
-    dH.release();
+    if (thin) {
+        // keep the half factor: T(rho) = Q0(rho)'G is later taken as Mix(rho)' (H'G), see scan.hip
+        bg->H = dH;
+        dH = DevBuf();
+        bg->ldh = cp;
+        bg->cols = cols;
+    } else {
+        dH.release();
+    }
     CRM_BG(dG.ensure(sizeof(double) * ldq * ldq * 2));
     CRM_BG(dQt.ensure(sizeof(double) * ldq * np));
     CRM_BG(dErr.ensure(sizeof(double) * ((ldq + 255) / 256) * ldq));
@@ -373,6 +381,13 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
                             (int)n, r, cp));
         }
         CRM_BG_HIP(hipStreamSynchronize(st));
+        if (thin) {
+            CRM_BG(bg->Mix[i].ensure(sizeof(double) * cp * ldq));
+            CRM_BG_HIP(hipMemsetAsync(bg->Mix[i].ptr, 0, sizeof(double) * cp * ldq, st));
+            CRM_BG_HIP(hipMemcpy2DAsync(bg->Mix[i].ptr, ldq * sizeof(double), Mbuf[i].ptr, ldm * sizeof(double),
+                                        r * sizeof(double), cols, hipMemcpyDeviceToDevice, st));
+            CRM_BG_HIP(hipStreamSynchronize(st));
+        }
         Mbuf[i].release();
         // Newton-Schulz polish of the orthonormality: Q0 <- Q0 (1.5 I - 0.5 Q0'Q0).  The Gram route
         // loses it for small eigenvalues (defect ~ eps * S_max / S_j) and the library eigenvectors
@@ -401,9 +416,29 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
             CRM_BG_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * np, st));
             CRM_BG(transpose(st, bg->Q0[i].as<double>(), ldq, n, r, dQt.as<double>(), np));
             CRM_BG(contract(ctx, dQt.as<double>(), np, N, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, round_up(r, GEMM_BK)));
+            if (thin) {
+                // the same correction on the mixing matrix keeps Q0 == H Mix:  Mix <- Mix N
+                CRM_BG_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * std::min(np, cp), st));
+                CRM_BG(transpose(st, bg->Mix[i].as<double>(), ldq, cols, r, dQt.as<double>(), cp));
+                CRM_BG(contract(ctx, dQt.as<double>(), cp, N, ldq, bg->Mix[i].as<double>(), ldq, (int)cols, r,
+                                round_up(r, GEMM_BK)));
+            }
         }
     }
     CRM_BG_HIP(hipStreamSynchronize(st));
+    // the mixing-matrix route amplifies rounding by sqrt(S_max / S_min): use it only for spectra
+    // whose kept part is well conditioned
+    bg->fast_T = thin;
+    for (int i = 0; i < nrho && bg->fast_T; i++) {
+        if (bg->r[i] == 0) continue;
+        double smax = 0.0, smin = 1e300;
+        for (double v : S0_host[i]) { smax = std::max(smax, v); smin = std::min(smin, v); }
+        if (!(smax <= 1e6 * smin)) bg->fast_T = false;
+    }
+    if (!bg->fast_T) {
+        bg->H.release();
+        for (int i = 0; i < nrho; i++) bg->Mix[i].release();
+    }
 #undef CRM_BG
 #undef CRM_BG_HIP
     *out = bg;

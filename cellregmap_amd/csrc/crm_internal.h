@@ -32,6 +32,7 @@ struct crm_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = crm::CRM_DEFAULT_BLOCK;
+    bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
@@ -40,8 +41,8 @@ struct crm_ctx {
     size_t timed_used = 0;
     double kr_flops = 0.0;
     // scan workspace (grown on demand, reused across calls)
-    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext;
+    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH;
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };

@@ -19,6 +19,11 @@ struct crm_background {
     long ldq = 0;                        // common leading dimension (multiple of 128)
     crm::DevBuf Q0[crm::CRM_MAX_RHO];    // [n_pad x ldq], zero padded
     crm::DevBuf S0[crm::CRM_MAX_RHO];    // [ldq]
+    // thin branch with a well-conditioned kept spectrum: Q0(rho) = H Mix(rho), H = [E1, B]
+    bool fast_T = false;
+    long ldh = 0, cols = 0;
+    crm::DevBuf H;                        // [n_pad x ldh]
+    crm::DevBuf Mix[crm::CRM_MAX_RHO];   // [ldh x ldq]
 };
 
 // One phenotype: y, W, E0 and what only depends on them.

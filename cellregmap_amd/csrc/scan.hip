@@ -68,7 +68,9 @@ void crm_background_destroy(crm_background* bg) {
     for (int i = 0; i < CRM_MAX_RHO; i++) {
         bg->Q0[i].release();
         bg->S0[i].release();
+        bg->Mix[i].release();
     }
+    bg->H.release();
     delete bg;
 }
 
@@ -517,6 +519,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* dZ1 = ctx->ws_Z.as<double>();
     double* dZ2 = dZ1 + z1_sz * ks1;
     double* dZ3 = dZ2 + z2_sz * ks2;
+    if (bg->fast_T) {
+        CRM_TRY(ctx->ws_TH.ensure(sizeof(double) * (size_t)bg->ldh * ldb));
+        CRM_HIP(hipMemsetAsync(ctx->ws_TH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ldb, st));
+    }
     CRM_TRY(ctx->ws_F.ensure(sizeof(double) * (size_t)BLK * k0 * k0));
     CRM_TRY(ctx->ws_Gext.ensure(sizeof(double) * (size_t)BLK * KT * KT));
     const size_t stats_ws = variant_stats_workspace(BLK, c);
@@ -615,17 +621,32 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             else
                 CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, CRM_MAX_COV));
         }
-        // 3. T(rho) = G' Q0(rho) for all grid points in one launch
+        // 3. T(rho) = G' Q0(rho) for all grid points.  With Q0(rho) = H Mix(rho) the n-length work is
+        //    done once, (H'G), followed by eleven small products Mix(rho)'(H'G): 2 n cols + 2 cols sum r
+        //    flops per variant instead of 2 n sum r.
+        const bool fastT = !collapsed && bg->fast_T && ctx->fast_T;
+        if (fastT) {
+            GemmProblem p{};
+            p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
+            p.C = ctx->ws_TH.as<double>(); p.ldc = ldb; p.M = (int)bg->cols; p.N = nb;
+            CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)bg->cols, nb, np, false, 0, 1, 0));
+        }
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
-            p.X = Gb; p.ldx = ldb;
-            p.Y = collapsed ? g0->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
+            if (fastT) {
+                p.X = ctx->ws_TH.as<double>(); p.ldx = ldb;
+                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+            } else {
+                p.X = Gb; p.ldx = ldb;
+                p.Y = collapsed ? g0->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
+            }
             p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
             p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
-        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, nb, (int)ldq, xrows, false, 0, 1, 0));
+        CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(st, d_probs + 1, nrho, nb, (int)ldq, fastT ? bg->ldh : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];

@@ -116,6 +116,11 @@ int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long coun
 
 /* Block size (variants per internal batch); 0 restores the default. */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
+/* on = 1 (default): for backgrounds built on the device with a well-conditioned kept spectrum
+ * (S_max <= 1e6 S_min), the rotations G'Q0(rho) of the dense scan are taken as Mix(rho)'(H'G) with
+ * Q0(rho) = H Mix(rho) -- one n-length product instead of one per grid point.  on = 0: always the
+ * direct products. */
+int crm_set_fast_rotation(crm_ctx* ctx, int on);
 /* Null-fit convergence.  on = 0 (default): the reference's procedure verbatim (Brent on
  * logit(delta), rtol = atol = 1e-6, glimix-core LMM.fit as called at _cellregmap.py:352).
  * on = 1: followed by secant steps on the analytic derivative, which pins the optimum to ~1e-12

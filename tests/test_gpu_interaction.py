@@ -217,3 +217,27 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
                 assert np.array_equal(info[k][i], sinfo[k])
     pv2, _ = run_interaction_many(Y, c.E, c.G, W=c.W, hK=c.hK)
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
+
+
+def test_rotation_through_the_mixing_matrices_equals_direct_rotation():
+    """T(rho) = Mix(rho)'(H'G) (default for device-built, well-conditioned backgrounds) against the
+    direct G'Q0(rho): same results to ~1e-9 with the null-fit polish on."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
+
+    c = _cohort(8, 40, 5, 48, seed=51)
+    crm = CellRegMap(c.y, c.E, W=c.W, Ls=get_L_values(c.hK, c.E))   # thin branch: 5 + 5*8 = 45 < 320
+    panel = GenotypePanel(c.G, groups=None)
+    lib = _lib.load()
+    ctxh = _engine._context(0)
+    _lib.check(lib.crm_set_null_fit_polish(ctxh, 1))
+    try:
+        fast = crm.scan_interaction(panel, return_stats=True)
+        _lib.check(lib.crm_set_fast_rotation(ctxh, 0))
+        direct = crm.scan_interaction(panel, return_stats=True)
+    finally:
+        _lib.check(lib.crm_set_fast_rotation(ctxh, 1))
+        _lib.check(lib.crm_set_null_fit_polish(ctxh, 0))
+    assert np.array_equal(fast[1]["rho1"], direct[1]["rho1"])
+    assert_allclose(fast[2]["lml"], direct[2]["lml"], rtol=1e-12)
+    assert_allclose(fast[2]["Q"], direct[2]["Q"], rtol=1e-8)
+    assert np.all(np.abs(fast[0] - direct[0]) <= 1e-7 * direct[0] + P_ATOL)
