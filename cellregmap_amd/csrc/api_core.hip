@@ -156,7 +156,7 @@ int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, con
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK * (long)ksplit);
     const long ldx = round_up(M, 128), ldy = round_up(N, 128);
-    DevBuf bx, by, bc, bp;
+    ScopedBuf bx, by, bc, bp;
     CRM_TRY(bx.ensure(sizeof(double) * cp * ldx));
     CRM_TRY(by.ensure(sizeof(double) * cp * ldy));
     const long cstride = (long)M * ldy;
@@ -173,7 +173,6 @@ int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, con
     CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
                              M, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
-    bx.release(); by.release(); bc.release(); bp.release();
     return CRM_OK;
 }
 
@@ -184,7 +183,7 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
     const long cp = round_up(cells, GEMM_BK);
     const long ldg = round_up(B, 128) + 128, lde = round_up(k0, 32), ldy = round_up(N, 128);
     const int M = B * k0;
-    DevBuf bg, be, by, bc, bp;
+    ScopedBuf bg, be, by, bc, bp;
     CRM_TRY(bg.ensure(sizeof(double) * cp * ldg));
     CRM_TRY(be.ensure(sizeof(double) * cp * lde));
     CRM_TRY(by.ensure(sizeof(double) * cp * ldy));
@@ -201,7 +200,6 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
     CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
                              M, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
-    bg.release(); be.release(); by.release(); bc.release(); bp.release();
     return CRM_OK;
 }
 
@@ -215,7 +213,7 @@ extern "C" {
 int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lambda) {
     if (!c || count <= 0 || k <= 0 || !F || !lambda) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
-    DevBuf bF, bQ, bL, bP;
+    ScopedBuf bF, bQ, bL, bP;
     CRM_TRY(bF.ensure(sizeof(double) * (size_t)count * k * k));
     CRM_TRY(bQ.ensure(sizeof(double) * count));
     CRM_TRY(bL.ensure(sizeof(double) * (size_t)count * k));
@@ -226,7 +224,6 @@ int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lam
                               bP.as<double>(), nullptr, nullptr, true));
     CRM_HIP(hipMemcpyAsync(lambda, bL.ptr, sizeof(double) * (size_t)count * k, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
-    bF.release(); bQ.release(); bL.release(); bP.release();
     return CRM_OK;
 }
 
@@ -234,7 +231,7 @@ int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double*
                     int* ifault, double* liu) {
     if (!c || count <= 0 || k <= 0 || !Q || !lambda || !pvalue) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
-    DevBuf bQ, bL, bP, bI, bU;
+    ScopedBuf bQ, bL, bP, bI, bU;
     CRM_TRY(bQ.ensure(sizeof(double) * count));
     CRM_TRY(bL.ensure(sizeof(double) * (size_t)count * k));
     CRM_TRY(bP.ensure(sizeof(double) * count));
@@ -248,7 +245,6 @@ int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double*
     if (ifault) CRM_HIP(hipMemcpyAsync(ifault, bI.ptr, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
     if (liu) CRM_HIP(hipMemcpyAsync(liu, bU.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
-    bQ.release(); bL.release(); bP.release(); bI.release(); bU.release();
     return CRM_OK;
 }
 

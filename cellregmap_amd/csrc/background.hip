@@ -195,7 +195,7 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         CRM_HIP(hipMemcpy2DAsync(dH.as<double>() + k1, cp * sizeof(double), B, kb * sizeof(double),
                                  kb * sizeof(double), n, hipMemcpyHostToDevice, st));
     } else if (kb > 0) {
-        DevBuf dU, dK;
+        ScopedBuf dU, dK;
         CRM_TRY(dU.ensure(sizeof(double) * n * k2));
         CRM_TRY(dK.ensure(sizeof(double) * n * m));
         CRM_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
@@ -204,8 +204,6 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
                            dK.as<double>(), m, n, dH.as<double>(), cp, k1);
         CRM_HIP(hipGetLastError());
         CRM_HIP(hipStreamSynchronize(st));
-        dU.release();
-        dK.release();
     }
     CRM_TRY(dHt.ensure(sizeof(double) * cp * np));
     CRM_HIP(hipMemsetAsync(dHt.ptr, 0, sizeof(double) * cp * np, st));

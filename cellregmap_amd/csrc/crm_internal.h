@@ -22,6 +22,14 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(ptr); }
 };
 
+// temporary device buffer released on scope exit (error paths included)
+struct ScopedBuf : DevBuf {
+    ScopedBuf() = default;
+    ScopedBuf(const ScopedBuf&) = delete;
+    ScopedBuf& operator=(const ScopedBuf&) = delete;
+    ~ScopedBuf() { release(); }
+};
+
 int upload_padded(hipStream_t st, double* dst, long ld_dst, long rows_pad, const double* src,
                   long ld_src, long rows, long cols);
 
