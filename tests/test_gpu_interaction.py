@@ -146,7 +146,8 @@ def test_collapsed_path_equals_dense_path():
                 for panel in (auto, donors):
                     got = crm.scan_interaction(panel, return_stats=True, **kw)
                     assert np.array_equal(got[1]["rho1"], ref[1]["rho1"])
-                    assert_allclose(got[2]["Q"], ref[2]["Q"], rtol=1e-8 if polish else Q_RTOL)
+                    # (no polish: two summation orders under Brent(1e-6) may part by its tolerance)
+                    assert_allclose(got[2]["Q"], ref[2]["Q"], rtol=1e-8 if polish else 5e-6)
                     assert_allclose(got[2]["delta"], ref[2]["delta"], rtol=1e-8 if polish else 5e-6)
                     rt = 1e-7 if polish else P_RTOL
                     assert np.all(np.abs(got[0] - ref[0]) <= rt * ref[0] + P_ATOL)
