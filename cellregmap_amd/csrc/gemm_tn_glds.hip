@@ -24,7 +24,8 @@ __host__ __device__ inline int glds_kr_variants(int k0) {
     return nb > GEMM_BM ? GEMM_BM : nb;
 }
 
-template <bool KR, int KRQ>
+// ECQ: context columns staged per row in units of 32 (round_up(k0, 32) / 32); 0 for the plain kernel
+template <bool KR, int KRQ, int ECQ>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
                                                                int mtiles_max, long cells_per_split,
                                                                long split_stride, int k0) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
 
     // ---- LDS carve-up ------------------------------------------------------------------------
     const int nb = KR ? glds_kr_variants(k0) : 0;
-    const int EC = KR ? (k0 + 31) / 32 * 32 : 0;       // context columns staged per row
+    constexpr int EC = 32 * ECQ;                        // context columns staged per row
     double* Ys = smem;                                  // [2][BK][128]
     double* Xs = Ys + 2 * GEMM_BK * LD;                 // plain: [2][BK][128]
     double* Es = Xs;                                    // KR: [2][BK][EC]
@@ -73,16 +74,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
                                                  (lptr_t)(Xs + (buf * GEMM_BK + r) * LD), 16, 0, 0);
         }
         if (KR) {
-            const int ppr = EC >> 1;  // 16-byte pieces per row
+            constexpr int ppr = EC / 2;  // 16-byte pieces per row
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int ii = wave + 4 * q;       // wave-instruction index, EC/8 of them
-                if (ii < (EC >> 3)) {
-                    const int p = ii * 64 + lane;
-                    const int r = p / ppr, g = p - r * ppr;
-                    __builtin_amdgcn_global_load_lds(Eg + (roff + r) * P.lde + ((g ^ ((r & 1) << 3)) << 1),
-                                                     (lptr_t)(Es + buf * GEMM_BK * EC + ii * 128), 16, 0, 0);
-                }
+            for (int q = 0; q < ECQ; q++) {       // EC/8 wave-instructions, ECQ per wavefront
+                const int ii = wave + 4 * q;
+                const int p = ii * 64 + lane;
+                const int r = p / ppr, g = p - r * ppr;
+                __builtin_amdgcn_global_load_lds(Eg + (roff + r) * P.lde + ((g ^ ((r & 1) << 3)) << 1),
+                                                 (lptr_t)(Es + buf * GEMM_BK * EC + ii * 128), 16, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < KRQ; q++) {
@@ -208,15 +207,26 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         const int nb = glds_kr_variants(k0);
         lds += (size_t)2 * GEMM_BK * (EC + nb) * sizeof(double);
         constexpr int KRQ_BIG = (GEMM_BK * GEMM_BM + 255) / 256;
-        if (GEMM_BK * nb <= 256)
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cells / ksplit, split_stride, k0);
-        else
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cells / ksplit, split_stride, k0);
+        const bool small = GEMM_BK * nb <= 256;
+#define CRM_GLDS(Q)                                                                                          \
+    do {                                                                                                     \
+        if (small)                                                                                           \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q>), grid, dim3(256), lds, st, probs_dev, mt,   \
+                               cells / ksplit, split_stride, k0);                                            \
+        else                                                                                                 \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q>), grid, dim3(256), lds, st, probs_dev, \
+                               mt, cells / ksplit, split_stride, k0);                                        \
+    } while (0)
+        switch (EC / 32) {
+            case 1: CRM_GLDS(1); break;
+            case 2: CRM_GLDS(2); break;
+            case 3: CRM_GLDS(3); break;
+            default: CRM_GLDS(4); break;
+        }
+#undef CRM_GLDS
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);
-        hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1>), grid, dim3(256), lds, st, probs_dev, mt,
+        hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,
                            cells / ksplit, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());

@@ -37,6 +37,8 @@ def _random_problem(n, k0, c, p, donors, seed, mode):
     (300, 33, 2, 6, 5, "A"),
     (199, 3, 1, 130, 9, "C"),
     (150, 70, 1, 3, 4, "A"),
+    (260, 120, 2, 4, 5, "A"),
+    (300, 128, 1, 3, 6, "B"),
 ])
 def test_odd_shapes_match_oracle(n, k0, c, p, donors, mode):
     from cellregmap_amd import CellRegMap, GenotypePanel
