@@ -7,6 +7,7 @@ from enum import Enum
 from ._engine import (
     CellRegMap,
     GenotypePanel,
+    candidate_groups,
     detect_groups,
     estimate_betas,
     get_L_values,
@@ -32,6 +33,7 @@ __all__ = [
     "__version__",
     "CellRegMap",
     "GenotypePanel",
+    "candidate_groups",
     "detect_groups",
     "run_association",
     "run_association_fast",

@@ -169,13 +169,17 @@ def background_from_qs(qs_list, rho, device=0):
     return _Background(h, rho, device)
 
 
-def detect_groups(G, max_groups=2048, sample_columns=64, chunk=2048):
-    """Find the donor structure of an expanded genotype matrix: groups of cells whose rows are
-    identical in every variant.  Returns ``(group_of_cell int32 (n,), rows_of_representatives)``
-    or ``None`` when the rows do not collapse (more than ``max_groups`` or n/2 distinct rows).
-    Candidates come from a column sample; every column is then verified exactly."""
+def candidate_groups(G, max_groups=2048, sample_columns=64):
+    """Candidate donor structure of an expanded genotype matrix from a column sample: cells with
+    identical sampled entries share a group.  Returns ``(group_of_cell int32 (n,), representative
+    row per group int64 (m,))`` -- groups labelled in order of first appearance -- or ``None`` when the
+    sample already shows more than ``max_groups`` (or n/2) distinct rows.  The candidates still have
+    to be verified on every column (``detect_groups`` on the host, ``crm_panel_create_auto`` on the
+    device)."""
     G = np.asarray(G)
     n, p = G.shape
+    if n < 2 or p < 1:
+        return None
     cols = np.unique(np.linspace(0, p - 1, min(p, sample_columns)).astype(int))
     key = np.ascontiguousarray(G[:, cols])
     _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
@@ -183,16 +187,26 @@ def detect_groups(G, max_groups=2048, sample_columns=64, chunk=2048):
     m = first.size
     if m > max_groups or m > n // 2:
         return None
-    rep = first[inv]
-    for c0 in range(0, p, chunk):
-        blk = G[:, c0:c0 + chunk]
-        if not np.array_equal(blk, blk[rep]):
-            return None
-    # label groups in order of first appearance
     order = np.argsort(first, kind="stable")
     relabel = np.empty(m, np.int32)
     relabel[order] = np.arange(m, dtype=np.int32)
-    return relabel[inv].astype(np.int32), first[order]
+    return relabel[inv].astype(np.int32), first[order].astype(np.int64)
+
+
+def detect_groups(G, max_groups=2048, sample_columns=64, chunk=2048):
+    """``candidate_groups`` followed by an exact host-side check of every column.  Returns
+    ``(group_of_cell, representative rows)`` or ``None`` when the rows do not collapse."""
+    G = np.asarray(G)
+    found = candidate_groups(G, max_groups, sample_columns)
+    if found is None:
+        return None
+    group, reps = found
+    rep = reps[group]
+    for c0 in range(0, G.shape[1], chunk):
+        blk = G[:, c0:c0 + chunk]
+        if not np.array_equal(blk, blk[rep]):
+            return None
+    return group, reps
 
 
 class GenotypePanel:
@@ -206,20 +220,29 @@ class GenotypePanel:
         lib = _lib.load()
         G = np.asarray(G, float)
         assert G.ndim == 2
+        if not G.flags.c_contiguous:
+            G = np.ascontiguousarray(G)
         self.shape = G.shape
         self.device = device
         self.n_groups = None
         h = ctypes.c_void_p()
-        found = detect_groups(G) if isinstance(groups, str) and groups == "auto" else None
-        if found is not None:
-            group, reps = found
-            Gd = np.ascontiguousarray(G[reps, :])
-            self._create_grouped(lib, group, Gd, device, h)
+        hint = candidate_groups(G) if isinstance(groups, str) and groups == "auto" else None
+        grouped = ctypes.c_int(0)
+        if hint is None:
+            rc = lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1], None, 0,
+                                           None, ctypes.byref(h), ctypes.byref(grouped))
         else:
-            if not G.flags.c_contiguous:
-                G = np.ascontiguousarray(G)
-            _lib.check(lib.crm_panel_create(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
-                                            ctypes.byref(h)))
+            group, reps = hint
+            group = np.ascontiguousarray(group, dtype=np.int32)
+            reps = np.ascontiguousarray(reps, dtype=np.int64)
+            rc = lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
+                                           _lib.ptr(group), reps.shape[0], _lib.ptr(reps), ctypes.byref(h),
+                                           ctypes.byref(grouped))
+        if rc == -4:  # CRM_ERR_NUMERIC: the reference's LMM raises ValueError on non-finite covariates
+            raise ValueError("There are non-finite values in the covariates matrix.")
+        _lib.check(rc)
+        if grouped.value:
+            self.n_groups = int(hint[1].shape[0])
         self.handle = h
         self._fin = weakref.finalize(self, lib.crm_panel_destroy, h)
 
@@ -351,9 +374,7 @@ class CellRegMap:
             G = np.asarray(G, float)
             if G.ndim != 2 or G.shape[0] != self.n_samples:
                 raise ValueError(f"G must be {self.n_samples} x p, got {G.shape}")
-            if not np.all(np.isfinite(G)):
-                raise ValueError("There are non-finite values in the covariates matrix.")
-            panel = GenotypePanel(G, self._device)
+            panel = GenotypePanel(G, self._device)  # raises ValueError on non-finite entries
         if panel.shape[0] != self.n_samples:
             raise ValueError(f"G has {panel.shape[0]} rows, expected {self.n_samples}")
         return panel

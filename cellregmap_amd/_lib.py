@@ -39,6 +39,8 @@ SIGNATURES = {
                                         ctypes.POINTER(vp)]),
     "crm_panel_create_grouped": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_long,
                                                 ctypes.c_long, ctypes.POINTER(vp)]),
+    "crm_panel_create_auto": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long, vp, ctypes.c_long,
+                                             vp, ctypes.POINTER(vp), c_int_p]),
     "crm_set_donor_collapse": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),

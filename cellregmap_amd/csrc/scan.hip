@@ -19,6 +19,27 @@ static int pick_split(long cells_pad, long blocks_without_split) {
     return s;
 }
 
+// flags[0] |= any non-finite entry; flags[1] |= any cell differing from its group's representative
+__global__ void verify_panel_kernel(const double* __restrict__ G, long ld, long p, const int* __restrict__ group,
+                                    const long* __restrict__ rep, int* __restrict__ flags) {
+    const long i = blockIdx.x;
+    const long j = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= p) return;
+    const double v = G[i * ld + j];
+    if (!(fabs(v) < INFINITY)) atomicOr(&flags[0], 1);
+    if (group) {
+        const double r = G[rep[group[i]] * ld + j];
+        if (__double_as_longlong(v) != __double_as_longlong(r)) atomicOr(&flags[1], 1);
+    }
+}
+
+__global__ void gather_rows_kernel(const double* __restrict__ G, long ld, const long* __restrict__ rep,
+                                   double* __restrict__ Gd) {
+    const long d = blockIdx.x;
+    const long j = (long)blockIdx.y * blockDim.x + threadIdx.x;
+    if (j < ld) Gd[d * ld + j] = G[rep[d] * ld + j];
+}
+
 }  // namespace crm
 
 extern "C" {
@@ -252,6 +273,71 @@ int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, con
     rc = launch_indicator(ctx->stream, P->group.as<int>(), n, P->n_pad, (int)m, P->Z.as<double>(), P->ldz);
     if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
     CRM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = P;
+    return CRM_OK;
+}
+
+// Upload an expanded genotype matrix, check it for non-finite entries and -- when a candidate
+// grouping is given (group_hint[i] in [0, m_hint), rep_rows[d] = a row carrying group d) -- verify ON THE
+// DEVICE that every cell equals its group's representative in every variant; if so the panel is stored
+// donor-level (grouped), otherwise dense.  Replaces the host-side isfinite pass and the host-side
+// verification of detect_groups (both O(n p) memory passes that dominated short scans).
+int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long p, const int* group_hint,
+                          long m_hint, const long* rep_rows, crm_panel** out, int* out_grouped) {
+    if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
+    if (out_grouped) *out_grouped = 0;
+    crm_panel* P = nullptr;
+    CRM_TRY(crm_panel_create(ctx, n, G, ldg, p, &P));
+    hipStream_t st = ctx->stream;
+    auto fail = [&](int code) { crm_panel_destroy(P); return code; };
+    ScopedBuf flags, dgroup, drep;
+    int rc;
+    if ((rc = flags.ensure(sizeof(int) * 2)) != CRM_OK) return fail(rc);
+    const bool hinted = group_hint && rep_rows && m_hint > 0 && m_hint < BLOCK_SLACK_MAX - 1;
+    if (hinted) {
+        for (long i = 0; i < n; i++)
+            if (group_hint[i] < 0 || group_hint[i] >= m_hint) return fail(CRM_ERR_ARG);
+        for (long d = 0; d < m_hint; d++)
+            if (rep_rows[d] < 0 || rep_rows[d] >= n) return fail(CRM_ERR_ARG);
+        if ((rc = dgroup.ensure(sizeof(int) * n)) != CRM_OK) return fail(rc);
+        if ((rc = drep.ensure(sizeof(long) * m_hint)) != CRM_OK) return fail(rc);
+        if (hipMemcpyAsync(dgroup.ptr, group_hint, sizeof(int) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(drep.ptr, rep_rows, sizeof(long) * m_hint, hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(CRM_ERR_HIP);
+    }
+    if (hipMemsetAsync(flags.ptr, 0, sizeof(int) * 2, st) != hipSuccess) return fail(CRM_ERR_HIP);
+    hipLaunchKernelGGL(verify_panel_kernel, dim3((unsigned)n, (unsigned)((p + 255) / 256)), dim3(256), 0, st,
+                       P->G.as<double>(), P->ld, p, hinted ? dgroup.as<int>() : nullptr,
+                       hinted ? drep.as<long>() : nullptr, flags.as<int>());
+    int h_flags[2] = {0, 0};
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h_flags, flags.ptr, sizeof h_flags, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(CRM_ERR_HIP);
+    if (h_flags[0]) {
+        set_error("panel: non-finite values in the genotype matrix");
+        return fail(CRM_ERR_NUMERIC);
+    }
+    if (hinted && !h_flags[1]) {
+        // collapse: gather the representative rows, drop the dense copy
+        P->grouped = true;
+        P->m = m_hint;
+        P->m_pad = round_up(m_hint, GEMM_BK);
+        P->ldz = round_up(m_hint, 128) + 128;
+        if ((rc = P->Gd.ensure(sizeof(double) * P->m_pad * P->ld)) != CRM_OK) return fail(rc);
+        if (hipMemsetAsync(P->Gd.ptr, 0, sizeof(double) * P->m_pad * P->ld, st) != hipSuccess) return fail(CRM_ERR_HIP);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m_hint, (unsigned)((P->ld + 255) / 256)), dim3(256), 0,
+                           st, P->G.as<double>(), P->ld, drep.as<long>(), P->Gd.as<double>());
+        if ((rc = P->group.ensure(sizeof(int) * n)) != CRM_OK) return fail(rc);
+        if ((rc = P->Z.ensure(sizeof(double) * P->n_pad * P->ldz)) != CRM_OK) return fail(rc);
+        if (hipMemcpyAsync(P->group.ptr, dgroup.ptr, sizeof(int) * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(CRM_ERR_HIP);
+        if ((rc = launch_indicator(st, P->group.as<int>(), n, P->n_pad, (int)m_hint, P->Z.as<double>(), P->ldz)) != CRM_OK)
+            return fail(rc);
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(CRM_ERR_HIP);
+        P->G.release();
+        if (out_grouped) *out_grouped = 1;
+    }
     *out = P;
     return CRM_OK;
 }

@@ -82,6 +82,12 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
  * genotype permutation hook (idx_G) falls back to the dense path by expanding blocks on the fly. */
 int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
                              long p, crm_panel** out);
+/* Upload an expanded n x p matrix; reject non-finite entries (CRM_ERR_NUMERIC: the reference's LMM
+ * raises ValueError on them) and, given a candidate grouping (group_hint[i] in [0, m_hint),
+ * rep_rows[d] = index of a cell of group d), verify on the device that every cell equals its group's
+ * representative in every variant.  *out_grouped = 1 when the panel was stored donor-level. */
+int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long p, const int* group_hint,
+                          long m_hint, const long* rep_rows, crm_panel** out, int* out_grouped);
 /* on = 0 forces the dense path for grouped panels (default 1). */
 int crm_set_donor_collapse(crm_ctx* ctx, int on);
 void crm_panel_destroy(crm_panel* panel);

@@ -92,3 +92,20 @@ def test_unsupported_sizes_fail_loudly():
     W = np.concatenate([c.W, rng.normal(size=(c.y.size, 9))], axis=1)  # 10 covariates > 8
     with pytest.raises(_lib.CrmError):
         CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
+
+
+def test_device_side_group_verification():
+    """A cell that deviates from its candidate group in a column the host sample did not look at must
+    keep the panel dense (the verification runs on the device over every column)."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+
+    c = _cohort(7, 20, 3, 400, seed=37)
+    assert GenotypePanel(c.G).n_groups == 7
+    G2 = c.G.copy()
+    G2[33, 123] += 0.5                      # not among the 64 sampled columns
+    panel = GenotypePanel(G2)
+    assert panel.n_groups is None
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    pv_auto, _ = crm.scan_interaction(panel)
+    pv_dense, _ = crm.scan_interaction(GenotypePanel(G2, groups=None))
+    assert np.array_equal(pv_auto, pv_dense)
