@@ -242,3 +242,26 @@ def test_rotation_through_the_mixing_matrices_equals_direct_rotation():
     assert_allclose(fast[2]["lml"], direct[2]["lml"], rtol=1e-12)
     assert_allclose(fast[2]["Q"], direct[2]["Q"], rtol=1e-8)
     assert np.all(np.abs(fast[0] - direct[0]) <= 1e-7 * direct[0] + P_ATOL)
+
+
+def test_scan_on_lapack_decompositions_including_null_columns():
+    """Background handed over as LAPACK's own economic decompositions (crm_background_create_qs): the
+    reference's thin SVD keeps the null-space columns of the rank-deficient mode C half matrix
+    (S0 ~ 1e-30) and arbitrary orthonormal vectors for them; they must be inert in the device path."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
+    from cellregmap_amd._engine import background_from_qs
+    from oracle.crm import OracleCellRegMap, khatri_rao_halves
+
+    c = _cohort(6, 40, 4, 24, seed=4)
+    ocrm = OracleCellRegMap(c.y, c.E, W=c.W, Ls=khatri_rao_halves(c.hK, c.E))
+    S0 = ocrm._qs[0.5][1]
+    assert S0.min() < 1e-20 * S0.max()          # rank deficient by construction (SURVEY 7, hard parts)
+    bg = background_from_qs([ocrm._qs[r] for r in ocrm._rho], ocrm._rho)
+    crm = CellRegMap(c.y, c.E, W=c.W, Ls=get_L_values(c.hK, c.E), background=bg)
+    pv, info, st = crm.scan_interaction(GenotypePanel(c.G, groups=None), return_stats=True)
+    opv, oinfo, ost = ocrm.scan_interaction(c.G, return_stats=True)
+    _compare(pv, info, st, opv, oinfo, ost)
+    # and the device's own decomposition (null columns dropped) gives the same answers
+    pv2, info2 = CellRegMap(c.y, c.E, W=c.W, Ls=get_L_values(c.hK, c.E)).scan_interaction(GenotypePanel(c.G, groups=None))
+    assert np.array_equal(info2["rho1"], info["rho1"])
+    assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
