@@ -40,7 +40,7 @@ struct crm_gene {
     crm::DevBuf Ep, YE, EE, idx;
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
-    const crm_panel* dt_panel = nullptr;
+    unsigned long dt_panel = 0;  // uid of the panel the tables were built for (0 = none)
     bool dt_full = false;  // also holds the phenotype-free tables (TZ, Bd, Z2, Z3)
     crm::DevBuf dt_TZ;    // [nrho][m_pad x ldq]          Z' Q0(rho)
     crm::DevBuf dt_Bd;    // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
@@ -51,6 +51,7 @@ struct crm_gene {
 
 struct crm_panel {
     crm_ctx* ctx = nullptr;
+    unsigned long uid = 0;  // process-unique (addresses get recycled)
     long n = 0, n_pad = 0, p = 0, ld = 0;
     crm::DevBuf G;  // dense: [n_pad x ld]
     // grouped (donor-constant) panel: cell i carries the genotypes of group[i]

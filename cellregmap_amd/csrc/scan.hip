@@ -4,6 +4,7 @@
 //   -> side contractions -> assemble (Q, F) -> eigenvalues + Davies.
 // Reference loop being replaced: cellregmap/_cellregmap.py:340-436.
 #include <algorithm>
+#include <atomic>
 
 #include "nullfit.h"
 #include "objects.h"
@@ -11,6 +12,11 @@
 using namespace crm;
 
 namespace crm {
+
+static unsigned long next_panel_uid() {
+    static std::atomic<unsigned long> counter{0};
+    return ++counter;
+}
 
 static int pick_split(long cells_pad, long blocks_without_split) {
     // enough workgroups to cover the 256 CUs twice, within what the padded cell count allows
@@ -219,6 +225,7 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
     CRM_HIP(hipSetDevice(ctx->device));
     crm_panel* P = new crm_panel();
     P->ctx = ctx;
+    P->uid = next_panel_uid();
     P->n = n;
     P->n_pad = round_up(n, CELL_PAD);
     P->p = p;
@@ -256,6 +263,7 @@ int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, con
     CRM_HIP(hipSetDevice(ctx->device));
     crm_panel* P = new crm_panel();
     P->ctx = ctx;
+    P->uid = next_panel_uid();
     P->n = n;
     P->n_pad = round_up(n, CELL_PAD);
     P->p = p;
@@ -663,11 +671,11 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             const bool reusable = !idx_E && !idx_G;
-            const bool have = g->dt_panel == panel && reusable && (gi > 0 || g->dt_full);
+            const bool have = g->dt_panel == panel->uid && reusable && (gi > 0 || g->dt_full);
             if (!have) {
-                g->dt_panel = nullptr;
+                g->dt_panel = 0;
                 CRM_TRY(build_donor_tables(g, panel, gi == 0, d_Ep, d_EE, Zt, cross));
-                if (reusable) g->dt_panel = panel;
+                if (reusable) g->dt_panel = panel->uid;
             }
         }
     }

@@ -265,3 +265,26 @@ def test_scan_on_lapack_decompositions_including_null_columns():
     pv2, info2 = CellRegMap(c.y, c.E, W=c.W, Ls=get_L_values(c.hK, c.E)).scan_interaction(GenotypePanel(c.G, groups=None))
     assert np.array_equal(info2["rho1"], info["rho1"])
     assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
+
+
+def test_donor_tables_are_not_reused_across_panels():
+    """One long-lived CellRegMap against a sequence of short-lived panels with different donor
+    groupings (allocator addresses get recycled; the per-donor tables must follow the panel)."""
+    import gc
+
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 20, 3, 32, seed=61)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        perm = rng.permutation(c.y.size)          # same genotypes, cells shuffled -> other grouping
+        G = c.G[perm] if trial % 2 else c.G
+        panel = GenotypePanel(G)
+        assert panel.n_groups == 8
+        pv, _ = crm.scan_interaction(panel)
+        del panel
+        gc.collect()
+        ref, _ = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(GenotypePanel(G, groups=None))
+        assert np.all(np.abs(pv - ref) <= P_RTOL * ref + P_ATOL)
