@@ -96,17 +96,23 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     }
 }
 
-constexpr int PMAX = CRM_MAX_COV + 1;
+constexpr int PMAX = CRM_MAX_COV_WIDE + 1;
 
 __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const double* __restrict__ Gext,
                                                         int KT) {
-    // per variant: everything below is k0- or (c+1)-sized
-    __shared__ double L[PMAX][PMAX];      // Cholesky factor of X'K^-1 X
-    __shared__ double xky[PMAX];          // X'K^-1 y, then (X'K^-1X)^-1 X'K^-1 y
-    __shared__ double dkx[CRM_MAX_K0][PMAX];   // D'K^-1 X
-    __shared__ double sol[CRM_MAX_K0][PMAX];   // rows: (X'K^-1X)^-1 X'K^-1 D_j
-    __shared__ double uvec[CRM_MAX_K0];
+    // per variant: everything below is k0- or (c+1)-sized; LDS carved from the dynamic segment:
+    // L [P][P] (Cholesky factor of X'K^-1X), xky [P], dkx [k0][P] (D'K^-1X), sol [k0][P], uvec [k0]
+    extern __shared__ double fsm[];
     __shared__ int ok_flag;
+    const int Pd = a.c + 1;
+    double* Lm = fsm;
+    double* xky = Lm + Pd * Pd;
+    double* dkxm = xky + Pd;
+    double* solm = dkxm + a.k0 * Pd;
+    double* uvec = solm + a.k0 * Pd;
+#define L(i, j) Lm[(i) * Pd + (j)]
+#define dkx(j, i) dkxm[(j) * Pd + (i)]
+#define sol(j, i) solm[(j) * Pd + (i)]
     const int b = blockIdx.x;
     const NullFitOut fit = a.fit[b];
     const int k0 = a.k0, c = a.c;
@@ -127,36 +133,36 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
         bool ok = true;
         for (int i = 0; i < P; i++) {
             for (int j = 0; j <= i; j++)
-                L[i][j] = (plain_xx(i, j) - Ge[(long)(k0 + i) * KT + (k0 + j)]) * inv;
+                L(i, j) = (plain_xx(i, j) - Ge[(long)(k0 + i) * KT + (k0 + j)]) * inv;
             xky[i] = (plain_xy(i) - Ge[(long)(k0 + i) * KT + (k0 + c + 1)]) * inv;
         }
         if (!fit.use_g) {  // g in span(W): the projection is the one of W alone
-            for (int j = 0; j < c; j++) L[c][j] = 0.0;
-            L[c][c] = 1.0;
+            for (int j = 0; j < c; j++) L(c, j) = 0.0;
+            L(c, c) = 1.0;
             xky[c] = 0.0;
         }
         for (int j = 0; j < P && ok; j++) {
-            double d = L[j][j];
-            for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+            double d = L(j, j);
+            for (int k = 0; k < j; k++) d -= L(j, k) * L(j, k);
             if (!(d > 0.0)) { ok = false; break; }
             const double l = sqrt(d);
-            L[j][j] = l;
+            L(j, j) = l;
             for (int i = j + 1; i < P; i++) {
-                double s = L[i][j];
-                for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-                L[i][j] = s / l;
+                double s = L(i, j);
+                for (int k = 0; k < j; k++) s -= L(i, k) * L(j, k);
+                L(i, j) = s / l;
             }
         }
         if (ok) {
             for (int i = 0; i < P; i++) {
                 double s = xky[i];
-                for (int k = 0; k < i; k++) s -= L[i][k] * xky[k];
-                xky[i] = s / L[i][i];
+                for (int k = 0; k < i; k++) s -= L(i, k) * xky[k];
+                xky[i] = s / L(i, i);
             }
             for (int i = P - 1; i >= 0; i--) {
                 double s = xky[i];
-                for (int k = i + 1; k < P; k++) s -= L[k][i] * xky[k];
-                xky[i] = s / L[i][i];
+                for (int k = i + 1; k < P; k++) s -= L(k, i) * xky[k];
+                xky[i] = s / L(i, i);
             }
         }
         ok_flag = ok ? 1 : 0;
@@ -173,22 +179,22 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
             double v = (plain - Ge[(long)j * KT + (k0 + i)]) * inv;
             if (i == c && !fit.use_g) v = 0.0;
             row[i] = v;
-            dkx[j][i] = v;
+            dkx(j, i) = v;
         }
         for (int i = 0; i < P; i++) {
             double s = row[i];
-            for (int k = 0; k < i; k++) s -= L[i][k] * row[k];
-            row[i] = s / L[i][i];
+            for (int k = 0; k < i; k++) s -= L(i, k) * row[k];
+            row[i] = s / L(i, i);
         }
         for (int i = P - 1; i >= 0; i--) {
             double s = row[i];
-            for (int k = i + 1; k < P; k++) s -= L[k][i] * row[k];
-            row[i] = s / L[i][i];
+            for (int k = i + 1; k < P; k++) s -= L(k, i) * row[k];
+            row[i] = s / L(i, i);
         }
-        for (int i = 0; i < P; i++) sol[j][i] = row[i];
+        for (int i = 0; i < P; i++) sol(j, i) = row[i];
         const double dky = (a.Z1[(long)b * a.ldZ1 + j] - Ge[(long)j * KT + (k0 + c + 1)]) * inv;
         double u = dky;
-        for (int i = 0; i < P; i++) u -= dkx[j][i] * xky[i];
+        for (int i = 0; i < P; i++) u -= dkx(j, i) * xky[i];
         uvec[j] = u;
     }
     __syncthreads();
@@ -204,18 +210,24 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
         // pair index of (lo, hi) in the row-major upper triangle
         const long pidx = (long)lo * k0 - (long)lo * (lo - 1) / 2 + (hi - lo);
         double v = (a.Z3[(long)b * a.ldZ3 + pidx] - Ge[(long)j * KT + jp]) * inv;
-        for (int i = 0; i < P; i++) v -= dkx[j][i] * sol[jp][i];
+        for (int i = 0; i < P; i++) v -= dkx(j, i) * sol(jp, i);
         F[e] = ok ? 0.5 * v : NAN;
     }
 }
+#undef L
+#undef dkx
+#undef sol
 
 }  // namespace
 
 int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext) {
     if (variants <= 0) return CRM_OK;
     const int KT = a.k0 + a.c + 2;
-    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV) {
-        set_error("assemble: k0=%d (max %d), c=%d (max %d)", a.k0, CRM_MAX_K0, a.c, CRM_MAX_COV);
+    const int P = a.c + 1;
+    const size_t fin_lds = sizeof(double) * ((size_t)P * P + P + 2 * (size_t)a.k0 * P + a.k0);
+    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV_WIDE || KT > 144 || fin_lds > 150 * 1024) {
+        set_error("assemble: k0=%d, c=%d outside the supported range (k0 <= %d, c <= %d, k0 + c + 2 <= 144, "
+                  "(c+1)(2 k0 + c + 2) <= 19000)", a.k0, a.c, CRM_MAX_K0, CRM_MAX_COV_WIDE);
         return CRM_ERR_UNSUPPORTED;
     }
     const int ts = (KT + 15) / 16;
@@ -224,7 +236,10 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
     else if (ts <= 6) hipLaunchKernelGGL(gram_ext_kernel<6>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
     else hipLaunchKernelGGL(gram_ext_kernel<9>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
     CRM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(finalize_kernel, dim3(variants), dim3(128), 0, st, a, Gext, KT);
+    if (fin_lds > 60 * 1024)
+        CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&finalize_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+    hipLaunchKernelGGL(finalize_kernel, dim3(variants), dim3(128), fin_lds, st, a, Gext, KT);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

@@ -134,7 +134,7 @@ __global__ void donor_stats_kernel(const double* __restrict__ Gam, long ld_gam, 
     double acc = 0.0;
     for (int d = 0; d < m; d++) {
         const double g = Gam[(long)d * ld_gam + b];
-        acc += (q == 0 ? g * g : g) * sums[d * 16 + q];
+        acc += (q == 0 ? g * g : g) * sums[d * DT_SUMS_LD + q];
     }
     if (q == 0) gg[b] = acc;
     else if (q == 1) gy[b] = acc;

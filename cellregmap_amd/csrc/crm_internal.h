@@ -8,9 +8,10 @@ namespace crm {
 
 constexpr int CRM_DEFAULT_BLOCK = 1024;  // variants per internal batch
 constexpr int CRM_MAX_RHO = 16;    // rho grid points (the reference uses 1 or 11)
-constexpr int CRM_MAX_COV = 8;    // columns of W the interaction null fit is instantiated for
-constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W the association paths accept (LDS null-fit kernel)
+constexpr int CRM_MAX_COV = 8;    // columns of W the register null-fit kernel is instantiated for
+constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W overall (beyond CRM_MAX_COV: the LDS null-fit kernel)
 constexpr int CRM_MAX_K0 = 128;   // contexts (columns of E0)
+constexpr int DT_SUMS_LD = 64;         // columns of the per-donor sums table (1 + 1 + c)
 constexpr int BLOCK_SLACK_MAX = 4096;  // groups of a donor-constant panel
 
 struct DevBuf {

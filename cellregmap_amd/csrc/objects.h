@@ -45,7 +45,7 @@ struct crm_gene {
     crm::DevBuf dt_TZ;    // [nrho][m_pad x ldq]          Z' Q0(rho)
     crm::DevBuf dt_Bd;    // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
     crm::DevBuf dt_Z1, dt_Z2, dt_Z3;  // [m_pad x ld]     Z'[y o E, W o E],  Z'E,  Z'(E (x) E)
-    crm::DevBuf dt_sums;  // [m_pad x 16]: column 0 group size, 1 sum y, 2.. sum W_i
+    crm::DevBuf dt_sums;  // [m_pad x DT_SUMS_LD]: column 0 group size, 1 sum y, 2.. sum W_i
     crm::DevBuf dt_Zt;    // indicators of the permuted groups (idx_G) + the permuted group index
 };
 

@@ -368,7 +368,7 @@ __global__ void donor_sums_kernel(const int* __restrict__ group, long cells, int
     double acc = 0.0;
     for (long i = 0; i < cells; i++)
         if (group[i] == d) acc += q == 0 ? 1.0 : yW[i * ldw + (q - 1)];
-    sums[d * 16 + q] = acc;
+    sums[d * DT_SUMS_LD + q] = acc;
 }
 
 __global__ void permute_group_kernel(const int* __restrict__ group, const int* __restrict__ idx, long n,
@@ -481,8 +481,8 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
         CRM_TRY(launch_reduce_splits(st, sd.buf->as<double>(), sz, ks, sz));
         CRM_HIP(hipStreamSynchronize(st));
     }
-    CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * 16));
-    CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * 16, st));
+    CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * DT_SUMS_LD));
+    CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * DT_SUMS_LD, st));
     hipLaunchKernelGGL(donor_sums_kernel, dim3((unsigned)((m + 63) / 64), c + 2), dim3(64), 0, st,
                        panel->group.as<int>(), n, (int)m, gene->yW.as<double>(), gene->ld_yw, c,
                        gene->dt_sums.as<double>());
@@ -539,8 +539,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
     }
     if (count == 0) return CRM_OK;
-    if (g0->c > CRM_MAX_COV) {
-        set_error("interaction scan: %d covariate columns (supported 1..%d)", g0->c, CRM_MAX_COV);
+    if (ctx->polish && g0->c > CRM_MAX_COV) {
+        set_error("interaction scan: the null-fit polish is only built for up to %d covariate columns", CRM_MAX_COV);
         return CRM_ERR_UNSUPPORTED;
     }
     CRM_HIP(hipSetDevice(ctx->device));
@@ -563,6 +563,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     const int npair = k0 * (k0 + 1) / 2;
     const long ldZ1 = round_up((long)k0 * (1 + c), 128), ldZ2 = round_up(k0, 128), ldZ3 = round_up(npair, 128);
     const int KT = k0 + c + 2;
+    const long ld_gW = round_up(std::max(c, CRM_MAX_COV), 8);
 
     // ---- context features for this permutation (E, E (x) E shared; y o E per gene) --------------
     CRM_TRY(g0->idx.ensure(sizeof(int) * 2 * n));
@@ -619,11 +620,11 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     }
     CRM_TRY(ctx->ws_F.ensure(sizeof(double) * (size_t)BLK * k0 * k0));
     CRM_TRY(ctx->ws_Gext.ensure(sizeof(double) * (size_t)BLK * KT * KT));
-    const size_t stats_ws = variant_stats_workspace(BLK, c);
+    const size_t stats_ws = variant_stats_workspace(BLK, std::min(c, CRM_MAX_COV));
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_gg = carve(sizeof(double) * BLK), o_gy = carve(sizeof(double) * BLK * ng),
-                 o_gW = carve(sizeof(double) * BLK * CRM_MAX_COV), o_trial = carve(sizeof(NullFitTrial) * BLK * nrho),
+                 o_gW = carve(sizeof(double) * BLK * ld_gW), o_trial = carve(sizeof(NullFitTrial) * BLK * nrho),
                  o_fit = carve(sizeof(NullFitOut) * BLK * ng), o_pos = carve(sizeof(int) * BLK * ng),
                  o_ord = carve(sizeof(int) * max_pairs), o_Q = carve(sizeof(double) * BLK),
                  o_pv = carve(sizeof(double) * BLK), o_lam = carve(sizeof(double) * BLK * k0),
@@ -711,9 +712,9 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             if (collapsed)
-                CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, g->dt_sums.as<double>(), c, d_gg, d_gy + (size_t)gi * BLK, d_gW, CRM_MAX_COV));
+                CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, g->dt_sums.as<double>(), c, d_gg, d_gy + (size_t)gi * BLK, d_gW, ld_gW));
             else
-                CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, CRM_MAX_COV));
+                CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, ld_gW));
         }
         // 3. T(rho) = G' Q0(rho) for all grid points.  With Q0(rho) = H Mix(rho) the n-length work is
         //    done once, (H'G), followed by eleven small products Mix(rho)'(H'G): 2 n cols + 2 cols sum r
@@ -755,7 +756,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 R.r = bg->r[i];
             }
             fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
-            fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = CRM_MAX_COV;
+            fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = ld_gW;
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             CRM_TRY(launch_nullfit(st, fa, nb));
         }
@@ -878,7 +879,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
             aa.Z1 = dZ1; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
             aa.WW = g->WW.as<double>(); aa.Wy = g->Wy.as<double>(); aa.yy = g->yy;
-            aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = CRM_MAX_COV;
+            aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = ld_gW;
             aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
             CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
             CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));

@@ -84,12 +84,30 @@ def test_non_finite_genotypes_raise():
         CellRegMap(c.y, c.E, W=c.W).scan_interaction(G)
 
 
+def test_many_covariates_in_the_interaction_scan():
+    """More than 8 fixed-effect columns (intercept + covariates + PCs): the LDS null-fit kernel and the
+    dynamically sized assembly take over."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(10, 30, 4, 10, seed=38)
+    rng = np.random.default_rng(2)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 13))], axis=1)   # 14 columns
+    crm = CellRegMap(c.y, c.E, W=W, hK=c.hK)
+    opv, oinfo, ost = OracleCellRegMap(c.y, c.E, W=W, hK=c.hK).scan_interaction(c.G, return_stats=True)
+    for groups in (None, "auto"):
+        pv, info, st = crm.scan_interaction(GenotypePanel(c.G, groups=groups), return_stats=True)
+        assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+        assert_allclose(st["Q"], ost["Q"], rtol=1e-6)
+        assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
 def test_unsupported_sizes_fail_loudly():
     from cellregmap_amd import CellRegMap, _lib
 
     c = _cohort(6, 10, 3, 4, seed=35)
     rng = np.random.default_rng(1)
-    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 9))], axis=1)  # 10 covariates > 8
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 62))], axis=1)[:, :63]  # 63 covariates > 62
     with pytest.raises(_lib.CrmError):
         CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
 
