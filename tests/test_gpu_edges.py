@@ -105,9 +105,9 @@ def test_many_covariates_in_the_interaction_scan():
 def test_unsupported_sizes_fail_loudly():
     from cellregmap_amd import CellRegMap, _lib
 
-    c = _cohort(6, 10, 3, 4, seed=35)
+    c = _cohort(8, 20, 3, 4, seed=35)
     rng = np.random.default_rng(1)
-    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 62))], axis=1)[:, :63]  # 63 covariates > 62
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 69))], axis=1)  # 70 independent covariates > 62
     with pytest.raises(_lib.CrmError):
         CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
 
