@@ -9,6 +9,7 @@ from ._engine import (
     GenotypePanel,
     candidate_groups,
     detect_groups,
+    compute_maf,
     estimate_betas,
     get_L_values,
     lrt_pvalues,
@@ -40,6 +41,7 @@ __all__ = [
     "run_interaction",
     "run_interaction_many",
     "scan_interaction_many",
+    "compute_maf",
     "estimate_betas",
     "get_L_values",
     "lrt_pvalues",

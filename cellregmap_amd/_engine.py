@@ -271,6 +271,9 @@ class GenotypePanel:
         return self
 
 
+_DEFERRED = object()  # constructor argument: build the background decompositions on first use
+
+
 class CellRegMap:
     """Mixed model with genetic effect heterogeneity -- MI355X engine.
 
@@ -326,12 +329,21 @@ class CellRegMap:
         else:
             self._rho1 = _RHO_GRID
             B = self._Ls if isinstance(self._Ls, HadamardHalves) else np.concatenate(self._Ls, axis=1)
-        if background is not None:
-            self._bg = background
+        self._bg_halves = B
+        if background is _DEFERRED:  # estimate_betas: predict_interaction never reads them
+            self._bg_lazy = None
+        elif background is not None:
+            self._bg_lazy = background
         else:
-            self._bg = _make_background(self._E1, B, self._rho1, device)
+            self._bg_lazy = _make_background(self._E1, B, self._rho1, device)
         self._gene = None
         self._gene_fin = None
+
+    @property
+    def _bg(self):
+        if self._bg_lazy is None:
+            self._bg_lazy = _make_background(self._E1, self._bg_halves, self._rho1, self._device)
+        return self._bg_lazy
 
     @property
     def n_samples(self):
@@ -465,11 +477,81 @@ class CellRegMap:
         (glimix-core FastScanner; _cellregmap.py:284-314)."""
         return self._scan_association(G, True, return_stats)
 
+    # -- effect sizes (_cellregmap.py:137-244) -----------------------------------------------------
+    def _lmm_fit(self, bg, M):
+        """Best restricted fit of LMM(y, M, QS(rho)) over the grid of ``bg``:
+        (rho, v0, v1, beta, grid index).  Rank-deficient M goes through the SVD basis like
+        glimix-core's LMM (beta is the minimum-norm solution)."""
+        lib = _lib.load()
+        U, s, Vt = _economic_svd(M)
+        full = s.shape[0] == M.shape[1]
+        X = _lib.f64(M if full else U * s)
+        y = _lib.f64(self._y)
+        E0 = _lib.f64(self._E0)
+        h = ctypes.c_void_p()
+        _lib.check(lib.crm_gene_create(bg.handle, _lib.ptr(y), _lib.ptr(X), X.shape[1], _lib.ptr(E0), E0.shape[1],
+                                       ctypes.byref(h)))
+        try:
+            fit = np.empty(6)
+            beta = np.empty(X.shape[1])
+            _lib.check(lib.crm_lmm_fit(h, 1, _lib.ptr(fit), _lib.ptr(beta)))
+        finally:
+            lib.crm_gene_destroy(h)
+        if not full:
+            beta = Vt.T @ beta
+        return fit[0], fit[1], fit[2], beta, int(fit[5])
+
+    def _snp_background(self, gE):
+        """Decompositions of [sqrt(rho) g o E0, sqrt(1-rho) L..] over the grid (:158-175).  As in the
+        reference only ``Ls`` enters here -- an ``hK`` passed to the constructor does not."""
+        if isinstance(self._Ls, HadamardHalves):
+            B = self._Ls
+        elif len(self._Ls) == 0:
+            B = None
+        else:
+            B = np.concatenate(self._Ls, axis=1)
+        return _make_background(gE, B, self._rho1, self._device, cache=False)
+
+    @staticmethod
+    def _cov_solve(bg, ri, v0, v1, rhs):
+        rhs = _lib.f64(np.asarray(rhs, float).reshape(rhs.shape[0], -1))
+        out = np.empty_like(rhs)
+        _lib.check(_lib.load().crm_cov_solve(bg.handle, ri, float(v0), float(v1), _lib.ptr(rhs), rhs.shape[1],
+                                             _lib.ptr(out)))
+        return out
+
     def predict_interaction(self, G, MAF):
-        raise NotImplementedError("effect-size estimation is outside the score-test path")
+        """Persistent effect and cell-level GxC effects per SNP (_cellregmap.py:137-205): returns
+        ``(beta_g (p,), beta_gxe (1, n, p))`` -- the reference's shapes."""
+        G = np.asarray(G, float)
+        E0, W = self._E0, self._W
+        maf = np.asarray(np.atleast_1d(MAF), float)
+        normalization = 1 / np.sqrt(2 * maf * (1 - maf))
+        beta_g_s, beta_gxe_s = [], []
+        for i in range(G.shape[1]):
+            g = G[:, [i]]
+            M = np.concatenate((W, g, E0), axis=1)
+            gE = g * E0
+            bg = self._snp_background(gE)
+            rho1, v0, v1, beta, ri = self._lmm_fit(bg, M)
+            yadj = (self._y - M @ beta).reshape(-1, 1)
+            v = self._cov_solve(bg, ri, v0, v1, yadj)
+            beta_g_s.append(beta[W.shape[1]])
+            beta_gxe_s.append((v0 * rho1) * E0 @ (gE.T @ v) * normalization[i])
+        return np.asarray(beta_g_s), np.stack(beta_gxe_s).T
 
     def estimate_aggregate_environment(self, g):
-        raise NotImplementedError("effect-size estimation is outside the score-test path")
+        """_cellregmap.py:207-244: the fit runs on the object's own background; only the final solve
+        uses the decomposition of the SNP's covariance halves."""
+        g = np.atleast_2d(np.asarray(g, float)).reshape((np.asarray(g).size, 1))
+        E0, W = self._E0, self._W
+        gE = g * E0
+        M = np.concatenate((W, g, E0), axis=1)
+        rho1, v0, v1, beta, ri = self._lmm_fit(self._bg, M)
+        yadj = self._y - M @ beta
+        bg = self._snp_background(gE)
+        v = self._cov_solve(bg, ri, v0, v1, yadj.reshape(-1, 1))[:, 0]
+        return E0 @ ((rho1 * v0) * gE.T @ v)
 
 
 def scan_interaction_many(crms, G, idx_E=None, idx_G=None):
@@ -574,6 +656,20 @@ def run_association_fast(y, W, E, G, hK=None, *, device=0):
     return pv
 
 
-def estimate_betas(y, W, E, G, maf=None, E1=None, E2=None, hK=None):
-    """Effect sizes (_cellregmap.py:640-682): outside the score-test path."""
-    raise NotImplementedError("estimate_betas is outside the score-test path of this engine")
+def compute_maf(X):
+    """Minor allele frequencies of a 0/1/2 (or dosage) matrix with NaN as missing
+    (_cellregmap.py:589-638, plain-array and DataFrame inputs)."""
+    X = np.asarray(X, float)
+    s0 = np.nansum(X, axis=0) / (2 * np.logical_not(np.isnan(X)).sum(axis=0))
+    return np.minimum(s0, 1 - s0)
+
+
+def estimate_betas(y, W, E, G, maf=None, E1=None, E2=None, hK=None, *, device=0):
+    """Effect sizes (_cellregmap.py:640-682): persistent effects and cell-level GxC effects."""
+    E1 = E if E1 is None else E1
+    E2 = E if E2 is None else E2
+    Ls = None if hK is None else get_L_values(hK, E2)
+    crm = CellRegMap(y=y, E=E, W=W, E1=E1, Ls=Ls, device=device, background=_DEFERRED)
+    if maf is None:
+        maf = compute_maf(G)
+    return crm.predict_interaction(G, maf)

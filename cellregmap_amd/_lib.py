@@ -46,6 +46,8 @@ SIGNATURES = {
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
     "crm_scan_interaction_multi": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_long, ctypes.c_long] + [vp] * 8),
     "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
+    "crm_lmm_fit": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),
+    "crm_cov_solve": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]),
     "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_set_null_fit_polish": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_set_fast_rotation": (ctypes.c_int, [vp, ctypes.c_int]),

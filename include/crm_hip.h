@@ -120,6 +120,18 @@ int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* pa
 int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long count, int fast,
                          double* out_pvalue, double* out_alt_lml, double* out_null);
 
+/* ---- effect sizes: the device operations behind predict_interaction (_cellregmap.py:137-205) and
+ * estimate_aggregate_environment (:207-244).
+ * crm_lmm_fit: LMM(y, M, QS(rho), restricted).fit() for every grid point of the gene's background
+ * (M = the gene's covariate matrix), keeping the first strictly larger lml.
+ *   out_fit  6 doubles {rho, v0, v1, lml, delta, grid index}
+ *   out_beta c doubles (may be NULL): the fixed effects of the kept fit (LMM.beta)
+ * crm_cov_solve: out = (v0 Q0 S0 Q0' + v1 I)^-1 rhs for grid point rho_index of `bg` -- QSCov.solve
+ * (_math.py:40-67); rhs and out are n x m row-major host arrays. */
+int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, double* out_beta);
+int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const double* rhs, int m,
+                  double* out);
+
 /* Block size (variants per internal batch); 0 restores the default. */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
 /* on = 1 (default): for backgrounds built on the device with a well-conditioned kept spectrum

@@ -21,8 +21,8 @@ module                    follows
                           chi2comb (Davies 1980, AS 155 ``qfc``) -> ``qfc.c``
 ``oracle.scoretest``      cellregmap/_math.py:33-160 (implicit QS algebra + the
                           dense textbook definitions)
-``oracle.crm``            cellregmap/_cellregmap.py:63-131, 246-314, 317-440,
-                          443-469, 471-587
+``oracle.crm``            cellregmap/_cellregmap.py:63-131, 137-244 (effect
+                          sizes), 246-314, 317-440, 443-469, 471-587, 589-682
 ========================  =====================================================
 
 PARITY STATUS
@@ -38,5 +38,8 @@ PARITY STATUS
   Davies p-value, so for these pieces: **parity unpinned** -- they are written
   from the published algorithms and checked against independent mathematics
   (dense REML likelihood, numerical Imhof integral, scipy distributions).
-  Only the Liu branch is pinned by the reference (test_math.py:76-83).
+  Only the Liu branch is pinned by the reference (test_math.py:76-83).  The
+  effect-size functions of ``oracle.crm`` sit on ``oracle.lmm`` and share its
+  status; ``compute_maf`` is pinned by the reference's doctest vector
+  (_cellregmap.py:600-609).
 """

@@ -140,6 +140,79 @@ class OracleCellRegMap:
         return lrt_pvalues(null_lml, alt, dof=1), info
 
 
+    # -- effect sizes (:137-244) --------------------------------------------------------------------
+    def predict_interaction(self, G, MAF):
+        """Per-SNP persistent effect and cell-level GxC effects (BLUP), _cellregmap.py:137-205."""
+        from .scoretest import cov_solve
+
+        G = np.asarray(G, float)
+        E0, W = self._E0, self._W
+        maf = np.asarray(np.atleast_1d(MAF), float)
+        norm = 1 / np.sqrt(2 * maf * (1 - maf))
+        beta_g_s, beta_gxe_s = [], []
+        for i in range(G.shape[1]):
+            g = G[:, [i]]
+            M = np.concatenate((W, g, E0), axis=1)
+            gE = g * E0
+            best_lml, best_rho, best, best_qs = -np.inf, 0, None, None
+            for rho in self._rho:
+                hS = np.concatenate([np.sqrt(rho) * gE] + [np.sqrt(1 - rho) * L for L in self._Ls], axis=1)
+                qs = economic_qs_linear(hS, return_q1=False)
+                lmm = LMM(self._y, M, qs, restricted=True)
+                lmm.fit(verbose=False, polish=self._polish)
+                if lmm.lml() > best_lml:
+                    best_lml, best_rho, best, best_qs = lmm.lml(), rho, lmm, qs
+            beta_g = best.beta[W.shape[1]]
+            yadj = (self._y - best.mean()).reshape(-1, 1)
+            cov = LowRankCov(best_qs[0][0], best_qs[1], best.v0, best.v1)
+            v = cov_solve(cov, yadj)
+            sigma2_gxe = best.v0 * best_rho
+            beta_gxe = sigma2_gxe * E0 @ (gE.T @ v) * norm[i]
+            beta_g_s.append(beta_g)
+            beta_gxe_s.append(beta_gxe)
+        return np.asarray(beta_g_s), np.stack(beta_gxe_s).T
+
+    def estimate_aggregate_environment(self, g):
+        """_cellregmap.py:207-244 (the LMM runs on the object's own background decompositions; only
+        the final solve uses the per-SNP one)."""
+        from .scoretest import cov_solve
+
+        g = np.atleast_2d(g).reshape((np.asarray(g).size, 1))
+        E0, W = self._E0, self._W
+        gE = g * E0
+        M = np.concatenate((W, g, E0), axis=1)
+        best_lml, best_rho, best = -np.inf, 0, None
+        half = {}
+        for rho in self._rho:
+            half[rho] = np.concatenate([np.sqrt(rho) * gE] + [np.sqrt(1 - rho) * L for L in self._Ls], axis=1)
+            lmm = LMM(self._y, M, self._qs[rho], restricted=True)
+            lmm.fit(verbose=False, polish=self._polish)
+            if lmm.lml() > best_lml:
+                best_lml, best_rho, best = lmm.lml(), rho, lmm
+        yadj = self._y - best.mean()
+        qs = economic_qs_linear(half[best_rho], return_q1=False)
+        v = cov_solve(LowRankCov(qs[0][0], qs[1], best.v0, best.v1), yadj)
+        return E0 @ (best_rho * best.v0 * gE.T @ v)
+
+
+def compute_maf(X):
+    """Plain-array branch of _cellregmap.py:589-638 (the reference imports dask / xarray first)."""
+    X = np.asarray(X, float)
+    s0 = np.nansum(X, axis=0) / (2 * np.logical_not(np.isnan(X)).sum(axis=0))
+    return np.minimum(s0, 1 - s0)
+
+
+def estimate_betas(y, W, E, G, maf=None, E1=None, E2=None, hK=None, polish=False):
+    """_cellregmap.py:640-682."""
+    E1 = E if E1 is None else E1
+    E2 = E if E2 is None else E2
+    Ls = None if hK is None else khatri_rao_halves(hK, E2)
+    crm = OracleCellRegMap(y=y, E=E, W=W, E1=E1, Ls=Ls, polish=polish)
+    if maf is None:
+        maf = compute_maf(G)
+    return crm.predict_interaction(G, maf)
+
+
 def lrt_pvalues(null_lml, alt_lmls, dof=1):
     """_cellregmap.py:443-469."""
     from scipy.stats import chi2

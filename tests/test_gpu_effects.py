@@ -1,0 +1,116 @@
+"""Effect sizes on the device against the oracle's restatement of
+cellregmap/_cellregmap.py:137-244 and :640-682."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from cellregmap_amd.synth import make_cohort  # noqa: E402
+
+
+def _cohort(seed=3, donors=8, cells=15, k0=3, p=4):
+    c = make_cohort(donors, cells, k0, p, seed=seed)
+    maf = np.clip(np.minimum(c.G.mean(0) / 2, 1 - c.G.mean(0) / 2), 0.05, 0.5)
+    return c, maf
+
+
+def _close(a, b, rtol):
+    scale = np.max(np.abs(b))
+    assert a.shape == b.shape
+    assert np.max(np.abs(a - b)) <= rtol * scale, (np.max(np.abs(a - b)), scale)
+
+
+@pytest.mark.parametrize("with_kinship", [True, False])
+def test_estimate_betas_matches_the_oracle(with_kinship):
+    import cellregmap_amd as crm
+    from oracle import crm as ocrm
+
+    c, maf = _cohort()
+    hK = c.hK if with_kinship else None
+    bg, bgxe = crm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=hK)
+    obg, obgxe = ocrm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=hK)
+    assert bgxe.shape == (1, c.y.size, c.G.shape[1])  # the reference's stack(...).T of (n, 1) columns
+    # the fixed effects move with delta, which Brent's search pins to ~1e-6 only
+    _close(bg, obg, 2e-5)
+    _close(bgxe, obgxe, 2e-5)
+
+
+def test_estimate_betas_with_polished_fits_is_tight():
+    import cellregmap_amd as crm
+    from cellregmap_amd import _engine, _lib
+    from oracle import crm as ocrm
+
+    c, maf = _cohort(seed=5)
+    ctx = _engine._context(0)
+    _lib.check(_lib.load().crm_set_null_fit_polish(ctx, 1))
+    try:
+        bg, bgxe = crm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=c.hK)
+    finally:
+        _lib.check(_lib.load().crm_set_null_fit_polish(ctx, 0))
+    obg, obgxe = ocrm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=c.hK, polish=True)
+    _close(bg, obg, 1e-7)
+    _close(bgxe, obgxe, 1e-7)
+
+
+def test_maf_default_and_compute_maf():
+    import cellregmap_amd as crm
+    from oracle import crm as ocrm
+
+    X = np.random.default_rng(0).integers(0, 3, size=(100, 10)).astype(float)
+    X[3, 4] = np.nan
+    np.testing.assert_allclose(crm.compute_maf(X), ocrm.compute_maf(X), rtol=0, atol=0)
+    assert np.all(crm.compute_maf(X) <= 0.5)
+    c, _ = _cohort(seed=7, p=2)
+    G = np.random.default_rng(1).integers(0, 3, size=(8, 2)).astype(float)[c.donor_of_cell]
+    bg, bgxe = crm.estimate_betas(c.y, c.W, c.E, G, hK=c.hK)
+    obg, obgxe = ocrm.estimate_betas(c.y, c.W, c.E, G, hK=c.hK)
+    _close(bg, obg, 2e-5)
+    _close(bgxe, obgxe, 2e-5)
+
+
+def test_estimate_aggregate_environment_matches_the_oracle():
+    import cellregmap_amd as crm
+    from oracle import crm as ocrm
+
+    # With E1 = E0 the restricted likelihood is flat in rho (E0 is also a fixed effect of this fit,
+    # so the E1E1' component is not identifiable) and the reference's pick of rho -- hence its
+    # result -- hangs on rounding noise of ~1e-13 in the lml.  A distinct E1 makes the case well posed.
+    c, _ = _cohort(seed=11)
+    E1 = np.random.default_rng(2).standard_normal((c.y.size, 4))
+    Ls = crm.get_L_values(c.hK, c.E)
+    dev = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls, E1=E1)
+    ora = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E), E1=E1)
+    for j in (0, 2):
+        a = dev.estimate_aggregate_environment(c.G[:, j])
+        b = ora.estimate_aggregate_environment(c.G[:, j])
+        _close(a, b, 2e-5)
+
+
+def test_collinear_contexts_go_through_the_svd_basis():
+    """E0 with a constant column makes M = [W, g, E0] rank deficient: glimix-core's LMM (and the
+    oracle) fit in the SVD basis and report the minimum-norm beta."""
+    import cellregmap_amd as crm
+    from oracle import crm as ocrm
+
+    c, maf = _cohort(seed=13, p=2)
+    E = np.concatenate([c.E, np.ones((c.y.size, 1))], axis=1)
+    bg, bgxe = crm.estimate_betas(c.y, c.W, E, c.G, maf=maf, hK=c.hK)
+    obg, obgxe = ocrm.estimate_betas(c.y, c.W, E, c.G, maf=maf, hK=c.hK)
+    _close(bg, obg, 2e-5)
+    _close(bgxe, obgxe, 2e-5)
+
+
+def test_cov_solve_is_the_inverse_of_the_covariance():
+    import cellregmap_amd as crm
+
+    c, _ = _cohort(seed=17)
+    dev = crm.CellRegMap(c.y, c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E))
+    bg = dev._bg
+    rng = np.random.default_rng(0)
+    rhs = rng.standard_normal((c.y.size, 3))
+    v0, v1 = 0.7, 0.4
+    for ri in (0, 5, 10):
+        Q0, S0 = bg.read(ri, c.y.size)
+        K = v0 * (Q0 * S0) @ Q0.T + v1 * np.eye(c.y.size)
+        out = dev._cov_solve(bg, ri, v0, v1, rhs)
+        np.testing.assert_allclose(K @ out, rhs, rtol=0, atol=1e-10)
