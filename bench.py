@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="variants per step")
     ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 (BASELINE.json configs[1] / [2])")
     ap.add_argument("--cpu-variants", type=int, default=8, help="variants of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--mode", default="C", choices=["C", "B"],
+                    help="background: C = E1E1' + K o EE' (headline), B = E1E1' + hK hK' (r = k + m)")
     ap.add_argument("--polish", type=int, default=0)
     ap.add_argument("--collapsed", type=int, default=1, help="also time the donor-collapsed path (N=1)")
     ap.add_argument("--genes", type=int, default=16, help="phenotypes of the shared multi-gene leg (0 = skip, N=1)")
@@ -84,7 +86,8 @@ def main():
     _lib.check(lib.crm_set_null_fit_polish(ctx, int(args.polish)))
     t0 = time.time()
     Ls = get_L_values(cohort.hK, cohort.E)
-    crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, Ls=Ls, device=local_rank)
+    bg_kw = {"Ls": Ls} if args.mode == "C" else {"hK": cohort.hK}
+    crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)
     crm._bind_gene()
     _lib.check(lib.crm_ctx_synchronize(ctx))
     t_ctor = time.time() - t0
@@ -206,7 +209,7 @@ def main():
         crms = [crm]
         for i in range(1, args.genes):
             yi = cohort.y[rng.permutation(n)] if i % 2 else cohort.y + rng.normal(size=n)
-            ci = CellRegMap(yi, cohort.E, W=cohort.W, Ls=Ls, device=local_rank, background=crm._bg)
+            ci = CellRegMap(yi, cohort.E, W=cohort.W, device=local_rank, background=crm._bg, **bg_kw)
             ci._bind_gene()
             crms.append(ci)
         handles = (ctypes.c_void_p * len(crms))(*[c._gene.value for c in crms])
@@ -266,7 +269,7 @@ def main():
         "ms_per_step": round(elapsed / max(steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {n} cells x {k0} contexts, mode C background (ranks {min(ranks)}..{max(ranks)}), "
+            "workload": f"{args.config}: {n} cells x {k0} contexts, mode {args.mode} background (ranks {min(ranks)}..{max(ranks)}), "
                         f"{steps} steps x {batch} variants per GPU of the {p_total}-variant panel, 1 gene",
             "batch_variants": batch, "cells": n, "contexts": k0, "rho_grid": len(ranks),
             "null_fit": "brent-1e-6" + ("+polish" if args.polish else ""),
