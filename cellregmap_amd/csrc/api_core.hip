@@ -203,6 +203,35 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
     return CRM_OK;
 }
 
+// transposed store: CT is N x (B*k0) row-major
+int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const double* G, const double* E,
+                           const double* Y, double* CT) {
+    if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !CT) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    const long cp = round_up(cells, GEMM_BK);
+    const long ldg = round_up(B, 128) + 128, lde = round_up(k0, 32), ldy = round_up(N, 128);
+    const int M = B * k0;
+    const long ldc = round_up(M, 128);
+    ScopedBuf bg, be, by, bc, bp;
+    CRM_TRY(bg.ensure(sizeof(double) * cp * ldg));
+    CRM_TRY(be.ensure(sizeof(double) * cp * lde));
+    CRM_TRY(by.ensure(sizeof(double) * cp * ldy));
+    CRM_TRY(bc.ensure(sizeof(double) * (long)N * ldc));
+    CRM_TRY(bp.ensure(sizeof(GemmProblem)));
+    CRM_TRY(upload_padded(c->stream, bg.as<double>(), ldg, cp, G, B, cells, B));
+    CRM_TRY(upload_padded(c->stream, be.as<double>(), lde, cp, E, k0, cells, k0));
+    CRM_TRY(upload_padded(c->stream, by.as<double>(), ldy, cp, Y, N, cells, N));
+    GemmProblem p{};
+    p.X = bg.as<double>(); p.E = be.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
+    p.ldx = ldg; p.lde = lde; p.ldy = ldy; p.ldc = ldc; p.M = M; p.N = N; p.k0 = k0;
+    CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
+    CRM_TRY(launch_kr_transposed(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, k0));
+    CRM_HIP(hipMemcpy2DAsync(CT, M * sizeof(double), bc.ptr, ldc * sizeof(double), M * sizeof(double), N,
+                             hipMemcpyDeviceToHost, c->stream));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    return CRM_OK;
+}
+
 }  // extern "C"
 
 // ---- eigenvalue / Davies hooks ---------------------------------------------------------------

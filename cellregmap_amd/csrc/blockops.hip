@@ -229,6 +229,29 @@ size_t variant_stats_workspace(int variants, int c) {
     return sizeof(double) * (size_t)STAT_SPLITS * (c + 2) * variants;
 }
 
+// dst[h, p*k0 + j] = src[h, ord[p]*k0 + j]: k0-wide column slabs reordered (pair order), zero beyond
+__global__ __launch_bounds__(256) void gather_slabs_kernel(const double* __restrict__ src, long ld_src,
+                                                            const int* __restrict__ ord, int npairs, int k0,
+                                                            double* __restrict__ dst, long ld_dst, int dst_cols) {
+    const long h = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= dst_cols) return;
+    double v = 0.0;
+    const int p = q / k0;
+    if (p < npairs) v = src[h * ld_src + (long)ord[p] * k0 + (q - p * k0)];
+    dst[h * ld_dst + q] = v;
+}
+
+int launch_gather_slabs(hipStream_t st, const double* src, long ld_src, long rows, const int* ord, int npairs,
+                        int k0, double* dst, long ld_dst, int dst_cols) {
+    if (rows <= 0 || dst_cols <= 0) return CRM_OK;
+    dim3 grid((unsigned)rows, (dst_cols + 255) / 256);
+    hipLaunchKernelGGL(gather_slabs_kernel, grid, dim3(256), 0, st, src, ld_src, ord, npairs, k0, dst, ld_dst,
+                       dst_cols);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols) {

@@ -50,8 +50,8 @@ struct crm_ctx {
     size_t timed_used = 0;
     double kr_flops = 0.0;
     // scan workspace (grown on demand, reused across calls)
-    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH;
+    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };

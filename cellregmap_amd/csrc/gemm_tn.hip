@@ -258,6 +258,17 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
 int g_contraction_glds = 1;  // 128-wide tiles through the LDS-DMA kernel (gemm_tn_glds.hip)
 int g_contraction_bn = 0;  // output-tile width override: 0 = choose per launch, else 64 or 128
 
+int launch_kr_transposed(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
+                         int k0) {
+    if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
+    if (cells % GEMM_BK != 0 || k0 < 1 || k0 > 128) {
+        set_error("transposed Khatri-Rao contraction: cells=%ld, k0=%d", cells, k0);
+        return CRM_ERR_ARG;
+    }
+    return launch_gemm_tn_glds(st, probs_dev, nz, (max_m + GEMM_BM - 1) / GEMM_BM, (max_n + 127) / 128, cells, true,
+                               k0, 1, 0, true);
+}
+
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;

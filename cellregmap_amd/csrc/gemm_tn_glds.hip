@@ -25,7 +25,9 @@ __host__ __device__ inline int glds_kr_variants(int k0) {
 }
 
 // ECQ: context columns staged per row in units of 32 (round_up(k0, 32) / 32); 0 for the plain kernel
-template <bool KR, int KRQ, int ECQ>
+// TR:  store the transpose, C'[n][m] (ldc = row length of C'): the MFMA operands swap roles, so the
+//      accumulator tiles come out transposed and the stores stay 128-byte contiguous
+template <bool KR, int KRQ, int ECQ, bool TR = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
                                                                int mtiles_max, long cells_per_split,
                                                                long split_stride, int k0) {
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < NT; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = TR ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     };
 
     constexpr int KS = GEMM_BK / 4;
@@ -182,6 +185,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     }
 
     double* Cb = P.C + (long)blockIdx.y * split_stride;
+    if (TR) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int nn = n0 + wn * 64 + j * 16 + lq + 4 * reg;
+                if (nn < P.N) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int m = m0 + wm * 64 + i * 16 + l15;
+                        if (m < P.M) Cb[(long)nn * P.ldc + m] = acc[i][j][reg];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -199,7 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
 }
 
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
-                        bool khatri_rao, int k0, int ksplit, long split_stride) {
+                        bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out) {
+    if (transposed_out && !khatri_rao) {
+        set_error("contraction: the transposed store is only built for the Khatri-Rao form");
+        return CRM_ERR_UNSUPPORTED;
+    }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
     size_t lds = (size_t)2 * GEMM_BK * 128 * sizeof(double);
     if (khatri_rao) {
@@ -208,14 +232,19 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         lds += (size_t)2 * GEMM_BK * (EC + nb) * sizeof(double);
         constexpr int KRQ_BIG = (GEMM_BK * GEMM_BM + 255) / 256;
         const bool small = GEMM_BK * nb <= 256;
-#define CRM_GLDS(Q)                                                                                          \
-    do {                                                                                                     \
-        if (small)                                                                                           \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q>), grid, dim3(256), lds, st, probs_dev, mt,   \
-                               cells / ksplit, split_stride, k0);                                            \
-        else                                                                                                 \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q>), grid, dim3(256), lds, st, probs_dev, \
-                               mt, cells / ksplit, split_stride, k0);                                        \
+#define CRM_GLDS_T(Q, T)                                                                                      \
+    do {                                                                                                      \
+        if (small)                                                                                            \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, T>), grid, dim3(256), lds, st, probs_dev, mt, \
+                               cells / ksplit, split_stride, k0);                                             \
+        else                                                                                                  \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, T>), grid, dim3(256), lds, st,          \
+                               probs_dev, mt, cells / ksplit, split_stride, k0);                              \
+    } while (0)
+#define CRM_GLDS(Q)                              \
+    do {                                         \
+        if (transposed_out) CRM_GLDS_T(Q, true); \
+        else CRM_GLDS_T(Q, false);               \
     } while (0)
         switch (EC / 32) {
             case 1: CRM_GLDS(1); break;
@@ -224,6 +253,7 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
             default: CRM_GLDS(4); break;
         }
 #undef CRM_GLDS
+#undef CRM_GLDS_T
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);
         hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,

@@ -77,6 +77,9 @@ size_t variant_stats_workspace(int variants, int c);
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols);
+// dst[h, p*k0 + j] = src[h, ord[p]*k0 + j] for p < npairs, zero in the remaining dst_cols
+int launch_gather_slabs(hipStream_t st, const double* src, long ld_src, long rows, const int* ord, int npairs,
+                        int k0, double* dst, long ld_dst, int dst_cols);
 // dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]
 int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
                         long cells, const int* row_index, int variants, double* dst, long ld_dst,

@@ -33,6 +33,32 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+// 1 / D for D > 0 (normal range): hardware reciprocal + two Newton steps -- full double precision to
+// the last bit or so, without the scaling / fix-up sequence of an IEEE division.
+__device__ inline double fast_rcp(double D) {
+    double x = __builtin_amdgcn_rcp(D);
+    double e = fma(-D, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-D, x, 1.0);
+    return fma(x, e, x);
+}
+
+// sum_j log D_j is accumulated as a product of mantissas and a sum of exponents (two bit-field
+// operations, one multiply and one integer add per entry) and turned into a logarithm once per pass.
+struct LogProduct {
+    double mant = 1.0;
+    int expo = 0;
+    __device__ inline void mul(double D) {
+        mant *= __builtin_amdgcn_frexp_mant(D);
+        expo += __builtin_amdgcn_frexp_exp(D);
+    }
+    __device__ inline void renorm() {  // mantissas lie in [0.5, 1): call at least every ~900 entries
+        expo += __builtin_amdgcn_frexp_exp(mant);
+        mant = __builtin_amdgcn_frexp_mant(mant);
+    }
+    __device__ inline double log_value() const { return log(mant) + (double)expo * 0.6931471805599453; }
+};
+
 __device__ inline double logistic_clamped(double x) {
     double v;
     if (x > 0.0) {
@@ -168,6 +194,8 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
         for (int i = 0; i < NP; i++) { S[i] = 0.0; S2[i] = 0.0; }
         lsum = 0.0;
         lsum2 = 0.0;
+        LogProduct lp;
+        int trips = 0;
         const double omd = 1.0 - delta;
         // UNR spectrum entries per lane and trip, all loads issued before the arithmetic: the loop is
         // bound by L2 latency otherwise (two wavefronts per SIMD at this register count)
@@ -190,10 +218,10 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
             for (int q = 0; q < UNR; q++) {
                 double wgt = ok[q] ? 1.0 : 0.0, wgt2 = 0.0;
                 if (weighted) {
-                    const double D = omd * s0[q] + delta;
-                    const double inv = 1.0 / D;
+                    const double D = ok[q] ? omd * s0[q] + delta : 1.0;
+                    const double inv = fast_rcp(D);
                     wgt = ok[q] ? inv : 0.0;
-                    lsum += ok[q] ? log(D) : 0.0;
+                    lp.mul(D);
                     if (grad) {
                         const double oms = 1.0 - s0[q];
                         lsum2 += ok[q] ? oms * inv : 0.0;
@@ -211,10 +239,11 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
                     }
                 }
             }
+            if (weighted && (++trips & 127) == 0) lp.renorm();
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) S[i] = wave_sum(S[i]);
-        if (weighted) lsum = wave_sum(lsum);
+        if (weighted) lsum = wave_sum(lp.log_value());
         if (grad) {
 #pragma unroll
             for (int i = 0; i < NP; i++) S2[i] = wave_sum(S2[i]);

@@ -510,6 +510,8 @@ struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: co
 // on the phenotype is done once per block: the block copies, T(rho) = G'Q0(rho), the Khatri-Rao
 // contraction per (variant, rho) pair that at least one gene selected, and the y-free side
 // contractions.  Per gene: g'y, the null fits, E'(g o y), assembly, eigenvalues and Davies.
+int g_shared_h_mode = -1;  // test hook: -1 cost model, 0 never, 1 whenever the background offers H
+
 static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
                      const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs) {
     const int ng = (int)genes.size();
@@ -657,6 +659,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // its mixed table needs the indicators as Khatri-Rao "contexts": m <= 128)
     const bool collapsed = grouped && ctx->collapse && bd_bytes <= ((size_t)48 << 30) && (!idx_G || panel->m <= 128);
     const bool cross = collapsed && idx_G;
+    const long ld_ah = round_up((long)BLK * k0, 128) + 128, ld_xg = round_up((long)max_pairs * k0, 128) + 128;
+    if (bg->fast_T && ctx->fast_T && ng > 1 && !collapsed) {  // operands of the shared-H route (step 6)
+        CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
+        CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)bg->ldh * ld_xg));
+        CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
+    }
     const long mp = grouped ? panel->m_pad : 0;
     if (collapsed) {
         const double* Zt = panel->Z.as<double>();
@@ -786,7 +794,19 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * npairs, hipMemcpyHostToDevice, st));
         double* Gs = ctx->ws_Gs.as<double>();
         CRM_TRY(launch_gather_block(st, Gt, ldb, xrows, xrows, nullptr, d_ord, npairs, Gs, ldp, (int)ldp));
-        // 6. A~ = KR(Gs, Ep)' Q0(rho), one problem per non-empty rho group of pairs
+        // 6. A~ = KR(Gs, Ep)' Q0(rho), one problem per non-empty rho group of pairs.
+        //    Several genes can select several rho* for one variant; with Q0(rho) = H Mix(rho) the
+        //    n-length Khatri-Rao contraction is then done once per variant against H (stored transposed)
+        //    and every (variant, rho) pair costs a cols-length product with Mix(rho) instead.
+        bool via_H = false;
+        if (fastT && ng > 1) {
+            double direct = 0.0, via = (double)nb * (double)bg->cols * (double)n;
+            for (int i = 0; i < nrho; i++) {
+                direct += (double)cnt[i] * bg->r[i] * (double)n;
+                via += (double)cnt[i] * bg->r[i] * (double)bg->ldh;
+            }
+            via_H = g_shared_h_mode < 0 ? via < 0.9 * direct : g_shared_h_mode > 0;
+        }
         int nz = 0, max_m = 0;
         double kr_flops = 0.0;
         for (int i = 0; i < nrho; i++) {
@@ -799,6 +819,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.Y = g0->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
                 p.ldc = (long)k0 * ldA;
                 p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
+            } else if (via_H) {
+                p.X = ctx->ws_XG.as<double>() + (size_t)start[i] * k0; p.ldx = ld_xg;
+                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+                p.ldc = ldA;
+                p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+                kr_flops += 2.0 * (double)bg->ldh * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             } else {
                 p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;
                 p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
@@ -809,7 +835,6 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             max_m = std::max(max_m, p.M);
             probs[nz++] = p;
         }
-        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
         if (ctx->timing) {
             if (ctx->timed_used == ctx->timed.size()) {
                 hipEvent_t a, b;
@@ -819,8 +844,24 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
+        if (via_H) {
+            GemmProblem p{};
+            p.X = Gt; p.ldx = ldb; p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;
+            p.Y = bg->H.as<double>(); p.ldy = bg->ldh;
+            p.C = ctx->ws_AH.as<double>(); p.ldc = ld_ah;
+            p.M = nb * k0; p.N = (int)bg->cols;
+            CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_kr_transposed(st, d_probs, 1, p.M, p.N, np, k0));
+            kr_flops += 2.0 * (double)n * (double)bg->cols * (double)k0 * (double)nb;
+            const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
+            CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
+                                        ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
         if (collapsed)
             CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
+        else if (via_H)
+            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, bg->ldh, false, 0, 1, 0));
         else
             CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, np, true, k0, 1, 0));
         if (ctx->timing) {
@@ -918,6 +959,11 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     std::vector<ScanOut> outs{{out_pvalue, out_rho1, out_e2, out_g2, out_eps2, out_Q, out_lml, out_delta,
                                out_scale, out_lambda, out_F}};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+}
+
+int crm_test_set_shared_h(int mode) {
+    crm::g_shared_h_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    return CRM_OK;
 }
 
 int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* panel, long first, long count,

@@ -163,6 +163,13 @@ int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, c
 /* C ((B*k0) x N) = KR(G, E)' Y with G: cells x B, E: cells x k0, Y: cells x N. */
 int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                          const double* E, const double* Y, double* C);
+/* Route of the multi-gene scan's contraction: -1 (default) cost model, 0 always per (variant, rho)
+ * pair against Q0(rho), 1 once per variant against H followed by Mix(rho) per pair (when the
+ * background keeps H). */
+int crm_test_set_shared_h(int mode);
+/* The same product stored transposed: CT (N x (B*k0)). */
+int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
+                           const double* E, const double* Y, double* CT);
 /* Eigenvalues (ascending) of `count` symmetric k x k matrices (lower triangle read). */
 int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* lambda);
 /* Davies/Liu p-values for `count` (Q, lambda[k]) pairs after the eigenvalue filter. */

@@ -220,6 +220,40 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
 
 
+def test_shared_h_route_of_the_multi_gene_scan():
+    """With Q0(rho) = H Mix(rho) the n-length Khatri-Rao contraction can be done once per variant
+    against H and finished per (variant, rho*) pair with Mix(rho*): same null fits (bit-identical
+    info), score statistics equal to rounding."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _lib, get_L_values, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 25, 4, 70, seed=41)
+    rng = np.random.default_rng(7)
+    Y = np.stack([c.y, c.y[rng.permutation(c.y.size)], rng.normal(size=c.y.size), c.y + rng.normal(size=c.y.size)], axis=1)
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(Y[:, 0], c.E, W=c.W, Ls=Ls)      # thin branch (4 + 4*8 columns < 200 cells): keeps H
+    crms = [first] + [CellRegMap(Y[:, i], c.E, W=c.W, Ls=Ls, background=first._bg) for i in range(1, 4)]
+    panel = GenotypePanel(c.G, groups=None)
+    lib = _lib.load()
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.crm_test_set_shared_h(mode))
+            for name, kw in (("plain", {}), ("idx_E", {"idx_E": rng.permutation(c.y.size)}),
+                             ("idx_G", {"idx_G": np.random.default_rng(3).permutation(c.y.size)})):
+                if name == "idx_E":
+                    kw = {"idx_E": np.random.default_rng(5).permutation(c.y.size)}
+                out[mode, name] = scan_interaction_many(crms, panel, **kw)
+    finally:
+        _lib.check(lib.crm_test_set_shared_h(-1))
+    for name in ("plain", "idx_E", "idx_G"):
+        (pv0, info0), (pv1, info1) = out[0, name], out[1, name]
+        for k in info0:
+            assert np.array_equal(info0[k], info1[k])
+        assert not np.array_equal(pv0, pv1)  # the other route really ran
+        assert_allclose(pv1, pv0, rtol=1e-9)
+
+
 def test_rotation_through_the_mixing_matrices_equals_direct_rotation():
     """T(rho) = Mix(rho)'(H'G) (default for device-built, well-conditioned backgrounds) against the
     direct G'Q0(rho): same results to ~1e-9 with the null-fit polish on."""

@@ -81,6 +81,23 @@ def test_contract_khatri_rao(ctx, variant, cells, B, k0, N):
     assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
 
 
+@pytest.mark.parametrize("cells,B,k0,N", [(64, 3, 5, 17), (1000, 37, 50, 300), (320, 130, 4, 129), (4096, 8, 128, 64)])
+def test_khatri_rao_contraction_with_transposed_store(ctx, cells, B, k0, N):
+    """The shared-H route of the multi-gene scan stores (KR(G,E)' H)' directly (operands of the MFMA
+    swapped, stores along M)."""
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    rng = np.random.default_rng(cells + B)
+    G = rng.normal(size=(cells, B))
+    E = rng.normal(size=(cells, k0))
+    Y = rng.normal(size=(cells, N))
+    CT = np.empty((N, B * k0))
+    _lib.check(lib.crm_test_contract_kr_t(h, cells, B, k0, N, _lib.ptr(G), _lib.ptr(E), _lib.ptr(Y), _lib.ptr(CT)))
+    KR = (G[:, :, None] * E[:, None, :]).reshape(cells, B * k0)
+    assert_allclose(CT, Y.T @ KR, rtol=0, atol=1e-11 * np.sqrt(cells))
+
+
 @pytest.mark.parametrize("k", [1, 2, 7, 50, 64, 65, 128])
 def test_eigvalsh_batched(ctx, k):
     from cellregmap_amd import _lib
