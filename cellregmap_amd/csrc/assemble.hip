@@ -9,22 +9,33 @@
 //
 // so that with A~ = Q0' diag(gtest) E0 (from the Khatri-Rao contraction) and the n-length
 // reductions Z1..Z3 nothing of size n is touched here.  Two kernels:
-//   gram_ext   : S S' for S = sqrt(d) o [A~ rows ; Q0'W ; Q0'g ; Q0'y]  (one pass over r)
+//   gram_ext   : S S' for S = sqrt(d) o [A~ rows ; Q0'W ; Q0'g ; Q0'y]  (one pass over r, FP64 MFMA)
 //   finalize   : X'K^-1X etc., the (c+1)x(c+1) solve, Q = 1/2 |u|^2,
 //                F = 1/2 (D'K^-1 D - D'K^-1 X (X'K^-1X)^-1 X'K^-1 D)
+#include <type_traits>
+
 #include "nullfit.h"
 
 namespace crm {
 
 namespace {
 
-constexpr int CH = 64;  // spectrum entries staged per step
+constexpr int CH = 64;   // spectrum entries staged per step
+constexpr int SLD = 66;  // LDS row length: 16 rows x 2 columns of a fragment read land on 32 distinct bank pairs
 
-template <int TS>
-__global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* __restrict__ Gext,
-                                                        int KT) {
-    __shared__ double Ss[16 * TS][CH + 1];
-    __shared__ double sd[CH];
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// S S' with S = sqrt(d) o [A~ rows ; Q0'W ; Q0'g ; Q0'y] (KT x r) on the FP64 matrix pipe.  One
+// workgroup per variant; S is staged through LDS in chunks of 64 spectrum entries (scaled on the way
+// in, next chunk prefetched into registers during the MFMAs).  Only the upper triangle of 16x16
+// output tiles is computed; the tiles are dealt round-robin to the four wavefronts, rotated by the
+// block index so that the SIMDs of a CU see the same load.
+template <int NTL>
+__global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* __restrict__ Gext, int KT) {
+    constexpr int ROWS = 16 * NTL, NTILES = NTL * (NTL + 1) / 2, MAXT = (NTILES + 3) / 4, RPT = ROWS / 4;
+    extern __shared__ double Ss[];  // [ROWS][SLD]
+    __shared__ int tile_ij[NTILES];
+    __shared__ const double* tail_ptr[CRM_MAX_COV_WIDE + 2];
     const int b = blockIdx.x;
     const NullFitOut fit = a.fit[b];
     const AssembleRho R = a.rho[fit.rho_index];
@@ -32,66 +43,146 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     const double ratio = fit.v0 / fit.v1;
     const long pos = a.sorted_pos[b];
     const double* __restrict__ Arows = a.A + pos * a.k0 * a.ldA;
-    const double* __restrict__ tg = R.T + (long)b * R.ldT;
     const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
     const int k0 = a.k0, c = a.c;
 
-    double acc[TS][TS];
+    if (tid < NTILES) {
+        int ti = 0, rem = tid;
+        while (rem >= NTL - ti) { rem -= NTL - ti; ti++; }
+        tile_ij[tid] = ti | ((ti + rem) << 8);
+    }
+    if (tid < c + 2) {
+        const double* p;
+        if (tid < c) p = R.tW + (long)tid * R.ldW;
+        else if (tid == c) p = R.T + (long)b * R.ldT;
+        else p = R.ty;
+        tail_ptr[tid] = p;
+    }
+    __syncthreads();
+    // tiles of this wavefront: idx = first, first + 4, ... (MAXT or MAXT - 1 of them)
+    const int first = (wave + b) & 3;
+    const int ntw = (NTILES - first + 3) / 4;
+    int t_i[MAXT], t_j[MAXT];
 #pragma unroll
-    for (int i = 0; i < TS; i++)
+    for (int t = 0; t < MAXT; t++) {
+        const int idx = first + 4 * t;
+        const int ij = tile_ij[idx < NTILES ? idx : 0];
+        t_i[t] = ((ij & 255) * 16 + l15) * SLD + lq;
+        t_j[t] = ((ij >> 8) * 16 + l15) * SLD + lq;
+    }
+    v4d acc[MAXT];
 #pragma unroll
-        for (int j = 0; j < TS; j++) acc[i][j] = 0.0;
+    for (int t = 0; t < MAXT; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    for (int c0 = 0; c0 < r; c0 += CH) {
-        if (tid < CH) {
-            const int j = c0 + tid;
-            double v = 0.0;
-            if (j < r) {
-                const double s = ratio * R.S0[j];
-                v = sqrt(s / (1.0 + s));
-            }
-            sd[tid] = v;
+    const int cc = lane;          // column of the chunk this thread stages
+    auto fetch = [&](int c0, double (&v)[RPT]) __attribute__((always_inline)) {
+        const int j = c0 + cc;
+        const bool okj = j < r;
+        double sdv = 0.0;
+        if (okj) {
+            const double s = ratio * R.S0[j];
+            sdv = sqrt(s / (1.0 + s));
         }
-        __syncthreads();
-        for (int e = tid; e < 16 * TS * CH; e += 256) {
-            const int row = e / CH, cc = e - row * CH;
-            const int j = c0 + cc;
-            double v = 0.0;
-            if (row < KT && j < r) {
-                if (row < k0) v = Arows[(long)row * a.ldA + j];
-                else if (row < k0 + c) v = R.tW[(long)(row - k0) * R.ldW + j];
-                else if (row == k0 + c) v = tg[j];
-                else v = R.ty[j];
-                v *= sd[cc];
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int row = wave + 4 * i;
+            double x = 0.0;
+            if (okj && row < KT) {
+                const double* __restrict__ p = row < k0 ? Arows + (long)row * a.ldA : tail_ptr[row - k0];
+                x = p[j];
             }
-            Ss[row][cc] = v;
+            v[i] = x * sdv;
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int cc = 0; cc < CH; cc++) {
-            double x[TS], y[TS];
+    };
+    auto stash = [&](const double (&v)[RPT]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < TS; i++) {
-                x[i] = Ss[ti + 16 * i][cc];
-                y[i] = Ss[tj + 16 * i][cc];
+        for (int i = 0; i < RPT; i++) Ss[(wave + 4 * i) * SLD + cc] = v[i];
+    };
+    // MFMAs of one staged chunk for NT tiles; operand fragments are read one k-step ahead
+    auto chunk_mma = [&](auto nt_tag) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_tag)::value;
+        if constexpr (NT > 0) {
+            double fa[2][NT], fb[2][NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                fa[0][t] = Ss[t_i[t]];
+                fb[0][t] = Ss[t_j[t]];
             }
 #pragma unroll
-            for (int i = 0; i < TS; i++)
+            for (int ks = 0; ks < CH / 4; ks++) {
+                const int cur = ks & 1, nx = cur ^ 1;
+                if (ks + 1 < CH / 4) {
 #pragma unroll
-                for (int j = 0; j < TS; j++) acc[i][j] += x[i] * y[j];
+                    for (int t = 0; t < NT; t++) {
+                        fa[nx][t] = Ss[t_i[t] + 4 * (ks + 1)];
+                        fb[nx][t] = Ss[t_j[t] + 4 * (ks + 1)];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][t], fb[cur][t], acc[t], 0, 0, 0);
+            }
         }
-        __syncthreads();
+    };
+
+    // chunk ch sits in LDS while chunk ch+1 (and, with DEEP, ch+2) are in registers / in flight: the
+    // kernel streams 8 (KT r) bytes per variant and needs the loads outstanding during the MFMAs
+    constexpr bool DEEP = false;  // measured: two chunks ahead costs occupancy (146 VGPRs) and gains nothing
+    const int nchunks = (r + CH - 1) / CH;
+    auto run_mma = [&]() __attribute__((always_inline)) {
+        if (ntw == MAXT) chunk_mma(std::integral_constant<int, MAXT>{});
+        else chunk_mma(std::integral_constant<int, MAXT - 1>{});
+    };
+    double bA[RPT], bB[DEEP ? RPT : 1];
+    fetch(0, bA);
+    stash(bA);
+    __syncthreads();
+    fetch(CH, bA);
+    if constexpr (DEEP) {
+        fetch(2 * CH, bB);
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            run_mma();
+            __syncthreads();
+            if (ch + 1 < nchunks) {
+                stash(bA);
+                __syncthreads();
+                fetch((ch + 3) * CH, bA);
+                run_mma();
+                __syncthreads();
+                if (ch + 2 < nchunks) {
+                    stash(bB);
+                    __syncthreads();
+                    fetch((ch + 4) * CH, bB);
+                }
+            }
+        }
+    } else {
+        for (int ch = 0; ch < nchunks; ch++) {
+            run_mma();
+            __syncthreads();
+            if (ch + 1 < nchunks) {
+                stash(bA);
+                __syncthreads();
+                fetch((ch + 2) * CH, bA);
+            }
+        }
     }
     double* __restrict__ out = Gext + (long)b * KT * KT;
 #pragma unroll
-    for (int i = 0; i < TS; i++) {
-        const int row = ti + 16 * i;
-        if (row >= KT) continue;
+    for (int t = 0; t < MAXT; t++) {
+        const int idx = first + 4 * t;
+        if (idx >= NTILES) continue;
+        const int ij = tile_ij[idx];
+        const int ri = (ij & 255) * 16, cj = (ij >> 8) * 16;
 #pragma unroll
-        for (int j = 0; j < TS; j++) {
-            const int col = tj + 16 * j;
-            if (col < KT) out[(long)row * KT + col] = acc[i][j];
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = ri + lq + 4 * reg, col = cj + l15;
+            if (row < KT && col < KT) {
+                out[(long)row * KT + col] = acc[t][reg];
+                if (ri != cj) out[(long)col * KT + row] = acc[t][reg];
+            }
         }
     }
 }
@@ -231,10 +322,19 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
         return CRM_ERR_UNSUPPORTED;
     }
     const int ts = (KT + 15) / 16;
-    if (ts <= 2) hipLaunchKernelGGL(gram_ext_kernel<2>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
-    else if (ts <= 4) hipLaunchKernelGGL(gram_ext_kernel<4>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
-    else if (ts <= 6) hipLaunchKernelGGL(gram_ext_kernel<6>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
-    else hipLaunchKernelGGL(gram_ext_kernel<9>, dim3(variants), dim3(256), 0, st, a, Gext, KT);
+#define CRM_GRAM(NTL)                                                                                         \
+    do {                                                                                                      \
+        const size_t lds = sizeof(double) * 16 * NTL * SLD;                                                   \
+        if (lds > 60 * 1024)                                                                                  \
+            CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_ext_kernel<NTL>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(gram_ext_kernel<NTL>, dim3(variants), dim3(256), lds, st, a, Gext, KT);            \
+    } while (0)
+    if (ts <= 2) CRM_GRAM(2);
+    else if (ts <= 4) CRM_GRAM(4);
+    else if (ts <= 6) CRM_GRAM(6);
+    else CRM_GRAM(9);
+#undef CRM_GRAM
     CRM_HIP(hipGetLastError());
     if (fin_lds > 60 * 1024)
         CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&finalize_kernel),
