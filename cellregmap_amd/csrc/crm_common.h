@@ -47,6 +47,15 @@ struct GemmProblem {
     int pad_;
 };
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an
+// XCD and its L2), so the workgroups of one residue class take a contiguous run of tile ids --
+// neighbouring row tiles (shared genotype cache lines) and one column tile of Q0 per XCD at a time.
+// Bijective for any grid size; affects speed / L2 traffic only.
+__device__ inline int xcd_tile_id(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 constexpr int GEMM_BM = 128;
 constexpr int GEMM_BN = 128;
 constexpr int GEMM_BK = 16;

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
                                                           long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
-    const int mtile = blockIdx.x % mtiles_max;
-    const int ntile = blockIdx.x / mtiles_max;
+    const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
+    const int mtile = tile % mtiles_max;
+    const int ntile = tile / mtiles_max;
     const int m0 = mtile * GEMM_BM;
     const int n0 = ntile * BN;
     constexpr int NT = BN / 32;          // 16-wide B fragments per wavefront (wave tile 64 x BN/2)

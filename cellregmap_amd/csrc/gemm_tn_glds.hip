@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     extern __shared__ __align__(16) double smem[];
     constexpr int BN = 128, NT = 4, LD = 128;
     const GemmProblem P = probs[blockIdx.z];
-    const int mtile = blockIdx.x % mtiles_max;
-    const int ntile = blockIdx.x / mtiles_max;
+    const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
+    const int mtile = tile % mtiles_max;
+    const int ntile = tile / mtiles_max;
     const int m0 = mtile * GEMM_BM;
     const int n0 = ntile * BN;
     if (m0 >= P.M || n0 >= P.N) return;
