@@ -117,6 +117,26 @@ def test_eigvalsh_batched(ctx, k):
         assert_allclose(lam[i], ref, rtol=0, atol=1e-13 * max(1.0, abs(ref).max()))
 
 
+def test_davies_on_the_published_as155_case(ctx):
+    """Q = 6 chi2_1 + 3 chi2_1 + chi2_1 (Imhof 1961 / Davies 1980, Table 1): P[Q < 7] = .4936,
+    P[Q < 20] = .8760; at x = 1 the reference's settings (lim 10000, acc 1e-6) run out of terms and the
+    modified-Liu value is returned instead."""
+    from cellregmap_amd import _lib
+    from oracle.davies import pvalue_from_weights
+
+    lib, h = ctx
+    lam = np.tile(np.array([1.0, 3.0, 6.0]), (3, 1))
+    Q = np.array([7.0, 20.0, 1.0])
+    pv = np.empty(3); ifault = np.empty(3, np.int32); liu = np.empty(3)
+    _lib.check(lib.crm_test_davies(h, 3, 3, _lib.ptr(Q), _lib.ptr(lam), _lib.ptr(pv), _lib.ptr(ifault), _lib.ptr(liu)))
+    assert abs(pv[0] - (1 - 0.4936)) < 1e-4 and abs(pv[1] - (1 - 0.8760)) < 1e-4
+    assert list(ifault) == [0, 0, 1]
+    p_ref, info = pvalue_from_weights(1.0, lam[2])
+    assert info["ifault"] == 1
+    assert_allclose(pv[2], p_ref, rtol=1e-8)
+    assert_allclose(pv[2], liu[2], rtol=0, atol=0)
+
+
 def test_davies_matches_oracle(ctx):
     from cellregmap_amd import _lib
     from oracle.davies import filter_weights, pvalue_from_weights
