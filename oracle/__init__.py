@@ -38,7 +38,9 @@ PARITY STATUS
   Davies p-value, so for these pieces: **parity unpinned** -- they are written
   from the published algorithms and checked against independent mathematics
   (dense REML likelihood, numerical Imhof integral, scipy distributions) and,
-  for ``qfc.c``, against the published table of AS 155 (Davies 1980, Table 1).
+  for ``qfc.c``, against the published table of AS 155 (Davies 1980, Table 1);
+  ``oracle.lmm`` also reproduces the worked examples of glimix-core's own
+  documentation (lml to 13 digits; values quoted from memory, no network).
   Only the Liu branch is pinned by the reference (test_math.py:76-83).  The
   effect-size functions of ``oracle.crm`` sit on ``oracle.lmm`` and share its
   status; ``compute_maf`` is pinned by the reference's doctest vector

@@ -114,3 +114,34 @@ def test_cov_solve_is_the_inverse_of_the_covariance():
         K = v0 * (Q0 * S0) @ Q0.T + v1 * np.eye(c.y.size)
         out = dev._cov_solve(bg, ri, v0, v1, rhs)
         np.testing.assert_allclose(K @ out, rhs, rtol=0, atol=1e-10)
+
+
+def test_lmm_fit_reproduces_the_documented_glimix_core_example():
+    """The ML fit of glimix-core's documentation example (see tests/test_oracle_lmm.py) through
+    crm_lmm_fit: lml to 1e-10, variances within the Brent tolerance, beta against the oracle."""
+    import ctypes
+
+    from cellregmap_amd import _engine, _lib
+    from oracle.lmm import LMM
+    from oracle.sugar import economic_qs_linear
+
+    G = np.array([[1, 2], [3, -1], [1.1, 0.5], [0.5, -0.4]], float)
+    y = np.array([-1, 2, 0.3, 0.5])
+    X = np.ones((4, 1))
+    lib = _lib.load()
+    bg = _engine._make_background(G, None, [1.0], 0, cache=False)
+    h = ctypes.c_void_p()
+    E0 = np.zeros((4, 1))
+    _lib.check(lib.crm_gene_create(bg.handle, _lib.ptr(y), _lib.ptr(X), 1, _lib.ptr(E0), 1, ctypes.byref(h)))
+    try:
+        fit = np.empty(6)
+        beta = np.empty(1)
+        _lib.check(lib.crm_lmm_fit(h, 0, _lib.ptr(fit), _lib.ptr(beta)))
+    finally:
+        lib.crm_gene_destroy(h)
+    assert abs(fit[3] - (-2.2726234086180557)) < 1e-10
+    np.testing.assert_allclose(fit[1], 0.33736446158226896, rtol=1e-6)
+    np.testing.assert_allclose(fit[2], 0.012503600451739165, rtol=1e-6)
+    ref = LMM(y, X, economic_qs_linear(G))
+    ref.fit(verbose=False)
+    np.testing.assert_allclose(beta, ref.beta, rtol=1e-6)

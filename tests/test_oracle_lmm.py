@@ -112,3 +112,21 @@ def test_polish_stays_within_the_reference_tolerance():
             h = 1e-5
             num = (b._neg_lml_at(x + h) - b._neg_lml_at(x - h)) / (2 * h)
             assert abs(num - b._neg_lml_grad_at(x)) < 1e-6 * (1 + abs(num))
+
+
+def test_documented_examples_of_glimix_core():
+    """Worked examples printed in glimix-core's own documentation (LMM class docstring / user guide,
+    version 3.1.x; quoted from memory -- the package is not installable here): ML fits on tiny data.
+    The log-likelihoods pin the model algebra to 13 digits; v0 / v1 carry the 1e-6 tolerance of the
+    Brent search on logit(delta)."""
+    X = np.array([[1, 2], [3, -1]], float)
+    lmm = LMM(np.array([-1, 2], float), np.ones((2, 1)), economic_qs_linear(X))
+    lmm.fit(verbose=False)
+    assert "%.3f" % lmm.lml() == "-3.649"
+
+    G = np.array([[1, 2], [3, -1], [1.1, 0.5], [0.5, -0.4]], float)
+    lmm = LMM(np.array([-1, 2, 0.3, 0.5]), np.ones((4, 1)), economic_qs_linear(G))
+    lmm.fit(verbose=False)
+    assert abs(lmm.lml() - (-2.2726234086180557)) < 1e-10
+    assert_allclose(lmm.v0, 0.33736446158226896, rtol=1e-6)
+    assert_allclose(lmm.v1, 0.012503600451739165, rtol=1e-6)
