@@ -101,3 +101,62 @@ def test_planted_effects_are_found(cfg2):
     assert np.all(pv[[10, 11]] < 1e-7)
     others = np.delete(pv, [10, 11])
     assert np.median(others) > 0.1
+
+
+def test_config3_block_headline_size():
+    """BASELINE config 3 (the bench workload: 20 000 cells x 50 contexts, mode C, r ~ 5 000) on one
+    block of variants: oracle spot check on the device's decompositions, dense path == donor-collapsed
+    path, affine invariance of the phenotype, and the factorisation behind it."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
+    from cellregmap_amd.synth import make_config
+    from oracle.crm import OracleCellRegMap
+
+    c = make_config("cfg3", n_variants=256)
+    n = c.y.size
+    Ls = get_L_values(c.hK, c.E)
+    crm = CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+    dense = GenotypePanel(c.G, groups=None)
+    pv, info, st = crm.scan_interaction(dense, return_stats=True)
+    assert np.all(np.isfinite(pv)) and np.all((pv > 0) & (pv <= 1))
+
+    # factorisation: Q0 S0 Q0' v == hS hS' v for one interior grid point, Q0 orthonormal
+    i = 6
+    rho = crm._rho1[i]
+    Q0, S0 = crm._bg.read(i, n)
+    v = np.random.default_rng(0).normal(size=(n, 2))
+    KE = c.E @ (c.E.T @ v)
+    u = Ls.us
+    lhs = rho * KE + (1 - rho) * sum(u[:, [j]] * (c.hK @ (c.hK.T @ (u[:, [j]] * v))) for j in range(u.shape[1]))
+    rhs = Q0 @ (S0[:, None] * (Q0.T @ v))
+    assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
+    G = Q0.T @ Q0
+    assert np.abs(G - np.eye(G.shape[0])).max() < 1e-11
+
+    # oracle on three variants, sharing the device's (Q0, S0)
+    qs = {crm._rho1[i]: ((Q0,), S0)}
+    for j, r in enumerate(crm._rho1):
+        if j != i:
+            q, s = crm._bg.read(j, n)
+            qs[r] = ((q,), s)
+    o = OracleCellRegMap.__new__(OracleCellRegMap)
+    o._polish = False
+    o._y, o._E0, o._W, o._E1 = c.y, c.E, c.W, c.E
+    o._Ls, o._rho, o._half, o._qs = Ls, list(crm._rho1), {}, qs
+    pick = [0, 101, 255]
+    opv, oinfo, ost = o.scan_interaction(c.G[:, pick], return_stats=True)
+    assert_allclose(info["rho1"][pick], oinfo["rho1"], atol=1e-12)
+    assert_allclose(st["Q"][pick], ost["Q"], rtol=1e-6)
+    assert np.all(np.abs(pv[pick] - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv[pick], opv]
+    del qs, o
+
+    # donor-collapsed path
+    pv_c, info_c, st_c = crm.scan_interaction(GenotypePanel(c.G), return_stats=True)
+    assert_allclose(info_c["rho1"], info["rho1"], atol=1e-12)
+    assert_allclose(st_c["Q"], st["Q"], rtol=5e-6)
+    assert np.all(np.abs(pv_c - pv) <= P_RTOL * pv + P_ATOL)
+
+    # y -> a y + b on the same background
+    crm2 = CellRegMap(2.5 * c.y + 3.0, c.E, W=c.W, Ls=Ls, background=crm._bg)
+    pv2, info2, st2 = crm2.scan_interaction(dense, return_stats=True)
+    assert_allclose(info2["rho1"], info["rho1"], atol=1e-12)
+    assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
