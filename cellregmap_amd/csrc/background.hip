@@ -15,6 +15,9 @@
 //   eigenvalues below sqrt(machine eps) are dropped, exactly as _math.py:204-235 does.
 #include <rocsolver/rocsolver.h>
 
+#include <chrono>
+#include <thread>
+
 #include <algorithm>
 
 #include "nullfit.h"
@@ -169,22 +172,27 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     if (rel_tol <= 0.0) rel_tol = 1e-12;
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    const bool trace = getenv("CRM_TRACE_SETUP") != nullptr;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[crm background] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_mark).count());
+        t_mark = now;
+    };
     const long cols = k1 + kb;
     const long np = round_up(n, CELL_PAD);
     const long cp = round_up(cols, 128);
     const bool thin = n > cols;  // economic_qs_linear: rows > cols -> SVD branch
 
-    rocblas_handle hnd;
-    CRM_ROC(rocblas_create_handle(&hnd));
     struct HandleGuard {
         rocblas_handle h;
         ~HandleGuard() { rocblas_destroy_handle(h); }
-    } guard{hnd};
-    CRM_ROC(rocblas_set_stream(hnd, st));
+    };
 
     Scratch S;
-    DevBuf &dH = S.bufs[0], &dHt = S.bufs[1], &dC = S.bufs[2], &dCr = S.bufs[3], &dW = S.bufs[4],
-           &dE = S.bufs[5], &dInfo = S.bufs[6], &dKeep = S.bufs[7], &dMt = S.bufs[9],
+    DevBuf &dH = S.bufs[0], &dHt = S.bufs[1], &dC = S.bufs[2], &dMt = S.bufs[9],
            &dG = S.bufs[10], &dErr = S.bufs[11], &dQt = S.bufs[12];
     // H = [E1, B] (cells x cols) and its transpose
     CRM_TRY(dH.ensure(sizeof(double) * np * cp));
@@ -234,13 +242,6 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
 
     const long dim = thin ? cols : n;       // order of the matrix that gets diagonalised
     const long dimp = round_up(dim, 128);
-    CRM_BG(dCr.ensure(sizeof(double) * dimp * dimp));
-    CRM_BG(dW.ensure(sizeof(double) * dimp));
-    CRM_BG(dE.ensure(sizeof(double) * dimp));
-    CRM_BG(dInfo.ensure(sizeof(int) * 4));
-    CRM_BG(dKeep.ensure(sizeof(int) * dimp));
-    std::vector<double> hW(dim);
-    std::vector<int> keep;
     std::vector<std::vector<double>> S0_host(nrho);
 
     if (thin) {
@@ -275,39 +276,59 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         ~MGuard() { for (auto& b : v) b.release(); }
     } mguard{Mbuf};
     long rmax = 1;
-    for (int i = 0; i < nrho; i++) {
+    // One host thread per grid point, each with its own stream, solver handle and work matrix: a
+    // dsyevd call is a long chain of small kernels (tridiagonalisation panels), launch-bound on one
+    // stream; the chains of the grid points are independent and overlap on the device.
+    auto decompose = [&](int i) -> int {
+        CRM_HIP(hipSetDevice(ctx->device));
+        hipStream_t ws;
+        CRM_HIP(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
+        struct StreamGuard {
+            hipStream_t s;
+            ~StreamGuard() { (void)hipStreamDestroy(s); }
+        } sguard{ws};
+        rocblas_handle wh;
+        CRM_ROC(rocblas_create_handle(&wh));
+        HandleGuard hguard{wh};
+        CRM_ROC(rocblas_set_stream(wh, ws));
+        ScopedBuf wCr, wW, wE, wInfo, wKeep;
+        CRM_TRY(wCr.ensure(sizeof(double) * dimp * dimp));
+        CRM_TRY(wW.ensure(sizeof(double) * dimp));
+        CRM_TRY(wE.ensure(sizeof(double) * dimp));
+        CRM_TRY(wInfo.ensure(sizeof(int) * 4));
+        CRM_TRY(wKeep.ensure(sizeof(int) * dimp));
+        std::vector<double> hW(dim);
+        std::vector<int> keep;
         const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
-        bg->rho[i] = rho[i];
         if (thin) {
             dim3 grid((unsigned)((cols + 255) / 256), (unsigned)cols);
-            hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)cols, k1,
-                               a, b, dCr.as<double>(), dimp);
+            hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, ws, dC.as<double>(), cp, (int)cols, k1,
+                               a, b, wCr.as<double>(), dimp);
         } else {
             // Sigma(rho) = rho E1 E1' + (1 - rho) B B'
             dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
-            hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, st, dG.as<double>(),
+            hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, ws, dG.as<double>(),
                                dG.as<double>() + dimp * dimp, dimp, (int)n, rho[i], 1.0 - rho[i],
-                               dCr.as<double>());
+                               wCr.as<double>());
         }
-        CRM_BG_HIP(hipGetLastError());
-        // symmetric eigen-decomposition: eigenvalues ascending in dW, eigenvectors as columns
-        // (column-major) of dCr
-        rocblas_status rs = rocsolver_dsyevd(hnd, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)dim,
-                                             dCr.as<double>(), (rocblas_int)dimp, dW.as<double>(),
-                                             dE.as<double>(), dInfo.as<int>());
+        CRM_HIP(hipGetLastError());
+        // symmetric eigen-decomposition: eigenvalues ascending in wW, eigenvectors as columns
+        // (column-major) of wCr
+        rocblas_status rs = rocsolver_dsyevd(wh, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)dim,
+                                             wCr.as<double>(), (rocblas_int)dimp, wW.as<double>(),
+                                             wE.as<double>(), wInfo.as<int>());
         if (rs != rocblas_status_success) {
             set_error("rocsolver_dsyevd failed with status %d", (int)rs);
-            return fail(CRM_ERR_HIP);
+            return CRM_ERR_HIP;
         }
         int info = 0;
-        CRM_BG_HIP(hipMemcpyAsync(hW.data(), dW.ptr, sizeof(double) * dim, hipMemcpyDeviceToHost, st));
-        CRM_BG_HIP(hipMemcpyAsync(&info, dInfo.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
-        CRM_BG_HIP(hipStreamSynchronize(st));
+        CRM_HIP(hipMemcpyAsync(hW.data(), wW.ptr, sizeof(double) * dim, hipMemcpyDeviceToHost, ws));
+        CRM_HIP(hipMemcpyAsync(&info, wInfo.ptr, sizeof(int), hipMemcpyDeviceToHost, ws));
+        CRM_HIP(hipStreamSynchronize(ws));
         if (info != 0) {
             set_error("background: eigen-decomposition did not converge at rho=%g (info %d)", rho[i], info);
-            return fail(CRM_ERR_NUMERIC);
+            return CRM_ERR_NUMERIC;
         }
-        keep.clear();
         if (thin) {
             const double cut = rel_tol * std::max(hW[dim - 1], 0.0);
             for (long j = dim - 1; j >= 0; j--)  // descending, like singular values
@@ -319,36 +340,58 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         }
         const int r = (int)keep.size();
         bg->r[i] = r;
-        rmax = std::max<long>(rmax, r);
         S0_host[i].resize(r);
         for (int j = 0; j < r; j++) S0_host[i][j] = hW[keep[j]];
         // keep what pass 2 needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
         const long ldm = round_up(std::max(r, 1), 128);
-        CRM_BG(Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
-        CRM_BG_HIP(hipMemsetAsync(Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
+        CRM_TRY(Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
+        CRM_HIP(hipMemsetAsync(Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, ws));
         if (r > 0) {
-            CRM_BG_HIP(hipMemcpyAsync(dKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
+            CRM_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, ws));
             if (thin) {
                 dim3 grid((unsigned)((r + 255) / 256), (unsigned)cols);
-                hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, st, dCr.as<double>(), dimp,
-                                   dW.as<double>(), dKeep.as<int>(), r, (int)cols, k1, a, b,
+                hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, ws, wCr.as<double>(), dimp,
+                                   wW.as<double>(), wKeep.as<int>(), r, (int)cols, k1, a, b,
                                    Mbuf[i].as<double>(), ldm);
             } else {
                 dim3 grid((unsigned)((r + 255) / 256), (unsigned)n);
-                hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, st, dCr.as<double>(), dimp,
-                                   dKeep.as<int>(), r, n, Mbuf[i].as<double>(), ldm);
+                hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, ws, wCr.as<double>(), dimp,
+                                   wKeep.as<int>(), r, n, Mbuf[i].as<double>(), ldm);
             }
-            CRM_BG_HIP(hipGetLastError());
+            CRM_HIP(hipGetLastError());
         }
-        CRM_BG_HIP(hipStreamSynchronize(st));
+        CRM_HIP(hipStreamSynchronize(ws));
+        return CRM_OK;
+    };
+    CRM_BG_HIP(hipStreamSynchronize(st));  // the Gram matrices the workers read
+    lap("half factor + Gram");
+    {
+        std::vector<int> rcs(nrho, CRM_OK);
+        std::vector<std::string> errs(nrho);
+        std::vector<std::thread> workers;
+        for (int i = 0; i < nrho; i++) {
+            bg->rho[i] = rho[i];
+            workers.emplace_back([&, i]() {
+                rcs[i] = decompose(i);
+                if (rcs[i] != CRM_OK) errs[i] = last_error_text();
+            });
+        }
+        for (auto& w : workers) w.join();
+        for (int i = 0; i < nrho; i++) {
+            if (rcs[i] != CRM_OK) {
+                set_error("%s", errs[i].c_str());
+                return fail(rcs[i]);
+            }
+            rmax = std::max<long>(rmax, bg->r[i]);
+        }
     }
+    lap("eigen-decompositions");
     // pass 2: Q0 buffers with the common leading dimension
     bg->ldq = round_up(rmax, 128);
     const long ldq = bg->ldq;
     dG.release();
     dMt.release();
     dC.release();
-    dCr.release();
     if (thin) {
         // keep the half factor: T(rho) = Q0(rho)'G is later taken as Mix(rho)' (H'G), see scan.hip
         bg->H = dH;
@@ -424,6 +467,7 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         }
     }
     CRM_BG_HIP(hipStreamSynchronize(st));
+    lap("Q0 = H Mix + polish");
     // the mixing-matrix route amplifies rounding by sqrt(S_max / S_min): use it only for spectra
     // whose kept part is well conditioned
     bg->fast_T = thin;
