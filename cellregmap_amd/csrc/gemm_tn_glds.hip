@@ -10,6 +10,7 @@
 // are swapped, and fragment reads apply the same XOR (column ^ 16 doubles on odd rows).  Consecutive
 // rows read by the two 16-lane halves of a ds_read_b64 group then fall on disjoint banks.
 #include <algorithm>
+#include <type_traits>
 
 #include "crm_common.h"
 
@@ -18,6 +19,18 @@ namespace crm {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) * gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef const double __attribute__((address_space(3))) * lcptr_t;
+
+// a wave-uniform global pointer pinned to scalar registers (keeps `base + lane offset` in the
+// saddr + voffset form of the load instead of a per-lane 64-bit add)
+typedef const char __attribute__((address_space(1))) * gbptr_t;
+__device__ inline gptr_t at_bytes(gptr_t base, unsigned byte_off) { return (gptr_t)((gbptr_t)base + byte_off); }
+__device__ inline gptr_t scalar_ptr(gptr_t p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gptr_t)(((unsigned long)hi << 32) | lo);
+}
 
 __host__ __device__ inline int glds_kr_variants(int k0) {
     int nb = GEMM_BM / k0 + 2;
@@ -25,14 +38,30 @@ __host__ __device__ inline int glds_kr_variants(int k0) {
 }
 
 // ECQ: context columns staged per row in units of 32 (round_up(k0, 32) / 32); 0 for the plain kernel
+// KRQ: 1 when at most 16 genotype columns are staged per row (k0 >= 10), else the 128-column form
 // TR:  store the transpose, C'[n][m] (ldc = row length of C'): the MFMA operands swap roles, so the
 //      accumulator tiles come out transposed and the stores stay 128-byte contiguous
+//
+// Instruction-level layout of the main loop: every fragment read is `ds_read_b64 v, vbase offset:imm` off
+// twelve per-lane base addresses that are only XOR-flipped between the two LDS buffers once per stage
+// (no address arithmetic per k-step), and the
+// reads / operand products of the next k-step are spread between the sixteen MFMAs of the current one
+// (sched_group_barrier), so that one wavefront alone keeps the matrix pipe fed: two wavefronts running
+// the same instruction stream fall into step, and clustered non-MFMA sections then idle the pipe in both.
+template <int KRQ>
+struct GldsGeno {
+    static constexpr int LD = KRQ == 1 ? 16 : 128;  // LDS row length of the staged genotype columns
+};
+
 template <bool KR, int KRQ, int ECQ, bool TR = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
                                                                int mtiles_max, long cells_per_split,
                                                                long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     constexpr int BN = 128, NT = 4, LD = 128;
+    constexpr int EC = 32 * ECQ;                        // context columns staged per row
+    constexpr int GLD = GldsGeno<KRQ>::LD;
+    constexpr int KS = GEMM_BK / 4;
     const GemmProblem P = probs[blockIdx.z];
     const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
     const int mtile = tile % mtiles_max;
@@ -43,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
     const long cell_begin = (long)blockIdx.y * cells_per_split;
@@ -51,11 +80,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
 
     // ---- LDS carve-up ------------------------------------------------------------------------
     const int nb = KR ? glds_kr_variants(k0) : 0;
-    constexpr int EC = 32 * ECQ;                        // context columns staged per row
-    double* Ys = smem;                                  // [2][BK][128]
-    double* Xs = Ys + 2 * GEMM_BK * LD;                 // plain: [2][BK][128]
-    double* Es = Xs;                                    // KR: [2][BK][EC]
-    double* Gs = Es + 2 * GEMM_BK * EC;                 // KR: [2][BK][nb]
+    double* const Ys = smem;                            // [2][BK][128]
+    double* const Xs = Ys + 2 * GEMM_BK * LD;           // plain: [2][BK][128]
+    double* const Es = Xs;                              // KR: [2][BK][EC]
+    double* const Gs = Es + 2 * GEMM_BK * EC;           // KR: [2][BK][GLD]
     const int b0 = KR ? (m0 / k0) : 0;
 
     gptr_t Yg = (gptr_t)P.Y + cell_begin * P.ldy + n0;
@@ -63,79 +91,118 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     gptr_t Eg = KR ? (gptr_t)P.E + cell_begin * P.lde : nullptr;
     double rg[KRQ];
 
-    // LDS-DMA of stage s into buffer `buf`: each wavefront issues the rows / pieces w, w+4, ...
-    auto issue = [&](int s, int buf) {
+    // LDS-DMA of stage s into buffer BUF: each wavefront issues the rows / pieces w, w+4, ...
+    // Every global address is a wave-uniform 64-bit base (advanced on the scalar unit) plus a per-lane
+    // 32-bit offset fixed before the loop -- the `saddr + voffset` form, no vector arithmetic per stage.
+    const unsigned y_lane = 8u * (unsigned)((lane ^ ((wave & 1) << 3)) * 2);  // bytes; source granule swap on odd rows
+    constexpr int ECN = ECQ > 0 ? ECQ : 1;
+    unsigned e_lane[ECN];
+    unsigned g_lane[KRQ];
+    bool g_on[KRQ];
+    if (KR) {
+        constexpr int ppr = EC > 0 ? EC / 2 : 1;  // 16-byte pieces per row
+#pragma unroll
+        for (int q = 0; q < ECQ; q++) {
+            const int p = (wave + 4 * q) * 64 + lane;
+            const int r = p / ppr, g = p - r * ppr;
+            e_lane[q] = 8u * (unsigned)(r * (int)P.lde + ((g ^ ((r & 1) << 3)) << 1));
+        }
+#pragma unroll
+        for (int q = 0; q < KRQ; q++) {
+            const int e = tid + 256 * q;
+            const int row = e / GLD, col = e - row * GLD;
+            g_on[q] = col < nb;
+            g_lane[q] = 8u * (unsigned)(row * (int)P.ldx + (g_on[q] ? col : 0));
+        }
+    }
+    auto issue = [&](int BUF, int s) __attribute__((always_inline)) {
         const long roff = (long)s * GEMM_BK;
 #pragma unroll
         for (int q = 0; q < GEMM_BK / 4; q++) {
             const int r = wave + 4 * q;
-            const int gsw = (lane ^ ((r & 1) << 3)) * 2;  // source granule swap on odd rows
-            __builtin_amdgcn_global_load_lds(Yg + (roff + r) * P.ldy + gsw,
-                                             (lptr_t)(Ys + (buf * GEMM_BK + r) * LD), 16, 0, 0);
-            if (!KR)
-                __builtin_amdgcn_global_load_lds(Xg + (roff + r) * P.ldx + gsw,
-                                                 (lptr_t)(Xs + (buf * GEMM_BK + r) * LD), 16, 0, 0);
+            gptr_t yrow = scalar_ptr(Yg + (roff + r) * P.ldy);
+            __builtin_amdgcn_global_load_lds(at_bytes(yrow, y_lane), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
+            if (!KR) {
+                gptr_t xrow = scalar_ptr(Xg + (roff + r) * P.ldx);
+                __builtin_amdgcn_global_load_lds(at_bytes(xrow, y_lane), (lptr_t)(Xs + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
+            }
         }
         if (KR) {
-            constexpr int ppr = EC / 2;  // 16-byte pieces per row
+            gptr_t erow = scalar_ptr(Eg + roff * P.lde);
+            gptr_t grow = scalar_ptr(Xg + roff * P.ldx);
 #pragma unroll
-            for (int q = 0; q < ECQ; q++) {       // EC/8 wave-instructions, ECQ per wavefront
-                const int ii = wave + 4 * q;
-                const int p = ii * 64 + lane;
-                const int r = p / ppr, g = p - r * ppr;
-                __builtin_amdgcn_global_load_lds(Eg + (roff + r) * P.lde + ((g ^ ((r & 1) << 3)) << 1),
-                                                 (lptr_t)(Es + buf * GEMM_BK * EC + ii * 128), 16, 0, 0);
+            for (int q = 0; q < ECQ; q++) {        // EC/8 wave-instructions, ECQ per wavefront
+                const unsigned eoffq = e_lane[q];
+                __builtin_amdgcn_global_load_lds(at_bytes(erow, eoffq),
+                                                 (lptr_t)(Es + BUF * GEMM_BK * EC + (wave + 4 * q) * 128), 16, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < KRQ; q++) {
-                const int e = tid + 256 * q;
-                const int row = e / nb, col = e - row * nb;
-                if (row < GEMM_BK) rg[q] = Xg[(roff + row) * P.ldx + col];
-            }
+            for (int q = 0; q < KRQ; q++) rg[q] = *at_bytes(grow, g_lane[q]);
         }
     };
-    auto stash_g = [&](int buf) {
+    auto stash_g = [&](int BUF) __attribute__((always_inline)) {
         if (KR) {
 #pragma unroll
-            for (int q = 0; q < KRQ; q++) {
-                const int e = tid + 256 * q;
-                if (e < GEMM_BK * nb) Gs[buf * GEMM_BK * nb + e] = rg[q];
-            }
+            for (int q = 0; q < KRQ; q++) Gs[BUF * GEMM_BK * GLD + tid + 256 * q] = g_on[q] ? rg[q] : 0.0;
         }
     };
 
-    // ---- per-lane fragment addressing ------------------------------------------------------------
-    int xa[4], xg[4], xe[4];
+    // ---- per-lane fragment base offsets (doubles; buffer 0, k-step 0) --------------------------
+    const int sw = (lq & 1) << 4;  // rows ks*4 + lq: parity of the row = parity of lq
+    // LDS byte addresses (segment and region bases folded in)
+    const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+    const unsigned XS_BASE = lds0 + 8u * 2 * GEMM_BK * LD, GS_BASE = XS_BASE + 8u * 2 * GEMM_BK * EC;
+    unsigned yo[NT], xo[4], go[4], eo[4];
+#pragma unroll
+    for (int t = 0; t < NT; t++) yo[t] = lds0 + 8u * (lq * LD + ((wn * 64 + l15 + t * 16) ^ sw));
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int mloc = wm * 64 + t * 16 + l15;
-        xa[t] = mloc;
+        xo[t] = XS_BASE + 8u * (lq * LD + (mloc ^ sw));
+        go[t] = 0;
+        eo[t] = 0;
         if (KR) {
             const int m = m0 + mloc;
             const int b = m / k0;
             const int bl = b - b0;
-            xg[t] = bl < nb ? bl : nb - 1;
-            xe[t] = m - b * k0;
+            go[t] = GS_BASE + 8u * (lq * GLD + (bl < nb ? bl : nb - 1));
+            eo[t] = XS_BASE + 8u * (lq * EC + ((m - b * k0) ^ sw));
         }
     }
-    const int yb = wn * 64 + l15;
+    auto lds_at = [](unsigned addr, int imm_doubles) __attribute__((always_inline)) {
+        return ((lcptr_t)(unsigned long)addr)[imm_doubles];
+    };
 
-    auto load_raw = [&](int buf, int ks, double (&a)[4], double (&e)[4], double (&b)[NT]) {
-        const int row = buf * GEMM_BK + ks * 4 + lq;
-        const int sw = (lq & 1) << 4;  // rows ks*4 + lq: parity of the row = parity of lq
-#pragma unroll
-        for (int t = 0; t < NT; t++) b[t] = Ys[row * LD + ((yb + t * 16) ^ sw)];
+    // (the offsets address the buffer being computed on; `flip` moves them to the other one)
+    auto flip = [&](int from_buf) __attribute__((always_inline)) {
+        const int sgn = from_buf ? -1 : 1;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
+            yo[t] += sgn * 8 * GEMM_BK * LD;
             if (KR) {
-                a[t] = Gs[row * nb + xg[t]];
-                e[t] = Es[row * EC + (xe[t] ^ sw)];
+                go[t] += sgn * 8 * GEMM_BK * GLD;
+                eo[t] += sgn * 8 * GEMM_BK * EC;
             } else {
-                a[t] = Xs[row * LD + (xa[t] ^ sw)];
+                xo[t] += sgn * 8 * GEMM_BK * LD;
             }
         }
     };
-    auto finish = [&](double (&a)[4], const double (&e)[4]) {
+    auto load_raw = [&](auto ks_tag, double (&a)[4], double (&e)[4], double (&b)[NT])
+                        __attribute__((always_inline)) {
+        constexpr int R0 = decltype(ks_tag)::value * 4;
+#pragma unroll
+        for (int t = 0; t < NT; t++) b[t] = lds_at(yo[t], R0 * LD);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (KR) {
+                a[t] = lds_at(go[t], R0 * GLD);
+                e[t] = lds_at(eo[t], R0 * EC);
+            } else {
+                a[t] = lds_at(xo[t], R0 * LD);
+            }
+        }
+    };
+    auto finish = [&](double (&a)[4], const double (&e)[4]) __attribute__((always_inline)) {
         if (KR) {
 #pragma unroll
             for (int t = 0; t < 4; t++) a[t] *= e[t];
@@ -147,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    auto mma = [&](const double (&a)[4], const double (&b)[NT]) {
+    auto mma = [&](const double (&a)[4], const double (&b)[NT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -155,34 +222,103 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
                 acc[i][j] = TR ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0)
                                : __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     };
+    // issue order of one k-step: the 8 (plain) / 12 (KR) fragment reads of the next k-step behind the
+    // first MFMAs, two per MFMA; the operand products behind the last four
+    auto interleave = [&]() __attribute__((always_inline)) {
+#ifndef CRM_ILV
+#define CRM_ILV 1
+#endif
+        constexpr int READS = KR ? 12 : 8;
+        if (CRM_ILV == 1) {
+#pragma unroll
+            for (int i = 0; i < READS / 2; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 - READS / 2 - (KR ? 4 : 0), 0);
+            if (KR) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            }
+        } else if (CRM_ILV == 2) {
+            // one read per MFMA, products behind the last four
+#pragma unroll
+            for (int i = 0; i < READS; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (KR) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 16 - READS, 0);
+            }
+        } else if (CRM_ILV == 3) {
+            // reads first (all in the shadow of the first four MFMAs), products spread
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, READS / 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (KR) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+        }
+    };
 
-    constexpr int KS = GEMM_BK / 4;
     double fa[2][4], fb[2][NT], fe[4];
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    static_assert(KS == 4, "the stage body is written out for four k-steps");
     issue(0, 0);
     stash_g(0);
     __syncthreads();  // drains the LDS-DMA (vmcnt) and publishes the tiles
-    load_raw(0, 0, fa[0], fe, fb[0]);
+    load_raw(K0{}, fa[0], fe, fb[0]);
     finish(fa[0], fe);
 
+    // one stage per trip; the fragments of its k-step 0 are in fa[0] / fb[0] on entry, those of the next
+    // stage's k-step 0 on exit
     for (int s = 0; s < stages; s++) {
         const int buf = s & 1;
         const bool more = s + 1 < stages;
         // buffer buf^1 was last read before the barrier of the previous stage: free for the DMA now
-        if (more) issue(s + 1, buf ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            const bool have_next = ks + 1 < KS || more;
-            if (ks + 1 < KS) {
-                load_raw(buf, ks + 1, fa[nxt], fe, fb[nxt]);
-            } else {
-                if (more) stash_g(buf ^ 1);
-                __syncthreads();
-                if (more) load_raw(buf ^ 1, 0, fa[nxt], fe, fb[nxt]);
-            }
-            mma(fa[cur], fb[cur]);
-            if (have_next) finish(fa[nxt], fe);
-        }
+        if (more) issue(buf ^ 1, s + 1);
+        load_raw(K1{}, fa[1], fe, fb[1]);
+        mma(fa[0], fb[0]);
+        finish(fa[1], fe);
+        interleave();
+        load_raw(K2{}, fa[0], fe, fb[0]);
+        mma(fa[1], fb[1]);
+        finish(fa[0], fe);
+        interleave();
+        load_raw(K3{}, fa[1], fe, fb[1]);
+        mma(fa[0], fb[0]);
+        finish(fa[1], fe);
+        interleave();
+        // every read of this buffer has been issued; the next stage's tiles must have landed
+        if (more) stash_g(buf ^ 1);
+        flip(buf);
+        __syncthreads();
+        // (after the last stage these reads fetch stale tiles of the other buffer; nothing uses them)
+        load_raw(K0{}, fa[0], fe, fb[0]);
+        mma(fa[1], fb[1]);
+        finish(fa[0], fe);
+        interleave();
     }
 
     double* Cb = P.C + (long)blockIdx.y * split_stride;
@@ -230,9 +366,9 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
     if (khatri_rao) {
         const int EC = (k0 + 31) / 32 * 32;
         const int nb = glds_kr_variants(k0);
-        lds += (size_t)2 * GEMM_BK * (EC + nb) * sizeof(double);
         constexpr int KRQ_BIG = (GEMM_BK * GEMM_BM + 255) / 256;
-        const bool small = GEMM_BK * nb <= 256;
+        const bool small = nb <= GldsGeno<1>::LD;
+        lds += (size_t)2 * GEMM_BK * (EC + (small ? GldsGeno<1>::LD : GldsGeno<KRQ_BIG>::LD)) * sizeof(double);
 #define CRM_GLDS_T(Q, T)                                                                                      \
     do {                                                                                                      \
         if (small)                                                                                            \
