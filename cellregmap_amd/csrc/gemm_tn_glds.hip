@@ -42,9 +42,13 @@ __host__ __device__ inline int glds_kr_variants(int k0) {
 // TR:  store the transpose, C'[n][m] (ldc = row length of C'): the MFMA operands swap roles, so the
 //      accumulator tiles come out transposed and the stores stay 128-byte contiguous
 //
-// Instruction-level layout of the main loop: every fragment read is `ds_read_b64 v, vbase offset:imm` off
-// twelve per-lane base addresses that are only XOR-flipped between the two LDS buffers once per stage
-// (no address arithmetic per k-step), and the
+// Instruction-level layout of the main loop.  rocprofv3 shows SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this
+// kernel: an FP64 MFMA and a vector-ALU instruction never overlap, so every VALU instruction in the loop
+// is taken out of the matrix pipe's time.  Hence: the stage loop is unrolled by two so that the LDS
+// buffer index is a compile-time constant and every fragment read is `ds_read_b64 v, vbase offset:imm`
+// off twelve loop-invariant per-lane bases; the global side uses wave-uniform bases advanced on the
+// scalar unit plus loop-invariant 32-bit lane offsets (`saddr + voffset`); what is left per stage of 64
+// MFMAs is the sixteen Khatri-Rao operand products.  The
 // reads / operand products of the next k-step are spread between the sixteen MFMAs of the current one
 // (sched_group_barrier), so that one wavefront alone keeps the matrix pipe fed: two wavefronts running
 // the same instruction stream fall into step, and clustered non-MFMA sections then idle the pipe in both.
@@ -117,14 +121,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     }
     auto issue = [&](int BUF, int s) __attribute__((always_inline)) {
         const long roff = (long)s * GEMM_BK;
+        // (re-defined inside the loop body so that the zero-extension stays next to the load and the
+        // instruction selector can fold it into the voffset operand)
+        unsigned yl = y_lane;
+        asm volatile("" : "+v"(yl));
 #pragma unroll
         for (int q = 0; q < GEMM_BK / 4; q++) {
             const int r = wave + 4 * q;
             gptr_t yrow = scalar_ptr(Yg + (roff + r) * P.ldy);
-            __builtin_amdgcn_global_load_lds(at_bytes(yrow, y_lane), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(at_bytes(yrow, yl), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
             if (!KR) {
                 gptr_t xrow = scalar_ptr(Xg + (roff + r) * P.ldx);
-                __builtin_amdgcn_global_load_lds(at_bytes(xrow, y_lane), (lptr_t)(Xs + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(at_bytes(xrow, yl), (lptr_t)(Xs + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
             }
         }
         if (KR) {
@@ -132,18 +140,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
             gptr_t grow = scalar_ptr(Xg + roff * P.ldx);
 #pragma unroll
             for (int q = 0; q < ECQ; q++) {        // EC/8 wave-instructions, ECQ per wavefront
-                const unsigned eoffq = e_lane[q];
+                unsigned eoffq = e_lane[q];
+                asm volatile("" : "+v"(eoffq));
                 __builtin_amdgcn_global_load_lds(at_bytes(erow, eoffq),
                                                  (lptr_t)(Es + BUF * GEMM_BK * EC + (wave + 4 * q) * 128), 16, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < KRQ; q++) rg[q] = *at_bytes(grow, g_lane[q]);
+            for (int q = 0; q < KRQ; q++) {
+                unsigned goffq = g_lane[q];
+                asm volatile("" : "+v"(goffq));
+                rg[q] = *at_bytes(grow, goffq);
+            }
         }
     };
     auto stash_g = [&](int BUF) __attribute__((always_inline)) {
         if (KR) {
 #pragma unroll
-            for (int q = 0; q < KRQ; q++) Gs[BUF * GEMM_BK * GLD + tid + 256 * q] = g_on[q] ? rg[q] : 0.0;
+            for (int q = 0; q < KRQ; q++) Gs[BUF * GEMM_BK * GLD + tid + 256 * q] = rg[q];  // (columns >= nb hold column 0; never read)
         }
     };
 
@@ -173,23 +186,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         return ((lcptr_t)(unsigned long)addr)[imm_doubles];
     };
 
-    // (the offsets address the buffer being computed on; `flip` moves them to the other one)
-    auto flip = [&](int from_buf) __attribute__((always_inline)) {
-        const int sgn = from_buf ? -1 : 1;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            yo[t] += sgn * 8 * GEMM_BK * LD;
-            if (KR) {
-                go[t] += sgn * 8 * GEMM_BK * GLD;
-                eo[t] += sgn * 8 * GEMM_BK * EC;
-            } else {
-                xo[t] += sgn * 8 * GEMM_BK * LD;
-            }
-        }
-    };
-    auto load_raw = [&](auto ks_tag, double (&a)[4], double (&e)[4], double (&b)[NT])
+    auto load_raw = [&](auto buf_tag, auto ks_tag, double (&a)[4], double (&e)[4], double (&b)[NT])
                         __attribute__((always_inline)) {
-        constexpr int R0 = decltype(ks_tag)::value * 4;
+        constexpr int R0 = decltype(buf_tag)::value * GEMM_BK + decltype(ks_tag)::value * 4;
 #pragma unroll
         for (int t = 0; t < NT; t++) b[t] = lds_at(yo[t], R0 * LD);
 #pragma unroll
@@ -203,6 +202,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         }
     };
     auto finish = [&](double (&a)[4], const double (&e)[4]) __attribute__((always_inline)) {
+#ifdef CRM_EXP_NOMUL
+        return;
+#endif
         if (KR) {
 #pragma unroll
             for (int t = 0; t < 4; t++) a[t] *= e[t];
@@ -288,38 +290,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     issue(0, 0);
     stash_g(0);
     __syncthreads();  // drains the LDS-DMA (vmcnt) and publishes the tiles
-    load_raw(K0{}, fa[0], fe, fb[0]);
+    load_raw(K0{}, K0{}, fa[0], fe, fb[0]);
     finish(fa[0], fe);
 
-    // one stage per trip; the fragments of its k-step 0 are in fa[0] / fb[0] on entry, those of the next
-    // stage's k-step 0 on exit
-    for (int s = 0; s < stages; s++) {
-        const int buf = s & 1;
+    // One stage out of buffer BUF (a compile-time constant: the stage loop is unrolled by two, so every
+    // LDS address is a loop-invariant per-lane base plus an immediate).  The fragments of its k-step 0
+    // are in fa[0] / fb[0] on entry, those of the next stage's k-step 0 on exit.
+    auto stage = [&](auto buf_tag, int s) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        using Other = std::integral_constant<int, BUF ^ 1>;
         const bool more = s + 1 < stages;
-        // buffer buf^1 was last read before the barrier of the previous stage: free for the DMA now
-        if (more) issue(buf ^ 1, s + 1);
-        load_raw(K1{}, fa[1], fe, fb[1]);
+        // buffer BUF^1 was last read before the barrier of the previous stage: free for the DMA now
+#ifndef CRM_EXP_NODMA
+        if (more) issue(BUF ^ 1, s + 1);
+#endif
+        load_raw(buf_tag, K1{}, fa[1], fe, fb[1]);
         mma(fa[0], fb[0]);
         finish(fa[1], fe);
         interleave();
-        load_raw(K2{}, fa[0], fe, fb[0]);
+        load_raw(buf_tag, K2{}, fa[0], fe, fb[0]);
         mma(fa[1], fb[1]);
         finish(fa[0], fe);
         interleave();
-        load_raw(K3{}, fa[1], fe, fb[1]);
+        load_raw(buf_tag, K3{}, fa[1], fe, fb[1]);
         mma(fa[0], fb[0]);
         finish(fa[1], fe);
         interleave();
         // every read of this buffer has been issued; the next stage's tiles must have landed
-        if (more) stash_g(buf ^ 1);
-        flip(buf);
+        if (more) stash_g(BUF ^ 1);
+#ifndef CRM_EXP_NOBARRIER
         __syncthreads();
+#endif
         // (after the last stage these reads fetch stale tiles of the other buffer; nothing uses them)
-        load_raw(K0{}, fa[0], fe, fb[0]);
+        load_raw(Other{}, K0{}, fa[0], fe, fb[0]);
         mma(fa[1], fb[1]);
         finish(fa[0], fe);
         interleave();
+    };
+    int s = 0;
+    for (; s + 1 < stages; s += 2) {
+        stage(K0{}, s);
+        stage(K1{}, s + 1);
     }
+    if (s < stages) stage(K0{}, s);
 
     double* Cb = P.C + (long)blockIdx.y * split_stride;
     if (TR) {
