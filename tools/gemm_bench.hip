@@ -41,19 +41,6 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     float ms;
-    {  // bare MFMA rate: 256 CUs x 2 blocks x 4 waves, 8 independent accumulators
-        double* out;
-        int blocks = 256 * 2, iters = 20000;
-        CK(hipMalloc(&out, sizeof(double) * blocks * 256));
-        hipLaunchKernelGGL(mfma_rate, dim3(blocks), dim3(256), 0, st, out, 100);
-        CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(mfma_rate, dim3(blocks), dim3(256), 0, st, out, iters);
-        CK(hipEventRecord(e1, st));
-        CK(hipEventSynchronize(e1));
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        double flops = (double)blocks * 4 * iters * 8 * 2048.0;
-        printf("bare mfma_f64_16x16x4: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms * 1e-9);
-    }
     const long cells = 20000, r = 5120;
     const int k0 = 50;
     int Bs[] = {128, 1024};
