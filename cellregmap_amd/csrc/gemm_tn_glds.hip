@@ -102,7 +102,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     constexpr int ECN = ECQ > 0 ? ECQ : 1;
     unsigned e_lane[ECN];
     unsigned g_lane[KRQ];
-    bool g_on[KRQ];
     if (KR) {
         constexpr int ppr = EC > 0 ? EC / 2 : 1;  // 16-byte pieces per row
 #pragma unroll
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         for (int q = 0; q < KRQ; q++) {
             const int e = tid + 256 * q;
             const int row = e / GLD, col = e - row * GLD;
-            g_on[q] = col < nb;
-            g_lane[q] = 8u * (unsigned)(row * (int)P.ldx + (g_on[q] ? col : 0));
+            g_lane[q] = 8u * (unsigned)(row * (int)P.ldx + (col < nb ? col : 0));  // columns >= nb: never read back
         }
     }
     auto issue = [&](int BUF, int s) __attribute__((always_inline)) {

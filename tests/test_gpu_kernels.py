@@ -55,7 +55,8 @@ def test_contract_layout_with_integer_data(ctx, variant):
 
 
 @pytest.mark.parametrize("cells,M,N,ksplit", [(1000, 130, 257, 1), (4096, 256, 128, 4), (777, 16, 16, 1),
-                                               (20000, 200, 1275, 5)])
+                                               (20000, 200, 1275, 5), (7, 140, 130, 1), (20, 129, 300, 1),
+                                               (48, 300, 129, 1)])  # 1, 2 and 3 stages of 16 cells
 def test_contract_random(ctx, variant, cells, M, N, ksplit):
     rng = np.random.default_rng(cells + M)
     X = rng.normal(size=(cells, M))
@@ -65,7 +66,8 @@ def test_contract_random(ctx, variant, cells, M, N, ksplit):
 
 
 @pytest.mark.parametrize("cells,B,k0,N", [(500, 7, 10, 140), (2048, 20, 50, 300), (333, 40, 3, 64),
-                                           (1024, 5, 128, 130), (640, 300, 1, 128)])
+                                           (1024, 5, 128, 130), (640, 300, 1, 128), (5, 9, 50, 200),
+                                           (30, 40, 7, 130), (40, 6, 33, 129), (100, 3, 97, 140)])
 def test_contract_khatri_rao(ctx, variant, cells, B, k0, N):
     from cellregmap_amd import _lib
 
