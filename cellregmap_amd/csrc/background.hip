@@ -186,10 +186,6 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     const long cp = round_up(cols, 128);
     const bool thin = n > cols;  // economic_qs_linear: rows > cols -> SVD branch
 
-    struct HandleGuard {
-        rocblas_handle h;
-        ~HandleGuard() { rocblas_destroy_handle(h); }
-    };
 
     Scratch S;
     DevBuf &dH = S.bufs[0], &dHt = S.bufs[1], &dC = S.bufs[2], &dMt = S.bufs[9],
@@ -279,18 +275,37 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     // One host thread per grid point, each with its own stream, solver handle and work matrix: a
     // dsyevd call is a long chain of small kernels (tridiagonalisation panels), launch-bound on one
     // stream; the chains of the grid points are independent and overlap on the device.
+    // (streams and solver handles are created here, one after the other: library initialisation is
+    // not something to race on)
+    struct Lane {
+        hipStream_t st = nullptr;
+        rocblas_handle h = nullptr;
+    };
+    struct Lanes {
+        std::vector<Lane> v;
+        ~Lanes() {
+            for (auto& l : v) {
+                if (l.h) rocblas_destroy_handle(l.h);
+                if (l.st) (void)hipStreamDestroy(l.st);
+            }
+        }
+    } lanes;
+    lanes.v.resize(nrho);
+    for (int i = 0; i < nrho; i++) {
+        if (hipStreamCreateWithFlags(&lanes.v[i].st, hipStreamNonBlocking) != hipSuccess) {
+            set_error("background: could not create a stream for grid point %d", i);
+            return fail(CRM_ERR_HIP);
+        }
+        if (rocblas_create_handle(&lanes.v[i].h) != rocblas_status_success ||
+            rocblas_set_stream(lanes.v[i].h, lanes.v[i].st) != rocblas_status_success) {
+            set_error("background: could not create a solver handle for grid point %d", i);
+            return fail(CRM_ERR_HIP);
+        }
+    }
     auto decompose = [&](int i) -> int {
         CRM_HIP(hipSetDevice(ctx->device));
-        hipStream_t ws;
-        CRM_HIP(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
-        struct StreamGuard {
-            hipStream_t s;
-            ~StreamGuard() { (void)hipStreamDestroy(s); }
-        } sguard{ws};
-        rocblas_handle wh;
-        CRM_ROC(rocblas_create_handle(&wh));
-        HandleGuard hguard{wh};
-        CRM_ROC(rocblas_set_stream(wh, ws));
+        hipStream_t ws = lanes.v[i].st;
+        rocblas_handle wh = lanes.v[i].h;
         ScopedBuf wCr, wW, wE, wInfo, wKeep;
         CRM_TRY(wCr.ensure(sizeof(double) * dimp * dimp));
         CRM_TRY(wW.ensure(sizeof(double) * dimp));
@@ -369,12 +384,26 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         std::vector<int> rcs(nrho, CRM_OK);
         std::vector<std::string> errs(nrho);
         std::vector<std::thread> workers;
-        for (int i = 0; i < nrho; i++) {
-            bg->rho[i] = rho[i];
-            workers.emplace_back([&, i]() {
+        for (int i = 0; i < nrho; i++) bg->rho[i] = rho[i];
+        // the first one alone (it pays the solver's one-time kernel loading), the rest side by side.
+        // CRM_SETUP_THREADS=1 keeps everything on the calling thread; so does a rocprofiler tool in
+        // the process (rocprofv3's kernel trace segfaulted in 2 of 3 runs with launches coming from
+        // eleven threads at once; never without the tool).
+        const char* tenv = getenv("CRM_SETUP_THREADS");
+        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY_CTOR");
+        const bool serial = tenv ? atoi(tenv) <= 1 : profiled;
+        rcs[0] = decompose(0);
+        if (rcs[0] != CRM_OK) errs[0] = last_error_text();
+        for (int i = 1; i < nrho && rcs[0] == CRM_OK; i++) {
+            if (serial) {
                 rcs[i] = decompose(i);
                 if (rcs[i] != CRM_OK) errs[i] = last_error_text();
-            });
+            } else {
+                workers.emplace_back([&, i]() {
+                    rcs[i] = decompose(i);
+                    if (rcs[i] != CRM_OK) errs[i] = last_error_text();
+                });
+            }
         }
         for (auto& w : workers) w.join();
         for (int i = 0; i < nrho; i++) {

@@ -65,6 +65,8 @@ constexpr int GEMM_BK = 16;
 // C + s * split_stride; reduce with reduce_splits).
 int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
+// number of slices along the cell axis for a launch that would otherwise have `blocks_without_split` workgroups
+int split_for(long cells_pad, long blocks_without_split);
 extern int g_contraction_bn;
 extern int g_contraction_glds;
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,

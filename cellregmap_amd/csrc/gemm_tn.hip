@@ -42,7 +42,7 @@ typedef const v2d __attribute__((address_space(1))) * gptr2_t;
 // KRQ: 8-byte prefetch slots per thread for the G tile of the Khatri-Rao operand
 template <bool KR, int KRQ, int BN>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
-                                                          int mtiles_max, long cells_per_split,
+                                                          int mtiles_max, long cells_per_split, long cells_total,
                                                           long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
     const int l15 = lane & 15, lq = lane >> 4;
 
     const long cell_begin = (long)blockIdx.y * cells_per_split;
-    const int stages = (int)(cells_per_split / GEMM_BK);
+    // (the last slice of a split over the cell axis may be shorter)
+    const int stages = (int)(std::min(cells_per_split, cells_total - cell_begin) / GEMM_BK);
 
     // ---- LDS carve-up (two stages of every tile) --------------------------------------
     const int nb = KR ? kr_variants_per_tile(k0) : 0;
@@ -259,6 +260,16 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
 int g_contraction_glds = 1;  // 128-wide tiles through the LDS-DMA kernel (gemm_tn_glds.hip)
 int g_contraction_bn = 0;  // output-tile width override: 0 = choose per launch, else 64 or 128
 
+int split_for(long cells_pad, long blocks_without_split) {
+    // enough workgroups to cover the 256 CUs twice, at least eight stages per slice, every slice non-empty
+    const long stages = cells_pad / GEMM_BK;
+    long want = (512 + blocks_without_split - 1) / std::max<long>(blocks_without_split, 1);
+    want = std::min<long>(std::min<long>(want, 64), std::max<long>(stages / 8, 1));
+    if (want <= 1) return 1;
+    const long per = (stages + want - 1) / want;
+    return (int)((stages + per - 1) / per);
+}
+
 int launch_kr_transposed(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
@@ -274,8 +285,11 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
     if (ksplit < 1) ksplit = 1;
-    if (cells % (GEMM_BK * (long)ksplit) != 0) {
-        set_error("contraction: cell count %ld is not a multiple of %d", cells, GEMM_BK * ksplit);
+    // slices of ceil(stages / ksplit) stages; every slice must hold at least one (see split_for)
+    const long total_stages = cells / GEMM_BK;
+    const long cps = (total_stages + ksplit - 1) / ksplit * GEMM_BK;
+    if (cells % GEMM_BK != 0 || (long)(ksplit - 1) * cps >= cells) {
+        set_error("contraction: %ld cells cannot be cut into %d slices of whole stages", cells, ksplit);
         return CRM_ERR_ARG;
     }
     const int mt = (max_m + GEMM_BM - 1) / GEMM_BM;
@@ -308,26 +322,26 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
         if (bn == 64) {
             if (small)
                 hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cells / ksplit, split_stride, k0);
+                                   cps, cells, split_stride, k0);
             else
                 hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cells / ksplit, split_stride, k0);
+                                   cps, cells, split_stride, k0);
         } else {
             if (small)
                 hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cells / ksplit, split_stride, k0);
+                                   cps, cells, split_stride, k0);
             else
                 hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cells / ksplit, split_stride, k0);
+                                   cps, cells, split_stride, k0);
         }
     } else {
         lds += (size_t)2 * GEMM_BK * LDT * sizeof(double);
         if (bn == 64)
             hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cells / ksplit, split_stride, 0);
+                               cps, cells, split_stride, 0);
         else
             hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cells / ksplit, split_stride, 0);
+                               cps, cells, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());
     return CRM_OK;

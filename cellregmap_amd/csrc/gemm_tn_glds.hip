@@ -59,7 +59,7 @@ struct GldsGeno {
 
 template <bool KR, int KRQ, int ECQ, bool TR = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
-                                                               int mtiles_max, long cells_per_split,
+                                                               int mtiles_max, long cells_per_split, long cells_total,
                                                                long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     constexpr int BN = 128, NT = 4, LD = 128;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
     const long cell_begin = (long)blockIdx.y * cells_per_split;
-    const int stages = (int)(cells_per_split / GEMM_BK);
+    // (the last slice of a split over the cell axis may be shorter)
+    const int stages = (int)(std::min(cells_per_split, cells_total - cell_begin) / GEMM_BK);
 
     // ---- LDS carve-up ------------------------------------------------------------------------
     const int nb = KR ? glds_kr_variants(k0) : 0;
@@ -373,6 +374,7 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         return CRM_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
+    const long cps = (cells / GEMM_BK + ksplit - 1) / ksplit * GEMM_BK;  // validated by launch_gemm_tn
     size_t lds = (size_t)2 * GEMM_BK * 128 * sizeof(double);
     if (khatri_rao) {
         const int EC = (k0 + 31) / 32 * 32;
@@ -384,10 +386,10 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
     do {                                                                                                      \
         if (small)                                                                                            \
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, T>), grid, dim3(256), lds, st, probs_dev, mt, \
-                               cells / ksplit, split_stride, k0);                                             \
+                               cps, cells, split_stride, k0);                                             \
         else                                                                                                  \
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, T>), grid, dim3(256), lds, st,          \
-                               probs_dev, mt, cells / ksplit, split_stride, k0);                              \
+                               probs_dev, mt, cps, cells, split_stride, k0);                              \
     } while (0)
 #define CRM_GLDS(Q)                              \
     do {                                         \
@@ -405,7 +407,7 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);
         hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,
-                           cells / ksplit, split_stride, 0);
+                           cps, cells, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());
     return CRM_OK;

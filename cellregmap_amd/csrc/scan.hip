@@ -18,12 +18,7 @@ static unsigned long next_panel_uid() {
     return ++counter;
 }
 
-static int pick_split(long cells_pad, long blocks_without_split) {
-    // enough workgroups to cover the 256 CUs twice, within what the padded cell count allows
-    int s = 1;
-    while (s < 16 && blocks_without_split * s < 512 && cells_pad % (GEMM_BK * (long)s * 2) == 0) s *= 2;
-    return s;
-}
+static int pick_split(long cells_pad, long blocks_without_split) { return split_for(cells_pad, blocks_without_split); }
 
 // flags[0] |= any non-finite entry; flags[1] |= any cell differing from its group's representative
 __global__ void verify_panel_kernel(const double* __restrict__ G, long ld, long p, const int* __restrict__ group,
