@@ -58,11 +58,24 @@ class HadamardHalves(Sequence):
         return self.us[:, [i]] * self.hK
 
 
+_us_cache = OrderedDict()  # digest of E -> U * S (an eQTL run calls get_L_values with one E per gene)
+
+
 def get_L_values(hK, E):
     """L_i = diag((U S)[:, i]) hK with U, S from the economic SVD of E
     (_cellregmap.py:533-545); sum_i L_i L_i' = K o EE' (proof.md)."""
-    U, S, _ = _economic_svd(E)
-    return HadamardHalves(U * S, np.asarray(hK, float))
+    E = np.asarray(E, float)
+    key = _digest(E)
+    us = _us_cache.get(key)
+    if us is None:
+        U, S, _ = _economic_svd(E)
+        us = U * S
+        _us_cache[key] = us
+        while len(_us_cache) > 4:
+            _us_cache.popitem(last=False)
+    else:
+        _us_cache.move_to_end(key)
+    return HadamardHalves(us, np.asarray(hK, float))
 
 
 class _Background:
@@ -89,8 +102,14 @@ _bg_cache = OrderedDict()
 BACKGROUND_CACHE_SIZE = 2
 
 
+try:  # ~10 GB/s; the cache key of a config-3 background covers 32 MB per CellRegMap(...)
+    import xxhash as _xxhash
+except ImportError:  # pragma: no cover
+    _xxhash = None
+
+
 def _digest(*arrays):
-    h = hashlib.blake2b(digest_size=16)
+    h = _xxhash.xxh3_128() if _xxhash is not None else hashlib.blake2b(digest_size=16)
     for a in arrays:
         if a is None:
             h.update(b"-")
@@ -169,6 +188,15 @@ def background_from_qs(qs_list, rho, device=0):
     return _Background(h, rho, device)
 
 
+_projections = {}
+
+
+def _projection(k):
+    if k not in _projections:
+        _projections[k] = np.random.default_rng(0x5EED).integers(1, 2 ** 63, size=k, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    return _projections[k]
+
+
 def candidate_groups(G, max_groups=2048, sample_columns=64):
     """Candidate donor structure of an expanded genotype matrix from a column sample: cells with
     identical sampled entries share a group.  Returns ``(group_of_cell int32 (n,), representative
@@ -181,9 +209,18 @@ def candidate_groups(G, max_groups=2048, sample_columns=64):
     if n < 2 or p < 1:
         return None
     cols = np.unique(np.linspace(0, p - 1, min(p, sample_columns)).astype(int))
-    key = np.ascontiguousarray(G[:, cols])
-    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    key = np.ascontiguousarray(G[:, cols], dtype=float)
+    # rows are grouped through a 64-bit hash of their bit patterns (wrap-around integer arithmetic: exact
+    # and order-independent, unlike a floating-point projection) and the grouping is then checked on the
+    # sampled entries; a row-wise np.unique, ~10x slower, only serves as the fallback for a collision
+    key += 0.0  # -0.0 -> +0.0
+    bits = key.view(np.uint64)
+    proj = (bits * _projection(key.shape[1])).sum(axis=1, dtype=np.uint64)
+    _, first, inv = np.unique(proj, return_index=True, return_inverse=True)
     inv = np.asarray(inv).reshape(-1)
+    if not (bits == bits[first[inv]]).all():
+        _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
     m = first.size
     if m > max_groups or m > n // 2:
         return None
@@ -356,6 +393,8 @@ class CellRegMap:
         W = self._W
         if W.shape[1] == 0:
             raise ValueError("W has no columns")
+        if W.shape[1] == 1 and np.linalg.norm(W) >= _SQRT_EPS:
+            return W  # one non-zero column: full rank without asking the SVD
         U, s, _ = _economic_svd(W)
         if s.shape[0] == W.shape[1]:
             return W

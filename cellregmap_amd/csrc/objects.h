@@ -8,6 +8,20 @@ namespace crm {
 constexpr long CELL_PAD = 128;  // cell axis padded (zero rows) to a multiple of this
 }
 
+// Phenotype-free per-donor tables of the collapsed path.  They depend on the background, on the
+// contexts E0 and on the donor structure of the panel (which cells belong to which donor), not on
+// the phenotype nor on the genotypes, so a background keeps the most recent ones for all its genes
+// and panels (an eQTL run scans thousands of genes, each against its own cis window, on one cohort).
+struct crm_donor_tables {
+    unsigned long e0_key = 0, group_key = 0;  // content hashes of E0 and of the donor index
+    unsigned long stamp = 0;                  // recency
+    crm::DevBuf TZ;   // [nrho][m_pad x ldq]          Z' Q0(rho)
+    crm::DevBuf Bd;   // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
+    crm::DevBuf Z2;   // [m_pad x ld]  Z'E   (or the m*m-row mixed table under idx_G)
+    crm::DevBuf Z3;   // [m_pad x ld]  Z'(E (x) E)
+    void release() { TZ.release(); Bd.release(); Z2.release(); Z3.release(); }
+};
+
 // Sigma(rho) = Q0 diag(S0) Q0' for every grid point (cellregmap/_cellregmap.py:95-131).
 struct crm_background {
     crm_ctx* ctx = nullptr;
@@ -24,6 +38,10 @@ struct crm_background {
     long ldh = 0, cols = 0;
     crm::DevBuf H;                        // [n_pad x ldh]
     crm::DevBuf Mix[crm::CRM_MAX_RHO];   // [ldh x ldq]
+    // shared donor tables, most recently used first (at most DT_CACHE entries)
+    static constexpr int DT_CACHE = 2;
+    std::vector<crm_donor_tables*> dt_cache;
+    unsigned long dt_clock = 0;
 };
 
 // One phenotype: y, W, E0 and what only depends on them.
@@ -40,11 +58,10 @@ struct crm_gene {
     crm::DevBuf Ep, YE, EE, idx;
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
-    unsigned long dt_panel = 0;  // uid of the panel the tables were built for (0 = none)
-    bool dt_full = false;  // also holds the phenotype-free tables (TZ, Bd, Z2, Z3)
-    crm::DevBuf dt_TZ;    // [nrho][m_pad x ldq]          Z' Q0(rho)
-    crm::DevBuf dt_Bd;    // [nrho][(m_pad*k0) x ldq]     KR(Z, E0)' Q0(rho)
-    crm::DevBuf dt_Z1, dt_Z2, dt_Z3;  // [m_pad x ld]     Z'[y o E, W o E],  Z'E,  Z'(E (x) E)
+    unsigned long e0_key = 0;    // content hash of E0 (key of the background's shared donor tables)
+    unsigned long dt_group = 0;  // donor structure (panel group_key) dt_Z1 / dt_sums were built for (0 = none)
+    crm_donor_tables dt_own;     // phenotype-free tables under a permutation hook (not shareable)
+    crm::DevBuf dt_Z1;    // [m_pad x ld]     Z'[y o E, W o E]
     crm::DevBuf dt_sums;  // [m_pad x DT_SUMS_LD]: column 0 group size, 1 sum y, 2.. sum W_i
     crm::DevBuf dt_Zt;    // indicators of the permuted groups (idx_G) + the permuted group index
 };
@@ -59,6 +76,7 @@ struct crm_panel {
     long m = 0, m_pad = 0;
     crm::DevBuf Gd;     // [m_pad x ld] one row per donor
     crm::DevBuf group;  // int[n]
+    unsigned long group_key = 0;  // content hash of (group, m)
     crm::DevBuf Z;      // [n_pad x ldz] 0/1 indicator of the groups (operand of the table builds)
     long ldz = 0;
 };

@@ -18,6 +18,22 @@ static unsigned long next_panel_uid() {
     return ++counter;
 }
 
+// content hash (64-bit words mixed splitmix-style): keys of the shared donor tables
+static unsigned long content_key(const void* data, size_t bytes, unsigned long seed) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    unsigned long h = seed ^ (0x9E3779B97F4A7C15ul * (bytes + 1));
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        unsigned long w;
+        memcpy(&w, p + i, 8);
+        h ^= w + 0x9E3779B97F4A7C15ul + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ul;
+        h ^= h >> 29;
+    }
+    for (; i < bytes; i++) h = (h ^ p[i]) * 0x100000001B3ul;
+    return h ? h : 1;
+}
+
 static int pick_split(long cells_pad, long blocks_without_split) { return split_for(cells_pad, blocks_without_split); }
 
 // flags[0] |= any non-finite entry; flags[1] |= any cell differing from its group's representative
@@ -93,6 +109,10 @@ void crm_background_destroy(crm_background* bg) {
         bg->Mix[i].release();
     }
     bg->H.release();
+    for (crm_donor_tables* t : bg->dt_cache) {
+        t->release();
+        delete t;
+    }
     delete bg;
 }
 
@@ -140,6 +160,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     g->bg = bg;
     g->c = c;
     g->k0 = k0;
+    g->e0_key = content_key(E0, sizeof(double) * (size_t)bg->n * k0, (unsigned long)k0);
     g->ldw = 16;
     g->lde = round_up(k0, 16);
     int rc = CRM_OK;
@@ -207,8 +228,9 @@ void crm_gene_destroy(crm_gene* g) {
     if (!g) return;
     (void)hipSetDevice(g->bg->ctx->device);
     (void)hipStreamSynchronize(g->bg->ctx->stream);
-    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_TZ, &g->dt_Bd,
-                    &g->dt_Z1, &g->dt_Z2, &g->dt_Z3, &g->dt_sums, &g->dt_Zt})
+    g->dt_own.release();
+    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
+                    &g->dt_Zt})
         b->release();
     delete g;
 }
@@ -273,6 +295,7 @@ int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, con
     if (rc == CRM_OK) rc = P->Z.ensure(sizeof(double) * P->n_pad * P->ldz);
     if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
     CRM_HIP(hipMemcpyAsync(P->group.ptr, group, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    P->group_key = content_key(group, sizeof(int) * n, (unsigned long)m);
     rc = launch_indicator(ctx->stream, P->group.as<int>(), n, P->n_pad, (int)m, P->Z.as<double>(), P->ldz);
     if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
     CRM_HIP(hipStreamSynchronize(ctx->stream));
@@ -339,6 +362,7 @@ int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long 
             return fail(rc);
         if (hipStreamSynchronize(st) != hipSuccess) return fail(CRM_ERR_HIP);
         P->G.release();
+        P->group_key = content_key(group_hint, sizeof(int) * n, (unsigned long)m_hint);
         if (out_grouped) *out_grouped = 1;
     }
     *out = P;
@@ -398,9 +422,9 @@ __global__ __launch_bounds__(128) void donor_cross_kernel(const double* __restri
 // Per-donor tables of the collapsed path: every n-length contraction of the scan is linear in
 // diag(g) (or diag(g)^2 = sum_d gamma_d^2 diag(z_d) for donor-constant g), so it is taken once per donor
 // indicator z_d with the same kernels and afterwards combined with the donor dosages gamma.
-static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full, const double* d_Ep,
+static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_tables* shared, const double* d_Ep,
                               const double* d_EE, const double* Zt, bool cross) {
-    // full: also the phenotype-free tables (TZ, Bd, Z2, Z3), owned by the first gene of a call.
+    // shared != nullptr: also (re)build the phenotype-free tables (TZ, Bd, Z2, Z3) into *shared.
     // Zt: indicators of the test direction (rows permuted by idx_G, else the panel's own);
     // cross: Z2 becomes the m*m-row table of the mixed products z'_d o z_d'.
     crm_background* bg = gene->bg;
@@ -411,20 +435,20 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
     const long m = panel->m, mp = panel->m_pad;
     const int npair = k0 * (k0 + 1) / 2;
     const long ldZ1 = gene->ld_ye, ldZ2 = gene->ld_ep, ldZ3 = gene->ld_ee;
+    const bool full = shared != nullptr;
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
     const double* Z = panel->Z.as<double>();
-    gene->dt_full = false;
     if (full) {
-        CRM_TRY(gene->dt_TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
-        CRM_TRY(gene->dt_Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
-        CRM_HIP(hipMemsetAsync(gene->dt_TZ.ptr, 0, sizeof(double) * (size_t)nrho * mp * ldq, st));
-        CRM_HIP(hipMemsetAsync(gene->dt_Bd.ptr, 0, sizeof(double) * (size_t)nrho * mp * k0 * ldq, st));
+        CRM_TRY(shared->TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
+        CRM_TRY(shared->Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
+        CRM_HIP(hipMemsetAsync(shared->TZ.ptr, 0, sizeof(double) * (size_t)nrho * mp * ldq, st));
+        CRM_HIP(hipMemsetAsync(shared->Bd.ptr, 0, sizeof(double) * (size_t)nrho * mp * k0 * ldq, st));
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
             p.X = Z; p.ldx = panel->ldz; p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-            p.C = gene->dt_TZ.as<double>() + (size_t)i * mp * ldq; p.ldc = ldq;
+            p.C = shared->TZ.as<double>() + (size_t)i * mp * ldq; p.ldc = ldq;
             p.M = (int)m; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
@@ -435,7 +459,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
             GemmProblem p{};
             p.X = Zt; p.ldx = panel->ldz; p.E = d_Ep; p.lde = gene->ld_ep; p.k0 = k0;
             p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-            p.C = gene->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
+            p.C = shared->Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldc = ldq;
             p.M = (int)m * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
@@ -444,19 +468,20 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
         CRM_HIP(hipStreamSynchronize(st));
     }
     // side tables (split over the cell axis: only one M tile)
+    DevBuf unused;
     struct Side { DevBuf* buf; const double* Y; long ldy; int N; long ld; bool needed; } side[3] = {
         {&gene->dt_Z1, gene->YE.as<double>(), gene->ld_ye, k0 * (1 + c), ldZ1, true},
-        {&gene->dt_Z2, d_Ep, gene->ld_ep, k0, ldZ2, full},
-        {&gene->dt_Z3, d_EE, gene->ld_ee, npair, ldZ3, full}};
+        {full ? &shared->Z2 : &unused, d_Ep, gene->ld_ep, k0, ldZ2, full},
+        {full ? &shared->Z3 : &unused, d_EE, gene->ld_ee, npair, ldZ3, full}};
     if (full && cross) {
         // C[(d*m + d'), :] = KR(Zt, Z)' Ep : the Khatri-Rao contraction with the indicators as "contexts"
         side[1].needed = false;
         const long rows = m * m;
-        CRM_TRY(gene->dt_Z2.ensure(sizeof(double) * (size_t)rows * ldZ2));
-        CRM_HIP(hipMemsetAsync(gene->dt_Z2.ptr, 0, sizeof(double) * (size_t)rows * ldZ2, st));
+        CRM_TRY(shared->Z2.ensure(sizeof(double) * (size_t)rows * ldZ2));
+        CRM_HIP(hipMemsetAsync(shared->Z2.ptr, 0, sizeof(double) * (size_t)rows * ldZ2, st));
         GemmProblem p{};
         p.X = Zt; p.ldx = panel->ldz; p.E = Z; p.lde = panel->ldz; p.k0 = (int)m;
-        p.Y = d_Ep; p.ldy = gene->ld_ep; p.C = gene->dt_Z2.as<double>(); p.ldc = ldZ2;
+        p.Y = d_Ep; p.ldy = gene->ld_ep; p.C = shared->Z2.as<double>(); p.ldc = ldZ2;
         p.M = (int)rows; p.N = k0;
         CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)rows, k0, np, true, (int)m, 1, 0));
@@ -483,7 +508,6 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, bool full,
                        gene->dt_sums.as<double>());
     CRM_HIP(hipGetLastError());
     CRM_HIP(hipStreamSynchronize(st));
-    gene->dt_full = full;
     return CRM_OK;
 }
 
@@ -574,23 +598,35 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         d_idxG = g0->idx.as<int>() + n;
         CRM_HIP(hipMemcpyAsync(d_idxG, idx_G, sizeof(int) * n, hipMemcpyHostToDevice, st));
     }
-    for (int gi = 0; gi < ng; gi++) {
-        crm_gene* g = genes[gi];
+    for (crm_gene* g : genes) {
         g->ld_ep = round_up(k0, 128);
         g->ld_ye = ldZ1;
         g->ld_ee = ldZ3;
-        CRM_TRY(g->YE.ensure(sizeof(double) * np * g->ld_ye));
-        if (gi == 0) {
-            CRM_TRY(g->Ep.ensure(sizeof(double) * np * g->ld_ep));
-            CRM_TRY(g->EE.ensure(sizeof(double) * np * g->ld_ee));
-        }
-        CRM_TRY(launch_context_features(st, g->E0.as<double>(), g->lde, d_idxE, n, np, k0, g->yW.as<double>(),
-                                        g->yW.as<double>() + 1, g->ld_yw, c,
-                                        gi == 0 ? g->Ep.as<double>() : nullptr, g->ld_ep, g->YE.as<double>(),
-                                        g->ld_ye, gi == 0 ? g->EE.as<double>() : nullptr, g->ld_ee));
     }
-    const double* d_Ep = g0->Ep.as<double>();
-    const double* d_EE = g0->EE.as<double>();
+    // y o E, W o E per gene; the permuted contexts and their pair products E (x) E once -- unless the
+    // scan runs collapsed on donor tables the background already holds (then nothing reads them)
+    const double* d_Ep = nullptr;
+    const double* d_EE = nullptr;
+    auto context_features = [&](bool shared_too) -> int {
+        for (int gi = 0; gi < ng; gi++) {
+            crm_gene* g = genes[gi];
+            const bool both = gi == 0 && shared_too;
+            CRM_TRY(g->YE.ensure(sizeof(double) * np * g->ld_ye));
+            if (both) {
+                CRM_TRY(g->Ep.ensure(sizeof(double) * np * g->ld_ep));
+                CRM_TRY(g->EE.ensure(sizeof(double) * np * g->ld_ee));
+            }
+            CRM_TRY(launch_context_features(st, g->E0.as<double>(), g->lde, d_idxE, n, np, k0, g->yW.as<double>(),
+                                            g->yW.as<double>() + 1, g->ld_yw, c,
+                                            both ? g->Ep.as<double>() : nullptr, g->ld_ep, g->YE.as<double>(),
+                                            g->ld_ye, both ? g->EE.as<double>() : nullptr, g->ld_ee));
+        }
+        if (shared_too) {
+            d_Ep = g0->Ep.as<double>();
+            d_EE = g0->EE.as<double>();
+        }
+        return CRM_OK;
+    };
 
     // ---- workspaces ----------------------------------------------------------------------------
     CRM_TRY(ctx->ws_T.ensure(sizeof(double) * (size_t)nrho * BLK * ldT));
@@ -661,6 +697,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
     }
     const long mp = grouped ? panel->m_pad : 0;
+    crm_donor_tables* tab = nullptr;  // phenotype-free donor tables of this call (collapsed mode)
     if (collapsed) {
         const double* Zt = panel->Z.as<double>();
         if (cross) {
@@ -672,17 +709,47 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(launch_indicator(st, gperm, n, np, (int)panel->m, g0->dt_Zt.as<double>(), panel->ldz));
             Zt = g0->dt_Zt.as<double>();
         }
+        // phenotype-free tables: shared through the background when no permutation hook is in use
+        // (key: contents of E0 and of the donor index), else private to this call's first gene
+        const bool reusable = !idx_E && !idx_G;
+        bool build_shared = false;
+        if (reusable) {
+            for (crm_donor_tables* t : bg->dt_cache)
+                if (t->e0_key == g0->e0_key && t->group_key == panel->group_key) tab = t;
+            if (!tab) {
+                if ((int)bg->dt_cache.size() >= crm_background::DT_CACHE) {  // drop the least recently used
+                    size_t lru = 0;
+                    for (size_t i = 1; i < bg->dt_cache.size(); i++)
+                        if (bg->dt_cache[i]->stamp < bg->dt_cache[lru]->stamp) lru = i;
+                    tab = bg->dt_cache[lru];
+                } else {
+                    tab = new crm_donor_tables();
+                    bg->dt_cache.push_back(tab);
+                }
+                tab->e0_key = 0;  // invalid until built
+                build_shared = true;
+            }
+            tab->stamp = ++bg->dt_clock;
+        } else {
+            tab = &g0->dt_own;
+            build_shared = true;
+        }
+        CRM_TRY(context_features(build_shared));
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
-            const bool reusable = !idx_E && !idx_G;
-            const bool have = g->dt_panel == panel->uid && reusable && (gi > 0 || g->dt_full);
+            const bool have = reusable && g->dt_group == panel->group_key && !(gi == 0 && build_shared);
             if (!have) {
-                g->dt_panel = 0;
-                CRM_TRY(build_donor_tables(g, panel, gi == 0, d_Ep, d_EE, Zt, cross));
-                if (reusable) g->dt_panel = panel->uid;
+                g->dt_group = 0;
+                CRM_TRY(build_donor_tables(g, panel, (gi == 0 && build_shared) ? tab : nullptr, d_Ep, d_EE, Zt, cross));
+                if (reusable) g->dt_group = panel->group_key;
             }
         }
+        if (build_shared && reusable) {
+            tab->e0_key = g0->e0_key;
+            tab->group_key = panel->group_key;
+        }
     }
+    if (!collapsed) CRM_TRY(context_features(true));
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit((size_t)BLK * ng);
     std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
@@ -737,7 +804,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
             } else {
                 p.X = Gb; p.ldx = ldb;
-                p.Y = collapsed ? g0->dt_TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
+                p.Y = collapsed ? tab->TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
             }
             p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
             p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
@@ -811,7 +878,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.C = ctx->ws_A.as<double>() + (size_t)start[i] * k0 * ldA;
             if (collapsed) {
                 // A~(b) = sum_d gamma_d,b * Bd(rho)[d]: rows of Bd are (k0 x ldq) slabs per donor
-                p.Y = g0->dt_Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
+                p.Y = tab->Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
                 p.ldc = (long)k0 * ldA;
                 p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
             } else if (via_H) {
@@ -874,14 +941,14 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         {
             GemmProblem p{};
             p.ldx = ldb; p.M = nb;
-            p.X = GG; p.Y = collapsed ? g0->dt_Z2.as<double>() : d_Ep; p.ldy = g0->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
+            p.X = GG; p.Y = collapsed ? tab->Z2.as<double>() : d_Ep; p.ldy = g0->ld_ep; p.C = dZ2; p.ldc = ldZ2; p.N = k0;
             probs[1] = p;
-            p.X = G2; p.Y = collapsed ? g0->dt_Z3.as<double>() : d_EE; p.ldy = g0->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
+            p.X = G2; p.Y = collapsed ? tab->Z3.as<double>() : d_EE; p.ldy = g0->ld_ee; p.C = dZ3; p.ldc = ldZ3; p.N = npair;
             probs[2] = p;
             CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data() + 1, sizeof(GemmProblem) * 2, hipMemcpyHostToDevice, st));
             if (cross) {
                 hipLaunchKernelGGL(donor_cross_kernel, dim3(nb), dim3(128), 0, st, Gb, ldb, (int)panel->m,
-                                   g0->dt_Z2.as<double>(), ldZ2, k0, dZ2, ldZ2);
+                                   tab->Z2.as<double>(), ldZ2, k0, dZ2, ldZ2);
                 CRM_HIP(hipGetLastError());
             } else {
                 CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
