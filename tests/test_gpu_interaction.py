@@ -322,3 +322,39 @@ def test_donor_tables_are_not_reused_across_panels():
         gc.collect()
         ref, _ = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(GenotypePanel(G, groups=None))
         assert np.all(np.abs(pv - ref) <= P_RTOL * ref + P_ATOL)
+
+
+def test_shared_donor_tables_follow_contexts_and_donor_structure():
+    """The phenotype-free donor tables live in the background, keyed by the contents of E0 and of the
+    donor index: further genes and fresh panels with the same donors reuse them, other contexts or
+    another grouping must not."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 20, 3, 48, seed=71)
+    rng = np.random.default_rng(5)
+    first = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    bg = first._bg
+
+    def dense(y, E, G):
+        return CellRegMap(y, E, W=c.W, E1=c.E, hK=c.hK, background=bg).scan_interaction(GenotypePanel(G, groups=None))[0]
+
+    def close(a, b):
+        return np.all(np.abs(a - b) <= P_RTOL * b + P_ATOL)
+
+    # gene 1 builds the tables; gene 2 (other phenotype, other SNPs, same donors) reuses them
+    G1, G2 = c.G[:, :24], c.G[:, 24:]
+    assert close(first.scan_interaction(GenotypePanel(G1))[0], dense(c.y, c.E, G1))
+    y2 = rng.permutation(c.y)
+    second = CellRegMap(y2, c.E, W=c.W, hK=c.hK, background=bg)
+    assert close(second.scan_interaction(GenotypePanel(G2))[0], dense(y2, c.E, G2))
+    # other contexts E0 on the same background (E1 stays): new tables
+    E_alt = c.E[rng.permutation(c.y.size)]
+    third = CellRegMap(c.y, E_alt, W=c.W, E1=c.E, hK=c.hK, background=bg)
+    assert close(third.scan_interaction(GenotypePanel(G1))[0], dense(c.y, E_alt, G1))
+    # another donor structure (cells shuffled) with the first contexts again
+    perm = rng.permutation(c.y.size)
+    assert close(first.scan_interaction(GenotypePanel(G2[perm]))[0], dense(c.y, c.E, G2[perm]))
+    # and back: a third distinct (E0, grouping) pair evicts the least recently used entry
+    assert close(second.scan_interaction(GenotypePanel(G1))[0], dense(y2, c.E, G1))
+    assert close(third.scan_interaction(GenotypePanel(G2))[0], dense(c.y, E_alt, G2))
