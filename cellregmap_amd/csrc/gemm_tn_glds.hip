@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
                                                                int mtiles_max, long cells_per_split, long cells_total,
                                                                long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
-    constexpr int BN = 128, NT = 4, LD = 128;
+    constexpr int BN = 128, LD = 128;
+    // Wave tile: 64 x 64 (wavefronts 2 x 2) for the plain product -- fewest fragment reads per MFMA; 32 x
+    // 128 (wavefronts 4 x 1) for the Khatri-Rao form -- per k-step two operand products instead of four
+    // (each one a VALU instruction that the FP64 matrix pipe cannot overlap), same twelve reads.
+    constexpr int MT = KR ? 2 : 4, NT = KR ? 8 : 4;   // 16-row / 16-column fragments per wavefront
+    constexpr int WROWS = 16 * MT, WCOLS = 16 * NT;
     constexpr int EC = 32 * ECQ;                        // context columns staged per row
     constexpr int GLD = GldsGeno<KRQ>::LD;
     constexpr int KS = GEMM_BK / 4;
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = KR ? wave : wave >> 1, wn = KR ? 0 : wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
     const long cell_begin = (long)blockIdx.y * cells_per_split;
     // (the last slice of a split over the cell axis may be shorter)
@@ -164,12 +169,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     // LDS byte addresses (segment and region bases folded in)
     const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
     const unsigned XS_BASE = lds0 + 8u * 2 * GEMM_BK * LD, GS_BASE = XS_BASE + 8u * 2 * GEMM_BK * EC;
-    unsigned yo[NT], xo[4], go[4], eo[4];
+    unsigned yo[NT], xo[MT], go[MT], eo[MT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) yo[t] = lds0 + 8u * (lq * LD + ((wn * 64 + l15 + t * 16) ^ sw));
+    for (int t = 0; t < NT; t++) yo[t] = lds0 + 8u * (lq * LD + ((wn * WCOLS + l15 + t * 16) ^ sw));
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int mloc = wm * 64 + t * 16 + l15;
+    for (int t = 0; t < MT; t++) {
+        const int mloc = wm * WROWS + t * 16 + l15;
         xo[t] = XS_BASE + 8u * (lq * LD + (mloc ^ sw));
         go[t] = 0;
         eo[t] = 0;
@@ -185,13 +190,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         return ((lcptr_t)(unsigned long)addr)[imm_doubles];
     };
 
-    auto load_raw = [&](auto buf_tag, auto ks_tag, double (&a)[4], double (&e)[4], double (&b)[NT])
+    auto load_raw = [&](auto buf_tag, auto ks_tag, double (&a)[MT], double (&e)[MT], double (&b)[NT])
                         __attribute__((always_inline)) {
         constexpr int R0 = decltype(buf_tag)::value * GEMM_BK + decltype(ks_tag)::value * 4;
 #pragma unroll
         for (int t = 0; t < NT; t++) b[t] = lds_at(yo[t], R0 * LD);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < MT; t++) {
             if (KR) {
                 a[t] = lds_at(go[t], R0 * GLD);
                 e[t] = lds_at(eo[t], R0 * EC);
@@ -200,87 +205,48 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
             }
         }
     };
-    auto finish = [&](double (&a)[4], const double (&e)[4]) __attribute__((always_inline)) {
+    auto finish = [&](double (&a)[MT], const double (&e)[MT]) __attribute__((always_inline)) {
 #ifdef CRM_EXP_NOMUL
         return;
 #endif
         if (KR) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) a[t] *= e[t];
+            for (int t = 0; t < MT; t++) a[t] *= e[t];
         }
     };
 
-    v4d acc[4][NT];
+    v4d acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    auto mma = [&](const double (&a)[4], const double (&b)[NT]) __attribute__((always_inline)) {
+    auto mma = [&](const double (&a)[MT], const double (&b)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < MT; i++)
 #pragma unroll
             for (int j = 0; j < NT; j++)
                 acc[i][j] = TR ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0)
                                : __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     };
-    // issue order of one k-step: the 8 (plain) / 12 (KR) fragment reads of the next k-step behind the
-    // first MFMAs, two per MFMA; the operand products behind the last four
+    // issue order of one k-step: the fragment reads of the next k-step behind the first MFMAs, two per
+    // MFMA; the operand products behind the last ones (measured: within +-0.5 % of the compiler's own
+    // order once the address arithmetic was gone; kept because it pins a known-good schedule)
     auto interleave = [&]() __attribute__((always_inline)) {
-#ifndef CRM_ILV
-#define CRM_ILV 1
-#endif
-        constexpr int READS = KR ? 12 : 8;
-        if (CRM_ILV == 1) {
+        constexpr int READS = KR ? 2 * MT + NT : MT + NT, PRODUCTS = KR ? MT : 0;
 #pragma unroll
-            for (int i = 0; i < READS / 2; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 16 - READS / 2 - (KR ? 4 : 0), 0);
-            if (KR) {
+        for (int i = 0; i < READS / 2; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - READS / 2 - PRODUCTS, 0);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                }
-            }
-        } else if (CRM_ILV == 2) {
-            // one read per MFMA, products behind the last four
-#pragma unroll
-            for (int i = 0; i < READS; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if (KR) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 16 - READS, 0);
-            }
-        } else if (CRM_ILV == 3) {
-            // reads first (all in the shadow of the first four MFMAs), products spread
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, READS / 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (KR) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            }
+        for (int i = 0; i < PRODUCTS; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
         }
     };
 
-    double fa[2][4], fb[2][NT], fe[4];
+    double fa[2][MT], fb[2][NT], fe[MT];
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
@@ -339,11 +305,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         for (int j = 0; j < NT; j++) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int nn = n0 + wn * 64 + j * 16 + lq + 4 * reg;
+                const int nn = n0 + wn * WCOLS + j * 16 + lq + 4 * reg;
                 if (nn < P.N) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int m = m0 + wm * 64 + i * 16 + l15;
+                    for (int i = 0; i < MT; i++) {
+                        const int m = m0 + wm * WROWS + i * 16 + l15;
                         if (m < P.M) Cb[(long)nn * P.ldc + m] = acc[i][j][reg];
                     }
                 }
@@ -352,14 +318,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < MT; i++) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int m = m0 + wm * 64 + i * 16 + lq + 4 * reg;
+            const int m = m0 + wm * WROWS + i * 16 + lq + 4 * reg;
             if (m < P.M) {
 #pragma unroll
                 for (int j = 0; j < NT; j++) {
-                    const int n = n0 + wn * 64 + j * 16 + l15;
+                    const int n = n0 + wn * WCOLS + j * 16 + l15;
                     if (n < P.N) Cb[(long)m * P.ldc + n] = acc[i][j][reg];
                 }
             }
