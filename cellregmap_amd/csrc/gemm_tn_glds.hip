@@ -21,10 +21,10 @@ typedef const double __attribute__((address_space(1))) * gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef const double __attribute__((address_space(3))) * lcptr_t;
 
-// a wave-uniform global pointer pinned to scalar registers (keeps `base + lane offset` in the
-// saddr + voffset form of the load instead of a per-lane 64-bit add)
 typedef const char __attribute__((address_space(1))) * gbptr_t;
 __device__ inline gptr_t at_bytes(gptr_t base, unsigned byte_off) { return (gptr_t)((gbptr_t)base + byte_off); }
+// a wave-uniform global pointer pinned to scalar registers (keeps `base + lane offset` in the
+// saddr + voffset form of the load instead of a per-lane 64-bit add)
 __device__ inline gptr_t scalar_ptr(gptr_t p) {
     const unsigned long v = (unsigned long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -48,10 +48,9 @@ __host__ __device__ inline int glds_kr_variants(int k0) {
 // buffer index is a compile-time constant and every fragment read is `ds_read_b64 v, vbase offset:imm`
 // off twelve loop-invariant per-lane bases; the global side uses wave-uniform bases advanced on the
 // scalar unit plus loop-invariant 32-bit lane offsets (`saddr + voffset`); what is left per stage of 64
-// MFMAs is the sixteen Khatri-Rao operand products.  The
-// reads / operand products of the next k-step are spread between the sixteen MFMAs of the current one
-// (sched_group_barrier), so that one wavefront alone keeps the matrix pipe fed: two wavefronts running
-// the same instruction stream fall into step, and clustered non-MFMA sections then idle the pipe in both.
+// MFMAs is the eight Khatri-Rao operand products (wave tile 32 x 128: two operand fragments per k-step).
+// The reads / operand products of the next k-step are spread between the sixteen MFMAs of the current one
+// (sched_group_barrier).
 template <int KRQ>
 struct GldsGeno {
     static constexpr int LD = KRQ == 1 ? 16 : 128;  // LDS row length of the staged genotype columns
