@@ -576,7 +576,13 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     }
     // several genes may ask for several rho* per variant: keep the (variant, rho) pair list bounded
     int BLK = (int)std::min<long>(ctx->block_variants, round_up(count, 128));
-    if (ng > 1) BLK = std::min(BLK, 512);
+    if (ng > 1) {
+        // pair-ordered buffers (A~ and, on the shared-H route, its gathered operand) grow with
+        // min(nrho, ng) * BLK: halve the block while they would take more than 64 GB
+        while (BLK > 128 &&
+               2.0 * sizeof(double) * std::min(nrho, ng) * (double)BLK * g0->k0 * (double)bg->ldq > 64.0 * (1ull << 30))
+            BLK /= 2;
+    }
     const int max_pairs = ng > 1 ? std::min(nrho, ng) * BLK : BLK;
     const long ldb = BLK + 128;              // slack columns for the Khatri-Rao tile over-read
     const long ldp = max_pairs + 128;        // pair-ordered copy of the block
