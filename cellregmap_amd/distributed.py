@@ -69,3 +69,39 @@ def scan_interaction_distributed(crm, G, idx_E=None, idx_G=None, group=None, sca
         pv, info = np.empty(0), {k: np.empty(0) for k in ("rho1", "e2", "g2", "eps2")}
     full = gather_variant_results({"pv": pv, **info}, p, group)
     return full.pop("pv"), full
+
+
+def scan_interaction_many_distributed(crms, G, idx_E=None, idx_G=None, group=None, scan_many=None):
+    """BASELINE config 4's shape: several genes (``CellRegMap`` objects sharing one background) against
+    one panel, the variants sharded over the ranks.  Every rank runs ``scan_interaction_many`` -- all
+    genes, its shard of the columns of ``G`` -- so the phenotype-free work of a variant is done once,
+    on one GPU; the gather returns ``(pvalues (genes x p), info of (genes x p) arrays)`` on every rank.
+
+    ``scan_many`` overrides the per-shard call (tests inject the CPU oracle)."""
+    import torch.distributed as dist
+
+    from ._engine import scan_interaction_many
+
+    G = np.asarray(G, float)
+    p = G.shape[1]
+    ng = len(crms)
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    first, count = variant_shard(p, rank, world)
+    keys = ("rho1", "e2", "g2", "eps2")
+    fn = scan_many if scan_many is not None else scan_interaction_many
+    if count > 0:
+        pv, info = fn(crms, np.ascontiguousarray(G[:, first:first + count]), idx_E, idx_G)
+    else:
+        pv, info = np.empty((ng, 0)), {k: np.empty((ng, 0)) for k in keys}
+    local = {}
+    for gi in range(ng):
+        local[f"pv:{gi:06d}"] = pv[gi]
+        for k in keys:
+            local[f"{k}:{gi:06d}"] = info[k][gi]
+    full = gather_variant_results(local, p, group)
+    out_pv = np.stack([full[f"pv:{gi:06d}"] for gi in range(ng)])
+    out_info = {k: np.stack([full[f"{k}:{gi:06d}"] for gi in range(ng)]) for k in keys}
+    return out_pv, out_info

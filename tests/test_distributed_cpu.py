@@ -66,3 +66,58 @@ def test_two_rank_gather_equals_single_process():
         assert np.array_equal(pv, ref_pv)
         for k in ref_info:
             assert np.array_equal(info[k], ref_info[k])
+
+
+def _worker_many(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cellregmap_amd.distributed import scan_interaction_many_distributed
+        from cellregmap_amd.synth import make_cohort
+        from oracle.crm import OracleCellRegMap
+
+        c = make_cohort(6, 10, 3, 5, seed=17)  # 5 variants over 2 ranks (3 + 2), 2 genes
+        ys = [c.y, c.y[::-1].copy()]
+        oracles = [OracleCellRegMap(y, c.E, W=c.W, hK=c.hK) for y in ys]
+
+        def scan_many(crms, G, idx_E, idx_G):
+            res = [o.scan_interaction(G, idx_E, idx_G) for o in crms]
+            return np.stack([r[0] for r in res]), {k: np.stack([r[1][k] for r in res]) for k in res[0][1]}
+
+        pv, info = scan_interaction_many_distributed(oracles, c.G, scan_many=scan_many)
+        q.put((rank, pv, info))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_multi_gene_gather_equals_single_process():
+    """Config 4's shape (several genes x one panel, variants sharded over the ranks)."""
+    import torch.multiprocessing as mp
+
+    from cellregmap_amd.synth import make_cohort
+    from oracle.crm import OracleCellRegMap
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_many, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = make_cohort(6, 10, 3, 5, seed=17)
+    for gi, y in enumerate((c.y, c.y[::-1].copy())):
+        ref_pv, ref_info = OracleCellRegMap(y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G)
+        for _, pv, info in results:
+            assert pv.shape == (2, 5)
+            assert np.array_equal(pv[gi], ref_pv)
+            for k in ref_info:
+                assert np.array_equal(info[k][gi], ref_info[k])
