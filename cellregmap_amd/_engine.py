@@ -308,6 +308,10 @@ class GenotypePanel:
         return self
 
 
+def _release_gene(lib, handle, _background_kept_alive):
+    lib.crm_gene_destroy(handle)
+
+
 _DEFERRED = object()  # constructor argument: build the background decompositions on first use
 
 
@@ -415,7 +419,8 @@ class CellRegMap:
         _lib.check(lib.crm_gene_create(self._bg.handle, _lib.ptr(y), _lib.ptr(Wb), Wb.shape[1], _lib.ptr(E0),
                                        E0.shape[1], ctypes.byref(h)))
         self._gene = h
-        self._gene_fin = weakref.finalize(self, lib.crm_gene_destroy, h)
+        # (the background object rides along so that it outlives the gene whatever the collection order)
+        self._gene_fin = weakref.finalize(self, _release_gene, lib, h, self._bg)
         return h
 
     def _panel(self, G):

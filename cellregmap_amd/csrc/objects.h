@@ -47,6 +47,7 @@ struct crm_background {
 // One phenotype: y, W, E0 and what only depends on them.
 struct crm_gene {
     crm_background* bg = nullptr;
+    crm_ctx* ctx = nullptr;  // (kept separately: destruction must not depend on the background's lifetime)
     int c = 0, k0 = 0;
     long ld_yw = 0, ldw = 0, lde = 0;
     crm::DevBuf yW;   // [n_pad x ld_yw]: column 0 = y, columns 1..c = W

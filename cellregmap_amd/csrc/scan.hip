@@ -158,6 +158,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     }
     crm_gene* g = new crm_gene();
     g->bg = bg;
+    g->ctx = bg->ctx;
     g->c = c;
     g->k0 = k0;
     g->e0_key = content_key(E0, sizeof(double) * (size_t)bg->n * k0, (unsigned long)k0);
@@ -226,8 +227,8 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
 
 void crm_gene_destroy(crm_gene* g) {
     if (!g) return;
-    (void)hipSetDevice(g->bg->ctx->device);
-    (void)hipStreamSynchronize(g->bg->ctx->stream);
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
                     &g->dt_Zt})
