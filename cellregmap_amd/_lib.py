@@ -55,6 +55,7 @@ SIGNATURES = {
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
     "crm_test_set_contraction": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "crm_test_set_shared_h": (ctypes.c_int, [ctypes.c_int]),
+    "crm_test_set_contraction_sync": (ctypes.c_int, [ctypes.c_int]),
     "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                          ctypes.c_int]),
     "crm_test_contract_kr": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,

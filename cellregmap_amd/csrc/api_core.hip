@@ -150,6 +150,12 @@ int crm_test_set_contraction(int tile_width, int lds_dma) {
     return CRM_OK;
 }
 
+int crm_test_set_contraction_sync(int every) {
+    if (every < 0) return CRM_ERR_ARG;
+    g_contraction_sync = every;
+    return CRM_OK;
+}
+
 int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit) {
     if (!c || cells <= 0 || M <= 0 || N <= 0 || !X || !Y || !C || ksplit < 1) return CRM_ERR_ARG;

@@ -69,6 +69,7 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
 int split_for(long cells_pad, long blocks_without_split);
 extern int g_contraction_bn;
 extern int g_contraction_glds;
+extern int g_contraction_sync;
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out = false);
 // Khatri-Rao contraction storing C' (N x M, leading dimension ldc): always the LDS-DMA kernel

@@ -56,11 +56,9 @@ struct GldsGeno {
     static constexpr int LD = KRQ == 1 ? 16 : 128;  // LDS row length of the staged genotype columns
 };
 
-template <bool KR, int KRQ, int ECQ, bool TR = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
-                                                               int mtiles_max, long cells_per_split, long cells_total,
-                                                               long split_stride, int k0) {
-    extern __shared__ __align__(16) double smem[];
+template <bool KR, int KRQ, int ECQ, bool TR>
+__device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, int mtile, int ntile, int slice,
+                                          long cells_per_split, long cells_total, long split_stride, int k0) {
     constexpr int BN = 128, LD = 128;
     // Wave tile: 64 x 64 (wavefronts 2 x 2) for the plain product -- fewest fragment reads per MFMA; 32 x
     // 128 (wavefronts 4 x 1) for the Khatri-Rao form -- per k-step two operand products instead of four
@@ -70,10 +68,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     constexpr int EC = 32 * ECQ;                        // context columns staged per row
     constexpr int GLD = GldsGeno<KRQ>::LD;
     constexpr int KS = GEMM_BK / 4;
-    const GemmProblem P = probs[blockIdx.z];
-    const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
-    const int mtile = tile % mtiles_max;
-    const int ntile = tile / mtiles_max;
     const int m0 = mtile * GEMM_BM;
     const int n0 = ntile * BN;
     if (m0 >= P.M || n0 >= P.N) return;
@@ -83,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = KR ? wave : wave >> 1, wn = KR ? 0 : wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
-    const long cell_begin = (long)blockIdx.y * cells_per_split;
+    const long cell_begin = (long)slice * cells_per_split;
     // (the last slice of a split over the cell axis may be shorter)
     const int stages = (int)(std::min(cells_per_split, cells_total - cell_begin) / GEMM_BK);
 
@@ -298,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     }
     if (s < stages) stage(K0{}, s);
 
-    double* Cb = P.C + (long)blockIdx.y * split_stride;
+    double* Cb = P.C + (long)slice * split_stride;
     if (TR) {
 #pragma unroll
         for (int j = 0; j < NT; j++) {
@@ -332,6 +326,60 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem*
     }
 }
 
+template <bool KR, int KRQ, int ECQ, bool TR = false>
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
+                                                               int mtiles_max, long cells_per_split, long cells_total,
+                                                               long split_stride, int k0) {
+    extern __shared__ __align__(16) double smem[];
+    const GemmProblem P = probs[blockIdx.z];
+    const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
+    glds_tile<KR, KRQ, ECQ, TR>(smem, P, tile % mtiles_max, tile / mtiles_max, (int)blockIdx.y, cells_per_split,
+                                cells_total, split_stride, k0);
+}
+
+// Persistent form with a soft per-XCD generation sync (experiment, crm_test_set_contraction_sync): 8 x 64
+// workgroups; the workgroups that share an XCD (blockIdx % 8) walk a contiguous run of the flattened
+// (problem, slice, tile) list 64 tiles at a time and wait -- bounded, so no assumption about residency can
+// deadlock -- until the whole group has finished a generation before starting the next: the 64 tiles of a
+// generation then stream the same Q0 column tile and the same context rows at the same time.
+template <bool KR, int KRQ, int ECQ, bool TR>
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmProblem* __restrict__ probs,
+                                                                    int mtiles_max, int tiles_per_slice, int slices,
+                                                                    int nprob, long cells_per_split, long cells_total,
+                                                                    long split_stride, int k0,
+                                                                    unsigned* __restrict__ counters, int every) {
+    extern __shared__ __align__(16) double smem[];
+    const int group = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const long total = (long)tiles_per_slice * slices * nprob;
+    const long q = total >> 3, r = total & 7;
+    const long start = group < r ? group * (q + 1) : r * (q + 1) + (group - r) * q;
+    const long cnt = q + (group < r ? 1 : 0);
+    for (long gen = 0; gen * slots < cnt; gen++) {
+        const long idx = gen * slots + slot;
+        if (idx < cnt) {
+            const long w = start + idx;
+            const int tile = (int)(w % tiles_per_slice);
+            const int sl = (int)((w / tiles_per_slice) % slices);
+            const int z = (int)(w / ((long)tiles_per_slice * slices));
+            const GemmProblem P = probs[z];
+            glds_tile<KR, KRQ, ECQ, TR>(smem, P, tile % mtiles_max, tile / mtiles_max, sl, cells_per_split, cells_total,
+                                        split_stride, k0);
+        }
+        if (threadIdx.x == 0 && (gen + 1) % every == 0) {
+            __hip_atomic_fetch_add(&counters[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)(slots * ((gen + 1) / every));
+            for (int spin = 0; spin < 20000; spin++) {
+                if (__hip_atomic_load(&counters[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int g_contraction_sync = 0;
+static unsigned* g_sync_counters = nullptr;
+
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out) {
     if (transposed_out && !khatri_rao) {
@@ -339,6 +387,11 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         return CRM_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
+    const bool sync = g_contraction_sync && khatri_rao && (long)mt * nt * ksplit * nz > 1024;
+    if (sync) {
+        if (!g_sync_counters) CRM_HIP(hipMalloc(&g_sync_counters, 64));
+        CRM_HIP(hipMemsetAsync(g_sync_counters, 0, 64, st));
+    }
     const long cps = (cells / GEMM_BK + ksplit - 1) / ksplit * GEMM_BK;  // validated by launch_gemm_tn
     size_t lds = (size_t)2 * GEMM_BK * 128 * sizeof(double);
     if (khatri_rao) {
@@ -349,7 +402,11 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         lds += (size_t)2 * GEMM_BK * (EC + (small ? GldsGeno<1>::LD : GldsGeno<KRQ_BIG>::LD)) * sizeof(double);
 #define CRM_GLDS_T(Q, T)                                                                                      \
     do {                                                                                                      \
-        if (small)                                                                                            \
+        if (sync && small)                                                                                    \
+            hipLaunchKernelGGL((gemm_tn_glds_sync_kernel<true, 1, Q, T>), dim3(512), dim3(256), lds, st,      \
+                               probs_dev, mt, mt * nt, ksplit, nz, cps, cells, split_stride, k0,              \
+                               g_sync_counters, g_contraction_sync);                                          \
+        else if (small)                                                                                       \
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, T>), grid, dim3(256), lds, st, probs_dev, mt, \
                                cps, cells, split_stride, k0);                                             \
         else                                                                                                  \

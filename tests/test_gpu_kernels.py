@@ -83,6 +83,29 @@ def test_contract_khatri_rao(ctx, variant, cells, B, k0, N):
     assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
 
 
+@pytest.mark.parametrize("every", [1, 3])
+def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
+    """The optional persistent form (8 x 64 workgroups, soft re-alignment per XCD group) on a launch of
+    more than 1024 tiles, ragged at both ends."""
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    cells, B, k0, N = 40, 1300, 13, 1100         # 133 row tiles x 9 column tiles = 1197 tiles
+    rng = np.random.default_rng(every)
+    G = rng.normal(size=(cells, B))
+    E = rng.normal(size=(cells, k0))
+    Y = rng.normal(size=(cells, N))
+    C = np.empty((B * k0, N))
+    _lib.check(lib.crm_test_set_contraction(0, 1))
+    _lib.check(lib.crm_test_set_contraction_sync(every))
+    try:
+        _lib.check(lib.crm_test_contract_kr(h, cells, B, k0, N, _lib.ptr(G), _lib.ptr(E), _lib.ptr(Y), _lib.ptr(C)))
+    finally:
+        _lib.check(lib.crm_test_set_contraction_sync(0))
+    KR = (G[:, :, None] * E[:, None, :]).reshape(cells, B * k0)
+    assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
+
+
 @pytest.mark.parametrize("cells,B,k0,N", [(64, 3, 5, 17), (1000, 37, 50, 300), (320, 130, 4, 129), (4096, 8, 128, 64)])
 def test_khatri_rao_contraction_with_transposed_store(ctx, cells, B, k0, N):
     """The shared-H route of the multi-gene scan stores (KR(G,E)' H)' directly (operands of the MFMA

@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&pd, sizeof(crm::GemmProblem)));
     if (argc > 1) crm::g_contraction_bn = atoi(argv[1]);
     if (argc > 2) crm::g_contraction_glds = atoi(argv[2]);
+    if (argc > 3) crm::g_contraction_sync = atoi(argv[3]);
     printf("tile width %d\n", crm::g_contraction_bn);
     for (int B : Bs) {
         // plain: T = G' Q0  (M = B, N = r)
