@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-variants", type=int, default=8, help="variants of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--mode", default="C", choices=["C", "B"],
                     help="background: C = E1E1' + K o EE' (headline), B = E1E1' + hK hK' (r = k + m)")
+    ap.add_argument("--block", type=int, default=0, help="variants per internal block (0 = library default)")
     ap.add_argument("--polish", type=int, default=0)
     ap.add_argument("--collapsed", type=int, default=1, help="also time the donor-collapsed path (N=1)")
     ap.add_argument("--genes", type=int, default=16, help="phenotypes of the shared multi-gene leg (0 = skip, N=1)")
@@ -84,6 +85,8 @@ def main():
 
     ctx = _engine._context(local_rank)
     _lib.check(lib.crm_set_null_fit_polish(ctx, int(args.polish)))
+    if args.block > 0:
+        _lib.check(lib.crm_set_block_variants(ctx, int(args.block)))
     t0 = time.time()
     Ls = get_L_values(cohort.hK, cohort.E)
     bg_kw = {"Ls": Ls} if args.mode == "C" else {"hK": cohort.hK}

@@ -98,7 +98,7 @@ int crm_ctx_synchronize(crm_ctx* c) {
 
 int crm_set_block_variants(crm_ctx* c, int variants) {
     if (!c || variants < 0) return CRM_ERR_ARG;
-    c->block_variants = variants == 0 ? CRM_DEFAULT_BLOCK : (int)round_up(variants, 128);
+    c->block_variants = variants == 0 ? 0 : (int)round_up(variants, 128);
     return CRM_OK;
 }
 

@@ -25,7 +25,8 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
     const int nrho = bg->nrho, c = gene->c;
     const long slab = (long)(1 + c) * ldq;
-    const int BLK = (int)std::min<long>(ctx->block_variants, round_up(std::max<long>(count, 1), 128));
+    const int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : CRM_DEFAULT_BLOCK,
+                                        round_up(std::max<long>(count, 1), 128));
     const long ldb = BLK + 128, ldT = ldq;
     const long ld_gW = round_up(c, 8);
 

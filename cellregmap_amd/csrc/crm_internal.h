@@ -6,7 +6,8 @@
 
 namespace crm {
 
-constexpr int CRM_DEFAULT_BLOCK = 1024;  // variants per internal batch
+constexpr int CRM_DEFAULT_BLOCK = 1024;  // variants per internal batch of the association scans
+constexpr int CRM_MAX_AUTO_BLOCK = 4096;  // interaction scan: largest automatic batch (see scan_core)
 constexpr int CRM_MAX_RHO = 16;    // rho grid points (the reference uses 1 or 11)
 constexpr int CRM_MAX_COV = 8;    // columns of W the register null-fit kernel is instantiated for
 constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W overall (beyond CRM_MAX_COV: the LDS null-fit kernel)
@@ -40,7 +41,7 @@ struct crm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int block_variants = crm::CRM_DEFAULT_BLOCK;
+    int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)

@@ -576,7 +576,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
     }
     // several genes may ask for several rho* per variant: keep the (variant, rho) pair list bounded
-    int BLK = (int)std::min<long>(ctx->block_variants, round_up(count, 128));
+    // automatic block: as many variants as keep the A~ buffer (block x k0 x ldq doubles) within 16 GB, at
+    // most 4096 -- fixed per-block costs (host round trip for the rho* groups, small launches, the last,
+    // partly filled round of workgroups) then weigh 2-3 % less than at 1024
+    long auto_blk = (long)(16.0 * (1ull << 30) / (sizeof(double) * (double)g0->k0 * (double)bg->ldq)) / 128 * 128;
+    auto_blk = std::max<long>(256, std::min<long>(auto_blk, CRM_MAX_AUTO_BLOCK));
+    int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
     if (ng > 1) {
         // pair-ordered buffers (A~ and, on the shared-H route, its gathered operand) grow with
         // min(nrho, ng) * BLK: halve the block while they would take more than 64 GB

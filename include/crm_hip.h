@@ -132,7 +132,8 @@ int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, double* out_bet
 int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const double* rhs, int m,
                   double* out);
 
-/* Block size (variants per internal batch); 0 restores the default. */
+/* Block size (variants per internal batch); 0 restores the default (automatic: up to 4096 variants of
+ * the interaction scan while its largest work buffer stays within 16 GB; 1024 for the association scans). */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
 /* on = 1 (default): for backgrounds built on the device with a well-conditioned kept spectrum
  * (S_max <= 1e6 S_min), the rotations G'Q0(rho) of the dense scan are taken as Mix(rho)'(H'G) with
