@@ -43,14 +43,15 @@ int main(int argc, char** argv) {
     float ms;
     const long cells = 20000, r = 5120;
     const int k0 = 50;
-    int Bs[] = {128, 1024};
+    int Bs[] = {128, 1024, 4096};   // 4096 = one automatic block of the scan at config 3
+    const long GLD = 4096 + 128;
     double *Q0, *G, *E, *C;
     CK(hipMalloc(&Q0, sizeof(double) * cells * r));
-    CK(hipMalloc(&G, sizeof(double) * cells * (1024 + 128)));
+    CK(hipMalloc(&G, sizeof(double) * cells * GLD));
     CK(hipMalloc(&E, sizeof(double) * cells * 64));
-    CK(hipMalloc(&C, sizeof(double) * 1024L * k0 * r));
+    CK(hipMalloc(&C, sizeof(double) * 4096L * k0 * r));
     hipLaunchKernelGGL(fill, dim3((cells * r + 255) / 256), dim3(256), 0, st, Q0, cells * r, 1u);
-    hipLaunchKernelGGL(fill, dim3((cells * 1152 + 255) / 256), dim3(256), 0, st, G, cells * 1152, 2u);
+    hipLaunchKernelGGL(fill, dim3((unsigned)((cells * GLD + 255) / 256)), dim3(256), 0, st, G, cells * GLD, 2u);
     hipLaunchKernelGGL(fill, dim3((cells * 64 + 255) / 256), dim3(256), 0, st, E, cells * 64, 3u);
     crm::GemmProblem* pd;
     CK(hipMalloc(&pd, sizeof(crm::GemmProblem)));
@@ -61,7 +62,7 @@ int main(int argc, char** argv) {
     for (int B : Bs) {
         // plain: T = G' Q0  (M = B, N = r)
         crm::GemmProblem p{};
-        p.X = G; p.Y = Q0; p.C = C; p.ldx = 1152; p.ldy = r; p.ldc = r; p.M = B; p.N = (int)r;
+        p.X = G; p.Y = Q0; p.C = C; p.ldx = GLD; p.ldy = r; p.ldc = r; p.M = B; p.N = (int)r;
         CK(hipMemcpy(pd, &p, sizeof p, hipMemcpyHostToDevice));
         crm::launch_gemm_tn(st, pd, 1, B, (int)r, cells, false, 0, 1, 0);
         CK(hipEventRecord(e0, st));
