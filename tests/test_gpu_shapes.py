@@ -54,6 +54,41 @@ def test_odd_shapes_match_oracle(n, k0, c, p, donors, mode):
         assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
 
 
+def _sweep_cases():
+    rng = np.random.default_rng(2026)
+    cases = []
+    for i in range(20):
+        mode = "ABC"[i % 3]
+        n = int(rng.integers(40, 420))
+        k0 = int(rng.choice([1, 2, 3, 5, 9, 13, 17, 31, 50, 63, 64, 65])) if mode != "C" else int(rng.integers(1, 7))
+        c = int(rng.choice([1, 1, 2, 4, 8, 9, 12]))
+        p = int(rng.integers(1, 40))
+        donors = int(rng.integers(3, 12))
+        perm = ["none", "E", "G"][int(rng.integers(0, 3))]
+        cases.append((i, n, k0, c, p, donors, mode, perm))
+    return cases
+
+
+@pytest.mark.parametrize("i,n,k0,c,p,donors,mode,perm", _sweep_cases())
+def test_randomised_sweep_against_the_oracle(i, n, k0, c, p, donors, mode, perm):
+    """Seeded sweep over cell counts, context counts (tile-edge cases of the Khatri-Rao operand), covariate
+    counts (both null-fit kernels), panel widths, background modes and the permutation hooks; dense and
+    donor-collapsed paths."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    y, E, W, G, kw = _random_problem(n, k0, c, p, donors, seed=1000 + i, mode=mode)
+    idx = np.random.default_rng(i).permutation(n)
+    hooks = {} if perm == "none" else ({"idx_E": idx} if perm == "E" else {"idx_G": idx})
+    crm = CellRegMap(y, E, W=W, **kw)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, **kw).scan_interaction(G, return_stats=True, **hooks)
+    for groups in (None, "auto"):
+        pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
+        assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+        assert_allclose(st["Q"], ost["Q"], rtol=1e-6)
+        assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+
+
 def test_sub_range_of_a_panel_through_the_c_abi():
     """crm_scan_interaction(first, count) on an odd, unaligned sub-range equals the full scan."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _lib
