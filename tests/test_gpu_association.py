@@ -69,3 +69,38 @@ def test_wide_and_register_null_fit_agree():
     opv, oinfo = ocrm.scan_association(c.G)
     assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
     assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
+
+
+def _assoc_sweep():
+    rng = np.random.default_rng(77)
+    out = []
+    for i in range(10):
+        out.append((i, int(rng.integers(5, 14)), int(rng.integers(8, 30)), int(rng.integers(1, 9)), int(rng.integers(1, 40)),
+                    int(rng.choice([1, 2, 5, 9, 20])), "ABC"[i % 3], bool(i % 2)))
+    return out
+
+
+@pytest.mark.parametrize("i,donors,cells,k,p,c,mode,fast", _assoc_sweep())
+def test_association_sweep_against_the_oracle(i, donors, cells, k, p, c, mode, fast):
+    """Seeded sweep: cohort shapes, covariate counts on both sides of the register / LDS null-fit split,
+    the three background modes, full and fast scans."""
+    from cellregmap_amd import CellRegMap, get_L_values
+    from oracle import crm as ocrm
+
+    co = _cohort(donors, cells, k, p, seed=300 + i)
+    rng = np.random.default_rng(i)
+    W = np.concatenate([co.W, rng.normal(size=(co.y.size, c - 1))], axis=1) if c > 1 else co.W
+    if mode == "A":
+        kw, okw = {}, {}
+    elif mode == "B":
+        kw, okw = {"hK": co.hK}, {"hK": co.hK}
+    else:
+        kw, okw = {"Ls": get_L_values(co.hK, co.E)}, {"Ls": ocrm.khatri_rao_halves(co.hK, co.E)}
+    dev = CellRegMap(co.y, co.E, W=W, **kw)
+    ora = ocrm.OracleCellRegMap(co.y, co.E, W=W, **okw)
+    pv, info = (dev.scan_association_fast if fast else dev.scan_association)(co.G)
+    opv, oinfo = (ora.scan_association_fast if fast else ora.scan_association)(co.G)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    for key in ("e2", "g2", "eps2"):
+        assert_allclose(info[key], oinfo[key], rtol=1e-5, atol=1e-12)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
