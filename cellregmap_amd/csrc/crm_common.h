@@ -71,7 +71,8 @@ extern int g_contraction_bn;
 extern int g_contraction_glds;
 extern int g_contraction_sync;
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
-                        bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out = false);
+                        bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out = false,
+                        int bn = 128);
 // Khatri-Rao contraction storing C' (N x M, leading dimension ldc): always the LDS-DMA kernel
 int launch_kr_transposed(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0);

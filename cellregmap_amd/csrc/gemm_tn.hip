@@ -300,14 +300,16 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
     if (bn != 64 && bn != 128) {
         const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
         bn = tiles128 < 1024 ? 64 : 128;
+        // narrow outputs (modes A / B: N = k1 + m columns): 64-wide tiles when they waste less padding
+        if (khatri_rao && ((max_n + 63) / 64) * 64 * 100 <= ((max_n + 127) / 128) * 128 * 85) bn = 64;
     }
     const int nt = (max_n + bn - 1) / bn;
-    if (bn == 128 && g_contraction_glds) {
+    if (g_contraction_glds && (bn == 128 || khatri_rao)) {
         if (khatri_rao && (k0 < 1 || k0 > 128)) {
             set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
             return CRM_ERR_UNSUPPORTED;
         }
-        return launch_gemm_tn_glds(st, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride);
+        return launch_gemm_tn_glds(st, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride, false, bn);
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
     size_t lds = (size_t)2 * GEMM_BK * (bn + 16) * sizeof(double);

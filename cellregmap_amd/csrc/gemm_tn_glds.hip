@@ -56,14 +56,15 @@ struct GldsGeno {
     static constexpr int LD = KRQ == 1 ? 16 : 128;  // LDS row length of the staged genotype columns
 };
 
-template <bool KR, int KRQ, int ECQ, bool TR>
+template <bool KR, int KRQ, int ECQ, bool TR, int BN>
 __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, int mtile, int ntile, int slice,
                                           long cells_per_split, long cells_total, long split_stride, int k0) {
-    constexpr int BN = 128, LD = 128;
+    static_assert(BN == 128 || (BN == 64 && KR), "64-wide tiles are built for the Khatri-Rao form");
+    constexpr int LD = BN;
     // Wave tile: 64 x 64 (wavefronts 2 x 2) for the plain product -- fewest fragment reads per MFMA; 32 x
     // 128 (wavefronts 4 x 1) for the Khatri-Rao form -- per k-step two operand products instead of four
     // (each one a VALU instruction that the FP64 matrix pipe cannot overlap), same twelve reads.
-    constexpr int MT = KR ? 2 : 4, NT = KR ? 8 : 4;   // 16-row / 16-column fragments per wavefront
+    constexpr int MT = KR ? 2 : 4, NT = KR ? BN / 16 : 4;   // 16-row / 16-column fragments per wavefront
     constexpr int WROWS = 16 * MT, WCOLS = 16 * NT;
     constexpr int EC = 32 * ECQ;                        // context columns staged per row
     constexpr int GLD = GldsGeno<KRQ>::LD;
@@ -97,7 +98,11 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
     // LDS-DMA of stage s into buffer BUF: each wavefront issues the rows / pieces w, w+4, ...
     // Every global address is a wave-uniform 64-bit base (advanced on the scalar unit) plus a per-lane
     // 32-bit offset fixed before the loop -- the `saddr + voffset` form, no vector arithmetic per stage.
-    const unsigned y_lane = 8u * (unsigned)((lane ^ ((wave & 1) << 3)) * 2);  // bytes; source granule swap on odd rows
+    // bytes; source granule swap on odd rows.  64-wide tiles: one wave-instruction carries two 512-byte rows
+    // (lanes 0-31 the even one, lanes 32-63 the odd one)
+    const unsigned y_lane = BN == 128 ? 8u * (unsigned)((lane ^ ((wave & 1) << 3)) * 2)
+                                      : (unsigned)(lane >> 5) * (unsigned)(P.ldy * 8) +
+                                            16u * (unsigned)((lane & 31) ^ ((lane >> 5) << 3));
     constexpr int ECN = ECQ > 0 ? ECQ : 1;
     unsigned e_lane[ECN];
     unsigned g_lane[KRQ];
@@ -122,9 +127,10 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         // instruction selector can fold it into the voffset operand)
         unsigned yl = y_lane;
         asm volatile("" : "+v"(yl));
+        constexpr int YROWS = BN == 128 ? 1 : 2;  // rows per wave-instruction
 #pragma unroll
-        for (int q = 0; q < GEMM_BK / 4; q++) {
-            const int r = wave + 4 * q;
+        for (int q = 0; q < GEMM_BK / (4 * YROWS); q++) {
+            const int r = (wave + 4 * q) * YROWS;
             gptr_t yrow = scalar_ptr(Yg + (roff + r) * P.ldy);
             __builtin_amdgcn_global_load_lds(at_bytes(yrow, yl), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
             if (!KR) {
@@ -326,15 +332,15 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
     }
 }
 
-template <bool KR, int KRQ, int ECQ, bool TR = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
+template <bool KR, int KRQ, int ECQ, bool TR = false, int BN = 128>
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
                                                                int mtiles_max, long cells_per_split, long cells_total,
                                                                long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
     const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
-    glds_tile<KR, KRQ, ECQ, TR>(smem, P, tile % mtiles_max, tile / mtiles_max, (int)blockIdx.y, cells_per_split,
-                                cells_total, split_stride, k0);
+    glds_tile<KR, KRQ, ECQ, TR, BN>(smem, P, tile % mtiles_max, tile / mtiles_max, (int)blockIdx.y, cells_per_split,
+                                    cells_total, split_stride, k0);
 }
 
 // Persistent form with a soft per-XCD generation sync (experiment, crm_test_set_contraction_sync): 8 x 64
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmPro
             const int sl = (int)((w / tiles_per_slice) % slices);
             const int z = (int)(w / ((long)tiles_per_slice * slices));
             const GemmProblem P = probs[z];
-            glds_tile<KR, KRQ, ECQ, TR>(smem, P, tile % mtiles_max, tile / mtiles_max, sl, cells_per_split, cells_total,
+            glds_tile<KR, KRQ, ECQ, TR, 128>(smem, P, tile % mtiles_max, tile / mtiles_max, sl, cells_per_split, cells_total,
                                         split_stride, k0);
         }
         if (threadIdx.x == 0 && (gen + 1) % every == 0) {
@@ -381,19 +387,23 @@ int g_contraction_sync = 0;
 static unsigned* g_sync_counters = nullptr;
 
 int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
-                        bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out) {
+                        bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out, int bn) {
+    if (bn != 128 && !(bn == 64 && khatri_rao && !transposed_out)) {
+        set_error("contraction: %d-wide LDS-DMA tiles are not built for this form", bn);
+        return CRM_ERR_UNSUPPORTED;
+    }
     if (transposed_out && !khatri_rao) {
         set_error("contraction: the transposed store is only built for the Khatri-Rao form");
         return CRM_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
-    const bool sync = g_contraction_sync && khatri_rao && (long)mt * nt * ksplit * nz > 1024;
+    const bool sync = g_contraction_sync && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024;
     if (sync) {
         if (!g_sync_counters) CRM_HIP(hipMalloc(&g_sync_counters, 64));
         CRM_HIP(hipMemsetAsync(g_sync_counters, 0, 64, st));
     }
     const long cps = (cells / GEMM_BK + ksplit - 1) / ksplit * GEMM_BK;  // validated by launch_gemm_tn
-    size_t lds = (size_t)2 * GEMM_BK * 128 * sizeof(double);
+    size_t lds = (size_t)2 * GEMM_BK * bn * sizeof(double);
     if (khatri_rao) {
         const int EC = (k0 + 31) / 32 * 32;
         const int nb = glds_kr_variants(k0);
@@ -413,9 +423,19 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, T>), grid, dim3(256), lds, st,          \
                                probs_dev, mt, cps, cells, split_stride, k0);                              \
     } while (0)
+#define CRM_GLDS_64(Q)                                                                                        \
+    do {                                                                                                      \
+        if (small)                                                                                            \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, false, 64>), grid, dim3(256), lds, st,        \
+                               probs_dev, mt, cps, cells, split_stride, k0);                              \
+        else                                                                                                  \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, false, 64>), grid, dim3(256), lds, st,  \
+                               probs_dev, mt, cps, cells, split_stride, k0);                              \
+    } while (0)
 #define CRM_GLDS(Q)                              \
     do {                                         \
-        if (transposed_out) CRM_GLDS_T(Q, true); \
+        if (bn == 64) CRM_GLDS_64(Q);            \
+        else if (transposed_out) CRM_GLDS_T(Q, true); \
         else CRM_GLDS_T(Q, false);               \
     } while (0)
         switch (EC / 32) {
@@ -425,6 +445,7 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
             default: CRM_GLDS(4); break;
         }
 #undef CRM_GLDS
+#undef CRM_GLDS_64
 #undef CRM_GLDS_T
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);

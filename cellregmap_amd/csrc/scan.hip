@@ -881,7 +881,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             via_H = g_shared_h_mode < 0 ? via < 0.9 * direct : g_shared_h_mode > 0;
         }
-        int nz = 0, max_m = 0;
+        int nz = 0, max_m = 0, max_n = 1;
         double kr_flops = 0.0;
         for (int i = 0; i < nrho; i++) {
             if (cnt[i] == 0) continue;
@@ -907,6 +907,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             }
             max_m = std::max(max_m, p.M);
+            max_n = std::max(max_n, p.N);
             probs[nz++] = p;
         }
         if (ctx->timing) {
@@ -935,9 +936,9 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         if (collapsed)
             CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
         else if (via_H)
-            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, bg->ldh, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
         else
-            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)ldq, np, true, k0, 1, 0));
+            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, max_n, np, true, k0, 1, 0));
         if (ctx->timing) {
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
             ctx->timed_used++;
