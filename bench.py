@@ -34,6 +34,25 @@ def algorithmic_flops(n, r_list, r_star, k0, c):
     return 2.0 * n * R + 2.0 * n * r_star * k0 + n * k0 * (k0 + 1) + 2.0 * n * k0 * (c + 2) + r_star * k0 * (k0 + 1)
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _launch_ranks(n, argv):
+    """One process per GPU through torch.distributed.run on 127.0.0.1; returns its exit code."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,9 +72,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as child processes.  Nothing in this
+        # process has touched the GPU yet (torch is not even imported), and it never will: it only
+        # relays the children's output and exit code.
+        raise SystemExit(_launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                         f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` directly)")
     import torch
 
     dist = None

@@ -312,6 +312,22 @@ def _release_gene(lib, handle, _background_kept_alive):
     lib.crm_gene_destroy(handle)
 
 
+def _permutation(idx, n):
+    """Index argument of the permutation hooks (_cellregmap.py:398-413) as int32 row indices: a
+    boolean mask selects rows like numpy's ``E0[idx, :]`` does, negative entries count from the
+    end; the hooks need one entry per sample."""
+    if idx is None:
+        return None
+    idx = np.asarray(idx)
+    if idx.dtype == bool:
+        idx = np.flatnonzero(idx)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    if idx.shape != (n,):
+        raise ValueError("permutation index must have one entry per sample")
+    idx = np.where(idx < 0, idx + n, idx)
+    return np.ascontiguousarray(idx, dtype=np.int32)
+
+
 _DEFERRED = object()  # constructor argument: build the background decompositions on first use
 
 
@@ -459,19 +475,7 @@ class CellRegMap:
         n, p = panel.shape
         gene = self._bind_gene()
 
-        def _perm(idx):
-            if idx is None:
-                return None
-            idx = np.asarray(idx)
-            if idx.dtype == bool:
-                idx = np.flatnonzero(idx)
-            idx = np.ascontiguousarray(idx, dtype=np.int64)
-            if idx.shape != (n,):
-                raise ValueError("permutation index must have one entry per sample")
-            idx = np.where(idx < 0, idx + n, idx)
-            return np.ascontiguousarray(idx, dtype=np.int32)
-
-        iE, iG = _perm(idx_E), _perm(idx_G)
+        iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         out = {k: np.empty(p) for k in ("pv", "rho1", "e2", "g2", "eps2")}
         extra = {}
         if return_stats:
@@ -616,20 +620,17 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None):
             raise ValueError("all CellRegMap objects must share one background (pass background=...)")
         if c._W.shape != first._W.shape or c._E0.shape != first._E0.shape:
             raise ValueError("all CellRegMap objects must share W and E")
+        # (the shared pass takes g'W, the context features and the donor tables from the first object)
+        if not (c._W is first._W or np.array_equal(c._W, first._W)):
+            raise ValueError("all CellRegMap objects of one pass must hold the same covariates W")
+        if not (c._E0 is first._E0 or np.array_equal(c._E0, first._E0)):
+            raise ValueError("all CellRegMap objects of one pass must hold the same contexts E")
     panel = first._panel(G)
     n, p = panel.shape
     genes = [c._bind_gene() for c in crms]
     ng = len(genes)
 
-    def _perm(idx):
-        if idx is None:
-            return None
-        idx = np.ascontiguousarray(np.asarray(idx), dtype=np.int64)
-        if idx.shape != (n,):
-            raise ValueError("permutation index must have one entry per sample")
-        return np.ascontiguousarray(np.where(idx < 0, idx + n, idx), dtype=np.int32)
-
-    iE, iG = _perm(idx_E), _perm(idx_G)
+    iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
     handles = (ctypes.c_void_p * ng)(*[g.value for g in genes])
     out = {k: np.empty((ng, p)) for k in ("pv", "rho1", "e2", "g2", "eps2")}
     _lib.check(lib.crm_scan_interaction_multi(handles, ng, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),

@@ -16,7 +16,7 @@ c_int_p = ctypes.POINTER(ctypes.c_int)
 c_long_p = ctypes.POINTER(ctypes.c_long)
 vp = ctypes.c_void_p
 
-#: every symbol include/crm_hip.h declares: name -> (restype, argtypes)
+#: every symbol include/crm_hip.h and include/crm_hip_test.h declare: name -> (restype, argtypes)
 SIGNATURES = {
     "crm_last_error": (ctypes.c_char_p, []),
     "crm_version": (ctypes.c_char_p, []),
@@ -53,9 +53,10 @@ SIGNATURES = {
     "crm_set_fast_rotation": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
-    "crm_test_set_contraction": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    "crm_test_set_shared_h": (ctypes.c_int, [ctypes.c_int]),
-    "crm_test_set_contraction_sync": (ctypes.c_int, [ctypes.c_int]),
+    "crm_kernel_timer_stop": (ctypes.c_int, [vp]),
+    "crm_test_set_contraction": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
+    "crm_test_set_shared_h": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_test_set_contraction_sync": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                          ctypes.c_int]),
     "crm_test_contract_kr": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -124,6 +124,12 @@ int crm_kernel_timer_reset(crm_ctx* c) {
     return CRM_OK;
 }
 
+int crm_kernel_timer_stop(crm_ctx* c) {
+    if (!c) return CRM_ERR_ARG;
+    c->timing = false;  // later scans record nothing; the pairs recorded so far stay readable
+    return CRM_OK;
+}
+
 int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* kr_flops,
                           double* total_ms) {
     if (!c) return CRM_ERR_ARG;
@@ -143,16 +149,16 @@ int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* 
 }
 
 // ---- single-kernel hooks -------------------------------------------------------------
-int crm_test_set_contraction(int tile_width, int lds_dma) {
-    if (tile_width != 0 && tile_width != 64 && tile_width != 128) return CRM_ERR_ARG;
-    g_contraction_bn = tile_width;
-    g_contraction_glds = lds_dma ? 1 : 0;
+int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
+    if (!c || (tile_width != 0 && tile_width != 64 && tile_width != 128)) return CRM_ERR_ARG;
+    c->tune.bn = tile_width;
+    c->tune.glds = lds_dma ? 1 : 0;
     return CRM_OK;
 }
 
-int crm_test_set_contraction_sync(int every) {
-    if (every < 0) return CRM_ERR_ARG;
-    g_contraction_sync = every;
+int crm_test_set_contraction_sync(crm_ctx* c, int every) {
+    if (!c || every < 0) return CRM_ERR_ARG;
+    c->tune.sync = every;
     return CRM_OK;
 }
 
@@ -174,7 +180,7 @@ int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, con
     p.X = bx.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
     p.ldx = ldx; p.ldy = ldy; p.ldc = ldy; p.M = M; p.N = N;
     CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
-    CRM_TRY(launch_gemm_tn(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, false, 0, ksplit, cstride));
+    CRM_TRY(launch_gemm_tn(c, bp.as<GemmProblem>(), 1, M, N, cp, false, 0, ksplit, cstride));
     CRM_TRY(launch_reduce_splits(c->stream, bc.as<double>(), cstride, ksplit, cstride));
     CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
                              M, hipMemcpyDeviceToHost, c->stream));
@@ -202,7 +208,7 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
     p.X = bg.as<double>(); p.E = be.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
     p.ldx = ldg; p.lde = lde; p.ldy = ldy; p.ldc = ldy; p.M = M; p.N = N; p.k0 = k0;
     CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
-    CRM_TRY(launch_gemm_tn(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, true, k0, 1, 0));
+    CRM_TRY(launch_gemm_tn(c, bp.as<GemmProblem>(), 1, M, N, cp, true, k0, 1, 0));
     CRM_HIP(hipMemcpy2DAsync(C, N * sizeof(double), bc.ptr, ldy * sizeof(double), N * sizeof(double),
                              M, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -231,7 +237,7 @@ int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const d
     p.X = bg.as<double>(); p.E = be.as<double>(); p.Y = by.as<double>(); p.C = bc.as<double>();
     p.ldx = ldg; p.lde = lde; p.ldy = ldy; p.ldc = ldc; p.M = M; p.N = N; p.k0 = k0;
     CRM_HIP(hipMemcpyAsync(bp.ptr, &p, sizeof p, hipMemcpyHostToDevice, c->stream));
-    CRM_TRY(launch_kr_transposed(c->stream, bp.as<GemmProblem>(), 1, M, N, cp, k0));
+    CRM_TRY(launch_kr_transposed(c, bp.as<GemmProblem>(), 1, M, N, cp, k0));
     CRM_HIP(hipMemcpy2DAsync(CT, M * sizeof(double), bc.ptr, ldc * sizeof(double), M * sizeof(double), N,
                              hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));

@@ -124,7 +124,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
         p.X = Gb; p.ldx = ldb; p.Y = bg->Q0[ri].as<double>(); p.ldy = ldq;
         p.C = ctx->ws_T.as<double>(); p.ldc = ldT; p.M = nb; p.N = bg->r[ri] > 0 ? bg->r[ri] : 1;
         CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, &p, sizeof p, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, ctx->ws_probs.as<GemmProblem>(), 1, nb, (int)ldq, np, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, nb, (int)ldq, np, false, 0, 1, 0));
         if (fast) {
             CRM_TRY(launch_fastscan(st, aa, d_prep, d_wts, nb, d_lml));
         } else {

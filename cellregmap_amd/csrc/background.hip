@@ -127,7 +127,7 @@ int contract(crm_ctx* ctx, const double* X, long ldx, const double* Y, long ldy,
     p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.C = C; p.ldc = ldc; p.M = M; p.N = N;
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
     CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, &p, sizeof p, hipMemcpyHostToDevice, ctx->stream));
-    CRM_TRY(launch_gemm_tn(ctx->stream, ctx->ws_probs.as<GemmProblem>(), 1, M, N, cells, false, 0, 1, 0));
+    CRM_TRY(launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, M, N, cells, false, 0, 1, 0));
     CRM_HIP(hipStreamSynchronize(ctx->stream));  // the problem record is reused by the next call
     return CRM_OK;
 }

@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "../../include/crm_hip.h"
+#include "../../include/crm_hip_test.h"
+
+struct crm_ctx;
 
 namespace crm {
 
@@ -63,18 +66,23 @@ constexpr int GEMM_BK = 16;
 // Launch nz problems (device array `probs`), each over `cells` (multiple of GEMM_BK)
 // rows, optionally split into `ksplit` slices along the cell axis (slice s writes
 // C + s * split_stride; reduce with reduce_splits).
-int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
+// Per-context choice of the contraction kernel variant (defaults = what the scan uses; the unit tests
+// and tools/gemm_bench force the others through include/crm_hip_test.h).
+struct GemmTune {
+    int bn = 0;         // output-tile width: 0 = chosen per launch, else 64 or 128
+    int glds = 1;       // 128-wide tiles / Khatri-Rao launches through the LDS-DMA kernel (gemm_tn_glds.hip)
+    int sync = 0;       // > 0: large Khatri-Rao launches as 8 x 64 persistent workgroups re-aligned every `sync` generations
+    int shared_h = -1;  // multi-gene scan: -1 cost model, 0 never, 1 always contract once per variant against H
+};
+int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
 // number of slices along the cell axis for a launch that would otherwise have `blocks_without_split` workgroups
 int split_for(long cells_pad, long blocks_without_split);
-extern int g_contraction_bn;
-extern int g_contraction_glds;
-extern int g_contraction_sync;
-int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
+int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out = false,
                         int bn = 128);
 // Khatri-Rao contraction storing C' (N x M, leading dimension ldc): always the LDS-DMA kernel
-int launch_kr_transposed(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
+int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0);
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
 

@@ -45,6 +45,8 @@ struct crm_ctx {
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
+    crm::GemmTune tune;   // contraction kernel variant (test hooks only change it)
+    crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -53,6 +55,6 @@ struct crm_ctx {
     // scan workspace (grown on demand, reused across calls)
     crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&sync_counters, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };

@@ -155,7 +155,7 @@ extern "C" int crm_cov_solve(crm_background* bg, int rho_index, double v0, doubl
         p.Y = bg->Q0[rho_index].as<double>(); p.ldy = ldq;
         p.C = d_T.as<double>(); p.ldc = ldq; p.M = m; p.N = r;
         CRM_HIP(hipMemcpyAsync(d_prob.ptr, &p, sizeof p, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_prob.as<GemmProblem>(), 1, m, (int)ldq, np, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_prob.as<GemmProblem>(), 1, m, (int)ldq, np, false, 0, 1, 0));
         hipLaunchKernelGGL(shrink_rotation_kernel, dim3((r + 255) / 256), dim3(256), 0, st, d_T.as<double>(), ldq,
                            m, bg->S0[rho_index].as<double>(), r, v0, v1);
         CRM_HIP(hipGetLastError());

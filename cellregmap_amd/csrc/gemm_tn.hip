@@ -15,7 +15,7 @@
 // while the current one feeds the matrix pipe.  Operand tiles are stored [stage row][column]
 // with a row stride of 144 doubles (= 128 B mod 256 B) so that the four 16-lane groups of a
 // ds_read_b64 fragment read hit disjoint bank halves.
-#include "crm_common.h"
+#include "crm_internal.h"
 
 namespace crm {
 
@@ -257,9 +257,6 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
     C[i] = s;
 }
 
-int g_contraction_glds = 1;  // 128-wide tiles through the LDS-DMA kernel (gemm_tn_glds.hip)
-int g_contraction_bn = 0;  // output-tile width override: 0 = choose per launch, else 64 or 128
-
 int split_for(long cells_pad, long blocks_without_split) {
     // enough workgroups to cover the 256 CUs twice, at least eight stages per slice, every slice non-empty
     const long stages = cells_pad / GEMM_BK;
@@ -270,20 +267,21 @@ int split_for(long cells_pad, long blocks_without_split) {
     return (int)((stages + per - 1) / per);
 }
 
-int launch_kr_transposed(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
+int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
     if (cells % GEMM_BK != 0 || k0 < 1 || k0 > 128) {
         set_error("transposed Khatri-Rao contraction: cells=%ld, k0=%d", cells, k0);
         return CRM_ERR_ARG;
     }
-    return launch_gemm_tn_glds(st, probs_dev, nz, (max_m + GEMM_BM - 1) / GEMM_BM, (max_n + 127) / 128, cells, true,
+    return launch_gemm_tn_glds(ctx, probs_dev, nz, (max_m + GEMM_BM - 1) / GEMM_BM, (max_n + 127) / 128, cells, true,
                                k0, 1, 0, true);
 }
 
-int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
+int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
+    hipStream_t st = ctx->stream;
     if (ksplit < 1) ksplit = 1;
     // slices of ceil(stages / ksplit) stages; every slice must hold at least one (see split_for)
     const long total_stages = cells / GEMM_BK;
@@ -296,7 +294,7 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
     // 128-wide tiles (two workgroups per CU) give the Khatri-Rao operand the most MFMAs per LDS read
     // (62.2 vs 60.1 TFLOP/s at config 3); 64-wide tiles (three per CU) fill the chip better when a
     // launch has few tiles (skinny side contractions: 50.5 vs 42.1 TFLOP/s at M = 1024, N = 5120)
-    int bn = g_contraction_bn;
+    int bn = ctx->tune.bn;
     if (bn != 64 && bn != 128) {
         const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
         bn = tiles128 < 1024 ? 64 : 128;
@@ -304,12 +302,12 @@ int launch_gemm_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max
         if (khatri_rao && ((max_n + 63) / 64) * 64 * 100 <= ((max_n + 127) / 128) * 128 * 85) bn = 64;
     }
     const int nt = (max_n + bn - 1) / bn;
-    if (g_contraction_glds && (bn == 128 || khatri_rao)) {
+    if (ctx->tune.glds && (bn == 128 || khatri_rao)) {
         if (khatri_rao && (k0 < 1 || k0 > 128)) {
             set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
             return CRM_ERR_UNSUPPORTED;
         }
-        return launch_gemm_tn_glds(st, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride, false, bn);
+        return launch_gemm_tn_glds(ctx, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride, false, bn);
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
     size_t lds = (size_t)2 * GEMM_BK * (bn + 16) * sizeof(double);

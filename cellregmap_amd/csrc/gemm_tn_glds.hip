@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "crm_common.h"
+#include "crm_internal.h"
 
 namespace crm {
 
@@ -205,9 +205,6 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         }
     };
     auto finish = [&](double (&a)[MT], const double (&e)[MT]) __attribute__((always_inline)) {
-#ifdef CRM_EXP_NOMUL
-        return;
-#endif
         if (KR) {
 #pragma unroll
             for (int t = 0; t < MT; t++) a[t] *= e[t];
@@ -265,9 +262,7 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         using Other = std::integral_constant<int, BUF ^ 1>;
         const bool more = s + 1 < stages;
         // buffer BUF^1 was last read before the barrier of the previous stage: free for the DMA now
-#ifndef CRM_EXP_NODMA
         if (more) issue(BUF ^ 1, s + 1);
-#endif
         load_raw(buf_tag, K1{}, fa[1], fe, fb[1]);
         mma(fa[0], fb[0]);
         finish(fa[1], fe);
@@ -282,9 +277,7 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         interleave();
         // every read of this buffer has been issued; the next stage's tiles must have landed
         if (more) stash_g(BUF ^ 1);
-#ifndef CRM_EXP_NOBARRIER
         __syncthreads();
-#endif
         // (after the last stage these reads fetch stale tiles of the other buffer; nothing uses them)
         load_raw(Other{}, K0{}, fa[0], fe, fb[0]);
         mma(fa[1], fb[1]);
@@ -383,10 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmPro
     }
 }
 
-int g_contraction_sync = 0;
-static unsigned* g_sync_counters = nullptr;
-
-int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
+int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out, int bn) {
     if (bn != 128 && !(bn == 64 && khatri_rao && !transposed_out)) {
         set_error("contraction: %d-wide LDS-DMA tiles are not built for this form", bn);
@@ -396,11 +386,15 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         set_error("contraction: the transposed store is only built for the Khatri-Rao form");
         return CRM_ERR_UNSUPPORTED;
     }
+    hipStream_t st = ctx->stream;
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
-    const bool sync = g_contraction_sync && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024;
+    const int sync_every = ctx->tune.sync;
+    const bool sync = sync_every > 0 && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024;
+    unsigned* sync_counters = nullptr;
     if (sync) {
-        if (!g_sync_counters) CRM_HIP(hipMalloc(&g_sync_counters, 64));
-        CRM_HIP(hipMemsetAsync(g_sync_counters, 0, 64, st));
+        CRM_TRY(ctx->sync_counters.ensure(64));
+        sync_counters = ctx->sync_counters.as<unsigned>();
+        CRM_HIP(hipMemsetAsync(sync_counters, 0, 64, st));
     }
     const long cps = (cells / GEMM_BK + ksplit - 1) / ksplit * GEMM_BK;  // validated by launch_gemm_tn
     size_t lds = (size_t)2 * GEMM_BK * bn * sizeof(double);
@@ -415,7 +409,7 @@ int launch_gemm_tn_glds(hipStream_t st, const GemmProblem* probs_dev, int nz, in
         if (sync && small)                                                                                    \
             hipLaunchKernelGGL((gemm_tn_glds_sync_kernel<true, 1, Q, T>), dim3(512), dim3(256), lds, st,      \
                                probs_dev, mt, mt * nt, ksplit, nz, cps, cells, split_stride, k0,              \
-                               g_sync_counters, g_contraction_sync);                                          \
+                               sync_counters, sync_every);                                          \
         else if (small)                                                                                       \
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, T>), grid, dim3(256), lds, st, probs_dev, mt, \
                                cps, cells, split_stride, k0);                                             \

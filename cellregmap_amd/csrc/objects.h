@@ -60,6 +60,7 @@ struct crm_gene {
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
     unsigned long e0_key = 0;    // content hash of E0 (key of the background's shared donor tables)
+    unsigned long w_key = 0;     // content hash of W (genes of one multi-gene pass must agree on it)
     unsigned long dt_group = 0;  // donor structure (panel group_key) dt_Z1 / dt_sums were built for (0 = none)
     crm_donor_tables dt_own;     // phenotype-free tables under a permutation hook (not shareable)
     crm::DevBuf dt_Z1;    // [m_pad x ld]     Z'[y o E, W o E]

@@ -162,6 +162,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     g->c = c;
     g->k0 = k0;
     g->e0_key = content_key(E0, sizeof(double) * (size_t)bg->n * k0, (unsigned long)k0);
+    g->w_key = content_key(W, sizeof(double) * (size_t)bg->n * c, (unsigned long)c);
     g->ldw = 16;
     g->lde = round_up(k0, 16);
     int rc = CRM_OK;
@@ -218,7 +219,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, ctx->stream));
     // splits write slabs nrho*slab apart
     CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho * ks, ctx->stream));
-    if ((rc = launch_gemm_tn(ctx->stream, ctx->ws_probs.as<GemmProblem>(), nrho, 1 + c, (int)ldq, np, false, 0, ks, slab * nrho)) != CRM_OK) return fail(rc);
+    if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), nrho, 1 + c, (int)ldq, np, false, 0, ks, slab * nrho)) != CRM_OK) return fail(rc);
     if ((rc = launch_reduce_splits(ctx->stream, g->rot.as<double>(), slab * nrho, ks, slab * nrho)) != CRM_OK) return fail(rc);
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = g;
@@ -454,7 +455,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
             probs[i] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m, (int)ldq, np, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs, nrho, (int)m, (int)ldq, np, false, 0, 1, 0));
         CRM_HIP(hipStreamSynchronize(st));
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
@@ -465,7 +466,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
             probs[i] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, nrho, (int)m * k0, (int)ldq, np, true, k0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs, nrho, (int)m * k0, (int)ldq, np, true, k0, 1, 0));
         CRM_HIP(hipStreamSynchronize(st));
     }
     // side tables (split over the cell axis: only one M tile)
@@ -485,7 +486,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
         p.Y = d_Ep; p.ldy = gene->ld_ep; p.C = shared->Z2.as<double>(); p.ldc = ldZ2;
         p.M = (int)rows; p.N = k0;
         CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)rows, k0, np, true, (int)m, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)rows, k0, np, true, (int)m, 1, 0));
         CRM_HIP(hipStreamSynchronize(st));
     }
     for (auto& sd : side) {
@@ -498,7 +499,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
         p.X = Zt; p.ldx = panel->ldz; p.Y = sd.Y; p.ldy = sd.ldy; p.C = sd.buf->as<double>(); p.ldc = sd.ld;
         p.M = (int)m; p.N = sd.N;
         CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)m, sd.N, np, false, 0, ks, sz));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)m, sd.N, np, false, 0, ks, sz));
         CRM_TRY(launch_reduce_splits(st, sd.buf->as<double>(), sz, ks, sz));
         CRM_HIP(hipStreamSynchronize(st));
     }
@@ -530,8 +531,6 @@ struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: co
 // on the phenotype is done once per block: the block copies, T(rho) = G'Q0(rho), the Khatri-Rao
 // contraction per (variant, rho) pair that at least one gene selected, and the y-free side
 // contractions.  Per gene: g'y, the null fits, E'(g o y), assembly, eigenvalues and Davies.
-int g_shared_h_mode = -1;  // test hook: -1 cost model, 0 never, 1 whenever the background offers H
-
 static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
                      const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs) {
     const int ng = (int)genes.size();
@@ -555,8 +554,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         return CRM_ERR_ARG;
     }
     for (crm_gene* g : genes) {
-        if (g->bg != bg || g->c != g0->c || g->k0 != g0->k0) {
-            set_error("scan: genes of one call must share the background, W and E0");
+        // the shared pass computes g'W, the context features and the donor tables once, from the first
+        // gene's W and E0: the others must hold the same values, not just the same shapes
+        if (g->bg != bg || g->c != g0->c || g->k0 != g0->k0 || g->w_key != g0->w_key || g->e0_key != g0->e0_key) {
+            set_error("scan: genes of one call must share the background, W and E0 (contents, not only shapes)");
             return CRM_ERR_ARG;
         }
     }
@@ -807,7 +808,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
             p.C = ctx->ws_TH.as<double>(); p.ldc = ldb; p.M = (int)bg->cols; p.N = nb;
             CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_gemm_tn(st, d_probs, 1, (int)bg->cols, nb, np, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)bg->cols, nb, np, false, 0, 1, 0));
         }
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
@@ -823,7 +824,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             probs[i] = p;
         }
         CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(st, d_probs + 1, nrho, nb, (int)ldq, fastT ? bg->ldh : xrows, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, nrho, nb, (int)ldq, fastT ? bg->ldh : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
@@ -879,7 +880,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 direct += (double)cnt[i] * bg->r[i] * (double)n;
                 via += (double)cnt[i] * bg->r[i] * (double)bg->ldh;
             }
-            via_H = g_shared_h_mode < 0 ? via < 0.9 * direct : g_shared_h_mode > 0;
+            via_H = ctx->tune.shared_h < 0 ? via < 0.9 * direct : ctx->tune.shared_h > 0;
         }
         int nz = 0, max_m = 0, max_n = 1;
         double kr_flops = 0.0;
@@ -910,7 +911,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             max_n = std::max(max_n, p.N);
             probs[nz++] = p;
         }
-        if (ctx->timing) {
+        const bool timing = ctx->timing && ctx->timed_used < 65536;  // bounded: a forgotten timer cannot grow for ever
+        if (timing) {
             if (ctx->timed_used == ctx->timed.size()) {
                 hipEvent_t a, b;
                 CRM_HIP(hipEventCreate(&a));
@@ -926,7 +928,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.C = ctx->ws_AH.as<double>(); p.ldc = ld_ah;
             p.M = nb * k0; p.N = (int)bg->cols;
             CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_kr_transposed(st, d_probs, 1, p.M, p.N, np, k0));
+            CRM_TRY(launch_kr_transposed(ctx, d_probs, 1, p.M, p.N, np, k0));
             kr_flops += 2.0 * (double)n * (double)bg->cols * (double)k0 * (double)nb;
             const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
             CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
@@ -934,12 +936,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
         if (collapsed)
-            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
         else if (via_H)
-            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
         else
-            CRM_TRY(launch_gemm_tn(st, d_probs, nz, max_m, max_n, np, true, k0, 1, 0));
-        if (ctx->timing) {
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, 1, 0));
+        if (timing) {
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
             ctx->timed_used++;
             ctx->kr_flops += kr_flops;
@@ -964,10 +966,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                                    tab->Z2.as<double>(), ldZ2, k0, dZ2, ldZ2);
                 CRM_HIP(hipGetLastError());
             } else {
-                CRM_TRY(launch_gemm_tn(st, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
+                CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, 1, nb, k0, xrows, false, 0, s2, z2_sz));
                 CRM_TRY(launch_reduce_splits(st, dZ2, z2_sz, s2, z2_sz));
             }
-            CRM_TRY(launch_gemm_tn(st, d_probs + 2, 1, nb, npair, xrows, false, 0, s3, z3_sz));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs + 2, 1, nb, npair, xrows, false, 0, s3, z3_sz));
             CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, s3, z3_sz));
         }
         // 9.-11. per gene: Z1 = Gt' [y o E, W o E], Q and F, eigenvalues + Davies, results
@@ -979,7 +981,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.X = Gt; p.ldx = ldb; p.Y = collapsed ? g->dt_Z1.as<double>() : g->YE.as<double>(); p.ldy = g->ld_ye;
                 p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
                 CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-                CRM_TRY(launch_gemm_tn(st, d_probs, 1, nb, k0 * (1 + c), xrows, false, 0, s1, z1_sz));
+                CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, nb, k0 * (1 + c), xrows, false, 0, s1, z1_sz));
                 CRM_TRY(launch_reduce_splits(st, dZ1, z1_sz, s1, z1_sz));
             }
             AssembleArgs aa{};
@@ -1036,8 +1038,9 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
 }
 
-int crm_test_set_shared_h(int mode) {
-    crm::g_shared_h_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
+    if (!ctx) return CRM_ERR_ARG;
+    ctx->tune.shared_h = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
     return CRM_OK;
 }
 

@@ -153,33 +153,9 @@ int crm_set_null_fit_polish(crm_ctx* ctx, int on);
 int crm_kernel_timer_reset(crm_ctx* ctx);
 int crm_kernel_timer_read(crm_ctx* ctx, double* kr_ms, long* kr_launches, double* kr_flops,
                           double* total_ms);
-
-/* ---- unit-test hooks (exercise single kernels through the same ABI) --------------------
- * Contraction kernel variant for subsequent launches (process-wide): tile_width 0 = chosen per
- * launch, 64 or 128 forced; lds_dma = 1 lets 128-wide launches use the direct-to-LDS kernel. */
-int crm_test_set_contraction(int tile_width, int lds_dma);
-/* every > 0: Khatri-Rao launches of more than 1024 tiles run as 8 x 64 persistent workgroups that walk
- * contiguous tile runs per XCD and re-align (bounded wait) every `every` generations -- 5x less L2-fabric
- * traffic, 0.7 % slower; 0 (default): one workgroup per tile. */
-int crm_test_set_contraction_sync(int every);
-/* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
-int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
-                      double* C, int ksplit);
-/* C ((B*k0) x N) = KR(G, E)' Y with G: cells x B, E: cells x k0, Y: cells x N. */
-int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
-                         const double* E, const double* Y, double* C);
-/* Route of the multi-gene scan's contraction: -1 (default) cost model, 0 always per (variant, rho)
- * pair against Q0(rho), 1 once per variant against H followed by Mix(rho) per pair (when the
- * background keeps H). */
-int crm_test_set_shared_h(int mode);
-/* The same product stored transposed: CT (N x (B*k0)). */
-int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
-                           const double* E, const double* Y, double* CT);
-/* Eigenvalues (ascending) of `count` symmetric k x k matrices (lower triangle read). */
-int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* lambda);
-/* Davies/Liu p-values for `count` (Q, lambda[k]) pairs after the eigenvalue filter. */
-int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const double* lambda,
-                    double* pvalue, int* ifault, double* liu);
+/* Stop recording (scans after this call create no further events; what was recorded stays readable
+ * until the next reset).  Recording also stops by itself after 65536 launches. */
+int crm_kernel_timer_stop(crm_ctx* ctx);
 
 #ifdef __cplusplus
 }

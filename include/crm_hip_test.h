@@ -1,0 +1,42 @@
+/* Unit-test hooks of libcrm_hip.so: single kernels exercised through the same C-ABI, and the knobs
+ * that force a kernel variant.  Not part of the drop-in boundary (include/crm_hip.h); every knob lives in
+ * the context it is given, so distinct contexts stay independent. */
+#ifndef CRM_HIP_TEST_H
+#define CRM_HIP_TEST_H
+
+#include "crm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Contraction kernel variant for subsequent launches on this context: tile_width 0 = chosen per
+ * launch, 64 or 128 forced; lds_dma = 1 lets 128-wide launches use the direct-to-LDS kernel. */
+int crm_test_set_contraction(crm_ctx* ctx, int tile_width, int lds_dma);
+/* every > 0: Khatri-Rao launches of more than 1024 tiles run as 8 x 64 persistent workgroups that walk
+ * contiguous tile runs per XCD and re-align (bounded wait) every `every` generations -- 5x less L2-fabric
+ * traffic, 0.7 % slower; 0 (default): one workgroup per tile. */
+int crm_test_set_contraction_sync(crm_ctx* ctx, int every);
+/* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
+int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
+                      double* C, int ksplit);
+/* C ((B*k0) x N) = KR(G, E)' Y with G: cells x B, E: cells x k0, Y: cells x N. */
+int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
+                         const double* E, const double* Y, double* C);
+/* Route of the multi-gene scan's contraction: -1 (default) cost model, 0 always per (variant, rho)
+ * pair against Q0(rho), 1 once per variant against H followed by Mix(rho) per pair (when the
+ * background keeps H). */
+int crm_test_set_shared_h(crm_ctx* ctx, int mode);
+/* The same product stored transposed: CT (N x (B*k0)). */
+int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
+                           const double* E, const double* Y, double* CT);
+/* Eigenvalues (ascending) of `count` symmetric k x k matrices (lower triangle read). */
+int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* lambda);
+/* Davies/Liu p-values for `count` (Q, lambda[k]) pairs after the eigenvalue filter. */
+int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const double* lambda,
+                    double* pvalue, int* ifault, double* liu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRM_HIP_TEST_H */

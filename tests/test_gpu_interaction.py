@@ -224,7 +224,7 @@ def test_shared_h_route_of_the_multi_gene_scan():
     """With Q0(rho) = H Mix(rho) the n-length Khatri-Rao contraction can be done once per variant
     against H and finished per (variant, rho*) pair with Mix(rho*): same null fits (bit-identical
     info), score statistics equal to rounding."""
-    from cellregmap_amd import CellRegMap, GenotypePanel, _lib, get_L_values, scan_interaction_many
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values, scan_interaction_many
     from cellregmap_amd.synth import make_cohort
 
     c = make_cohort(8, 25, 4, 70, seed=41)
@@ -238,14 +238,14 @@ def test_shared_h_route_of_the_multi_gene_scan():
     out = {}
     try:
         for mode in (0, 1):
-            _lib.check(lib.crm_test_set_shared_h(mode))
+            _lib.check(lib.crm_test_set_shared_h(_engine._context(0), mode))
             for name, kw in (("plain", {}), ("idx_E", {"idx_E": rng.permutation(c.y.size)}),
                              ("idx_G", {"idx_G": np.random.default_rng(3).permutation(c.y.size)})):
                 if name == "idx_E":
                     kw = {"idx_E": np.random.default_rng(5).permutation(c.y.size)}
                 out[mode, name] = scan_interaction_many(crms, panel, **kw)
     finally:
-        _lib.check(lib.crm_test_set_shared_h(-1))
+        _lib.check(lib.crm_test_set_shared_h(_engine._context(0), -1))
     for name in ("plain", "idx_E", "idx_G"):
         (pv0, info0), (pv1, info1) = out[0, name], out[1, name]
         for k in info0:

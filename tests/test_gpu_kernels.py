@@ -28,10 +28,10 @@ VARIANTS = [(0, 1), (64, 0), (128, 0), (128, 1), (64, 1)]
 def variant(request, ctx):
     from cellregmap_amd import _lib
 
-    lib, _ = ctx
-    _lib.check(lib.crm_test_set_contraction(*request.param))
+    lib, h = ctx
+    _lib.check(lib.crm_test_set_contraction(h, *request.param))
     yield request.param
-    _lib.check(lib.crm_test_set_contraction(0, 1))
+    _lib.check(lib.crm_test_set_contraction(h, 0, 1))
 
 
 def _contract(ctx, X, Y, ksplit=1):
@@ -98,12 +98,12 @@ def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
     E = rng.normal(size=(cells, k0))
     Y = rng.normal(size=(cells, N))
     C = np.empty((B * k0, N))
-    _lib.check(lib.crm_test_set_contraction(0, 1))
-    _lib.check(lib.crm_test_set_contraction_sync(every))
+    _lib.check(lib.crm_test_set_contraction(h, 0, 1))
+    _lib.check(lib.crm_test_set_contraction_sync(h, every))
     try:
         _lib.check(lib.crm_test_contract_kr(h, cells, B, k0, N, _lib.ptr(G), _lib.ptr(E), _lib.ptr(Y), _lib.ptr(C)))
     finally:
-        _lib.check(lib.crm_test_set_contraction_sync(0))
+        _lib.check(lib.crm_test_set_contraction_sync(h, 0))
     KR = (G[:, :, None] * E[:, None, :]).reshape(cells, B * k0)
     assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
 

@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "../cellregmap_amd/csrc/crm_common.h"
+#include "../cellregmap_amd/csrc/crm_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -35,8 +35,9 @@ __global__ void fill(double* p, long n, unsigned seed) {
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    hipStream_t st;
-    CK(hipStreamCreate(&st));
+    crm_ctx* ctx = nullptr;
+    if (crm_ctx_create(0, &ctx) != CRM_OK) { printf("no context: %s\n", crm_last_error()); return 1; }
+    hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -55,18 +56,18 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill, dim3((cells * 64 + 255) / 256), dim3(256), 0, st, E, cells * 64, 3u);
     crm::GemmProblem* pd;
     CK(hipMalloc(&pd, sizeof(crm::GemmProblem)));
-    if (argc > 1) crm::g_contraction_bn = atoi(argv[1]);
-    if (argc > 2) crm::g_contraction_glds = atoi(argv[2]);
-    if (argc > 3) crm::g_contraction_sync = atoi(argv[3]);
-    printf("tile width %d\n", crm::g_contraction_bn);
+    if (argc > 1) ctx->tune.bn = atoi(argv[1]);
+    if (argc > 2) ctx->tune.glds = atoi(argv[2]);
+    if (argc > 3) ctx->tune.sync = atoi(argv[3]);
+    printf("tile width %d\n", ctx->tune.bn);
     for (int B : Bs) {
         // plain: T = G' Q0  (M = B, N = r)
         crm::GemmProblem p{};
         p.X = G; p.Y = Q0; p.C = C; p.ldx = GLD; p.ldy = r; p.ldc = r; p.M = B; p.N = (int)r;
         CK(hipMemcpy(pd, &p, sizeof p, hipMemcpyHostToDevice));
-        crm::launch_gemm_tn(st, pd, 1, B, (int)r, cells, false, 0, 1, 0);
+        crm::launch_gemm_tn(ctx, pd, 1, B, (int)r, cells, false, 0, 1, 0);
         CK(hipEventRecord(e0, st));
-        crm::launch_gemm_tn(st, pd, 1, B, (int)r, cells, false, 0, 1, 0);
+        crm::launch_gemm_tn(ctx, pd, 1, B, (int)r, cells, false, 0, 1, 0);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -74,9 +75,9 @@ int main(int argc, char** argv) {
         // KR: A = KR(G, E)' Q0   (M = B*k0, N = r)
         p.E = E; p.lde = 64; p.M = B * k0; p.k0 = k0;
         CK(hipMemcpy(pd, &p, sizeof p, hipMemcpyHostToDevice));
-        crm::launch_gemm_tn(st, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
+        crm::launch_gemm_tn(ctx, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
         CK(hipEventRecord(e0, st));
-        crm::launch_gemm_tn(st, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
+        crm::launch_gemm_tn(ctx, pd, 1, B * k0, (int)r, cells, true, k0, 1, 0);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
