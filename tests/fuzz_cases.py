@@ -1,0 +1,58 @@
+"""Seeded random problems shared by the CPU spread test, the GPU fuzz test and tools/fuzz_scan.py
+(plain helper module, not a test)."""
+import numpy as np
+
+
+def random_problem(n, k0, c, p, donors, seed, mode):
+    """Cohort with ragged donors, normal contexts / covariates, donor-constant genotypes and a
+    phenotype with a persistent and a GxC effect; ``mode``: background A / B / C
+    (cellregmap/_cellregmap.py:101-131)."""
+    rng = np.random.default_rng(seed)
+    donor = np.sort(rng.integers(0, donors, size=n))
+    donor[:donors] = np.arange(donors)
+    donor = np.sort(donor)
+    Gd = rng.normal(size=(donors, p))
+    G = Gd[donor]
+    E = rng.normal(size=(n, k0))
+    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, c - 1))], axis=1) if c > 1 else np.ones((n, 1))
+    hK = np.zeros((n, donors))
+    hK[np.arange(n), donor] = 1.0
+    y = 0.4 * G[:, 0] + 0.5 * (G[:, 1 % p] * E[:, 0]) + E @ rng.normal(size=k0) * 0.3 + rng.normal(size=n)
+    kw = {}
+    if mode == "B":
+        kw["hK"] = hK
+    elif mode == "C":
+        kw["Ls"] = [E[:, [i]] * hK for i in range(k0)]
+    return y, E, W, G, kw
+
+
+def fuzz_cases(count, seed=7, max_cells=600, max_contexts=128, max_variants=70, wide_covariates=True):
+    """``count`` problem descriptions (i, n, k0, c, p, donors, mode, perm) drawn from one seeded stream:
+    30..max_cells cells, 1..max_contexts contexts (1..8 in mode C), 1..14 covariate columns (1..8
+    without ``wide_covariates``: the null-fit polish is built for the register kernel only), the three
+    background modes, no / context / genotype permutation hook."""
+    rng = np.random.default_rng(seed)
+    covs = [1, 1, 1, 2, 3, 5, 8, 9, 14] if wide_covariates else [1, 1, 1, 2, 3, 5, 8]
+    out = []
+    i = 0
+    while len(out) < count:
+        mode = "ABC"[int(rng.integers(0, 3))]
+        n = int(rng.integers(30, max_cells))
+        k0 = int(rng.integers(1, max_contexts + 1)) if mode != "C" else int(rng.integers(1, 9))
+        c = int(rng.choice(covs))
+        p = int(rng.integers(1, max_variants))
+        donors = int(rng.integers(2, 14))
+        perm = ["none", "E", "G"][int(rng.integers(0, 3))]
+        i += 1
+        if k0 + c + 2 > 144 or n <= c + 2 or donors > n:
+            continue
+        out.append((i - 1, n, k0, c, p, donors, mode, perm))
+    return out
+
+
+def build_case(case):
+    i, n, k0, c, p, donors, mode, perm = case
+    y, E, W, G, kw = random_problem(n, k0, c, p, donors, seed=5000 + i, mode=mode)
+    idx = np.random.default_rng(i).permutation(n)
+    hooks = {} if perm == "none" else ({"idx_E": idx} if perm == "E" else {"idx_G": idx})
+    return y, E, W, G, kw, hooks

@@ -358,3 +358,138 @@ def test_shared_donor_tables_follow_contexts_and_donor_structure():
     # and back: a third distinct (E0, grouping) pair evicts the least recently used entry
     assert close(second.scan_interaction(GenotypePanel(G1))[0], dense(y2, c.E, G1))
     assert close(third.scan_interaction(GenotypePanel(G2))[0], dense(c.y, E_alt, G2))
+
+
+@pytest.mark.parametrize("genotypes", ["dense", "donor-collapsed"])
+def test_many_phenotypes_against_the_oracle(genotypes):
+    """``scan_interaction_many`` / ``run_interaction_many`` against the ORACLE gene by gene (the per-gene
+    calls of cellregmap/_cellregmap.py:547-587), not against the device's own single-gene scan."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, run_interaction_many, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    c = make_cohort(8, 25, 4, 40, seed=43)
+    n = c.y.size
+    rng = np.random.default_rng(11)
+    Y = np.stack([c.y, c.y[rng.permutation(n)], rng.normal(size=n), c.y + rng.normal(size=n), 3.0 - 2.0 * c.y], axis=1)
+    W = np.concatenate([c.W, rng.normal(size=(n, 1))], axis=1)
+    G = c.G if genotypes == "donor-collapsed" else c.G + 0.05 * rng.normal(size=c.G.shape)  # general genotypes
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(Y[:, 0], c.E, W=W, Ls=Ls)
+    crms = [first] + [CellRegMap(Y[:, i], c.E, W=W, Ls=Ls, background=first._bg) for i in range(1, Y.shape[1])]
+    panel = GenotypePanel(G)
+    assert (panel.n_groups is not None) == (genotypes == "donor-collapsed")
+    oLs = ocrm.khatri_rao_halves(c.hK, c.E)
+    for hooks in ({}, {"idx_E": rng.permutation(n)}, {"idx_G": rng.permutation(n)}):
+        pv, info = scan_interaction_many(crms, panel, **hooks)
+        for i in range(Y.shape[1]):
+            opv, oinfo = ocrm.OracleCellRegMap(Y[:, i], c.E, W=W, Ls=oLs).scan_interaction(G, **hooks)
+            assert_allclose(info["rho1"][i], oinfo["rho1"], atol=1e-12)
+            for k in ("e2", "g2", "eps2"):
+                assert_allclose(info[k][i], oinfo[k], rtol=1e-5, atol=1e-12)
+            assert np.all(np.abs(pv[i] - opv) <= P_RTOL * opv + P_ATOL), (i, np.c_[pv[i], opv])
+    # the functional wrapper: one run_interaction per column of Y
+    pv2, info2 = run_interaction_many(Y, c.E, G, W=W, hK=c.hK)
+    for i in range(Y.shape[1]):
+        opv, oinfo = ocrm.run_interaction(Y[:, i], c.E, G, W=W, hK=c.hK)
+        assert_allclose(info2["rho1"][i], oinfo["rho1"], atol=1e-12)
+        assert np.all(np.abs(pv2[i] - opv) <= P_RTOL * opv + P_ATOL)
+
+
+def test_many_phenotypes_must_share_covariates_and_contexts_by_content():
+    """Same shapes are not enough: the shared pass takes g'W and the context features from the first
+    object (advisor finding, round 1)."""
+    import ctypes
+
+    from cellregmap_amd import CellRegMap, GenotypePanel, _lib, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 20, 3, 12, seed=47)
+    rng = np.random.default_rng(2)
+    W2 = np.concatenate([c.W, rng.normal(size=(c.y.size, 1))], axis=1)
+    W3 = np.concatenate([c.W, rng.normal(size=(c.y.size, 1))], axis=1)
+    a = CellRegMap(c.y, c.E, W=W2, hK=c.hK)
+    b = CellRegMap(c.y[::-1].copy(), c.E, W=W3, hK=c.hK, background=a._bg)
+    with pytest.raises(ValueError, match="same covariates"):
+        scan_interaction_many([a, b], c.G)
+    e = CellRegMap(c.y, c.E[::-1].copy(), W=W2, E1=c.E, hK=c.hK, background=a._bg)
+    with pytest.raises(ValueError, match="same contexts"):
+        scan_interaction_many([a, e], c.G)
+    # and the C-ABI refuses it too
+    lib = _lib.load()
+    panel = GenotypePanel(c.G)
+    handles = (ctypes.c_void_p * 2)(a._bind_gene().value, b._bind_gene().value)
+    out = np.empty((2, 12))
+    rc = lib.crm_scan_interaction_multi(handles, 2, panel.handle, 0, 12, None, None, _lib.ptr(out), None, None, None,
+                                        None, None)
+    assert rc == -2 and b"contents" in lib.crm_last_error()
+
+
+def test_boolean_permutation_index_selects_rows_like_numpy():
+    """A boolean idx_E / idx_G is a mask (numpy's ``E0[idx, :]``): with all entries True it is the identity,
+    in the single-gene and in the multi-gene entry point alike."""
+    from cellregmap_amd import CellRegMap, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 20, 3, 10, seed=48)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    ref, _ = crm.scan_interaction(c.G)
+    mask = np.ones(c.y.size, bool)
+    assert np.array_equal(crm.scan_interaction(c.G, idx_E=mask)[0], ref)
+    assert np.array_equal(scan_interaction_many([crm], c.G, idx_G=mask)[0][0], ref)
+    with pytest.raises(ValueError):
+        crm.scan_interaction(c.G, idx_E=mask[:-1])
+
+
+def _decaying_cohort(n, k, m, p, seed, decades=6.0):
+    """Ill-conditioned background: kinship factor hK = U diag(sigma) with sigma over `decades` decades (so the
+    spectrum S0 of K spans twice that), contexts strongly correlated with each other (condition number
+    ~1e4) -- the shape real kinship factors and principal-component contexts have, unlike the N(0,1)
+    contexts and donor indicators of the other cohorts."""
+    rng = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(rng.normal(size=(n, m)))
+    hK = U * np.logspace(0.0, -decades, m)
+    Z = rng.normal(size=(n, k))
+    mix = np.linalg.qr(rng.normal(size=(k, k)))[0] * np.logspace(0.0, -2.0, k)  # column scales 1 .. 1e-2
+    E = Z @ mix @ rng.normal(size=(k, k))
+    E = (E - E.mean(0)) / E.std(0)
+    G = rng.normal(size=(n, p))
+    W = np.ones((n, 1))
+    y = 0.5 * G[:, 0] * E[:, 0] + E @ rng.normal(size=k) * 0.3 + hK @ rng.normal(size=m) * 3.0 + rng.normal(size=n)
+    return y, E, W, G, hK
+
+
+@pytest.mark.parametrize("mode", ["B-thin", "C-thin", "C-eigh"])
+def test_decaying_spectrum_background(mode):
+    """Parity on an ill-conditioned background (the Gram route of the thin branch squares the condition
+    number; the kept spectrum is far beyond S_max <= 1e6 S_min, so the scan must take the direct
+    rotations G'Q0(rho) instead of the mixing matrices)."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
+    from oracle.crm import OracleCellRegMap, khatri_rao_halves
+
+    if mode == "B-thin":
+        y, E, W, G, hK = _decaying_cohort(400, 5, 24, 20, seed=1)
+        kw, okw = {"hK": hK}, {"hK": hK}
+    elif mode == "C-thin":      # cols = 3 + 3 * 12 = 39 < n
+        y, E, W, G, hK = _decaying_cohort(300, 3, 12, 20, seed=2)
+        kw, okw = {"Ls": get_L_values(hK, E)}, {"Ls": khatri_rao_halves(hK, E)}
+    else:                       # cols = 6 + 6 * 40 = 246 >= n = 200: the reference's eigh branch
+        y, E, W, G, hK = _decaying_cohort(200, 6, 40, 20, seed=3, decades=4.0)
+        kw, okw = {"Ls": get_L_values(hK, E)}, {"Ls": khatri_rao_halves(hK, E)}
+    crm = CellRegMap(y, E, W=W, **kw)
+    o = OracleCellRegMap(y, E, W=W, **okw)
+    S0 = o._qs[0.5][1]
+    kept = S0[S0 > 1e-12 * S0.max()]
+    assert kept.max() > 1e7 * kept.min()          # really ill-conditioned
+    pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=None), return_stats=True)
+    opv, oinfo, ost = o.scan_interaction(G, return_stats=True)
+    _compare(pv, info, st, opv, oinfo, ost)
+    # and with the polished null fit on both sides: the algebra itself, to 1e-8
+    lib = _lib.load()
+    _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 1))
+    try:
+        pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=None), return_stats=True)
+    finally:
+        _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 0))
+    ppv, pinfo, pst = OracleCellRegMap(y, E, W=W, polish=True, **okw).scan_interaction(G, return_stats=True)
+    _compare(pv, info, st, ppv, pinfo, pst, tight=True)

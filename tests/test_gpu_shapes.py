@@ -11,24 +11,7 @@ pytestmark = pytest.mark.gpu
 P_RTOL, P_ATOL = 1e-5, 1e-13
 
 
-def _random_problem(n, k0, c, p, donors, seed, mode):
-    rng = np.random.default_rng(seed)
-    donor = np.sort(rng.integers(0, donors, size=n))
-    donor[:donors] = np.arange(donors)
-    donor = np.sort(donor)
-    Gd = rng.normal(size=(donors, p))
-    G = Gd[donor]
-    E = rng.normal(size=(n, k0))
-    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, c - 1))], axis=1) if c > 1 else np.ones((n, 1))
-    hK = np.zeros((n, donors))
-    hK[np.arange(n), donor] = 1.0
-    y = 0.4 * G[:, 0] + 0.5 * (G[:, 1 % p] * E[:, 0]) + E @ rng.normal(size=k0) * 0.3 + rng.normal(size=n)
-    kw = {}
-    if mode == "B":
-        kw["hK"] = hK
-    elif mode == "C":
-        kw["Ls"] = [E[:, [i]] * hK for i in range(k0)]
-    return y, E, W, G, kw
+from fuzz_cases import random_problem as _random_problem  # noqa: E402
 
 
 @pytest.mark.parametrize("n,k0,c,p,donors,mode", [

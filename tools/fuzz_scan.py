@@ -1,53 +1,13 @@
-"""One-off fuzz: random shapes / modes / hooks, device (dense + collapsed) vs oracle.  GPU only."""
+"""Random problems, device (dense + collapsed) vs oracle, both null-fit procedures: prints the summaries that
+tests/test_gpu_fuzz.py asserts on.  GPU only.   python tools/fuzz_scan.py [polished|verbatim]"""
+import json
+import os
 import sys
-import numpy as np
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
-from test_gpu_shapes import _random_problem
-from cellregmap_amd import CellRegMap, GenotypePanel
-from oracle.crm import OracleCellRegMap
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-POLISH = len(sys.argv) > 3 and sys.argv[3] == "polish"   # refine the null-fit optimum on both sides
-if POLISH:
-    from cellregmap_amd import _engine, _lib
-    _lib.check(_lib.load().crm_set_null_fit_polish(_engine._context(0), 1))
-bad = 0
-worst_q = worst_p = 0.0
-rho_ties = 0
-for i in range(N):
-    mode = "ABC"[int(rng.integers(0, 3))]
-    n = int(rng.integers(30, 600))
-    k0 = int(rng.integers(1, 129)) if mode != "C" else int(rng.integers(1, 9))
-    c = int(rng.choice([1, 1, 1, 2, 3, 5, 8] if POLISH else [1, 1, 1, 2, 3, 5, 8, 9, 14]))
-    p = int(rng.integers(1, 70))
-    donors = int(rng.integers(2, 14))
-    perm = ["none", "E", "G"][int(rng.integers(0, 3))]
-    if k0 + c + 2 > 144 or n <= c + 2:
-        continue
-    y, E, W, G, kw = _random_problem(n, k0, c, p, donors, seed=5000 + i, mode=mode)
-    idx = np.random.default_rng(i).permutation(n)
-    hooks = {} if perm == "none" else ({"idx_E": idx} if perm == "E" else {"idx_G": idx})
-    try:
-        opv, oinfo, ost = OracleCellRegMap(y, E, W=W, polish=POLISH, **kw).scan_interaction(G, return_stats=True, **hooks)
-    except Exception as e:  # the oracle (like the reference) raises on degenerate variants
-        print(i, "oracle raised", type(e).__name__, (n, k0, c, p, donors, mode, perm))
-        continue
-    crm = CellRegMap(y, E, W=W, **kw)
-    for groups in (None, "auto"):
-        pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
-        ok = (np.allclose(info["rho1"], oinfo["rho1"], atol=1e-12) and np.allclose(st["Q"], ost["Q"], rtol=1e-6, atol=0)
-              and np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-13))
-        relq = np.max(np.abs(st["Q"] - ost["Q"]) / np.abs(ost["Q"]))
-        relp = np.max(np.abs(pv - opv) / opv)
-        same_rho = np.array_equal(info["rho1"], oinfo["rho1"])
-        rho_ties += 0 if same_rho else 1
-        if same_rho:
-            worst_q, worst_p = max(worst_q, relq), max(worst_p, relp)
-        if not ok:
-            bad += 1
-            print("MISMATCH", i, (n, k0, c, p, donors, mode, perm, groups), "rho equal", np.array_equal(info["rho1"], oinfo["rho1"]),
-                  "max rel Q", relq, "max rel p", relp, flush=True)
-print("cases", N, "beyond (Q 1e-6 | p 1e-5 | rho*)", bad, "| rho* ties resolved differently", rho_ties,
-      "| worst rel Q", worst_q, "worst rel p", worst_p)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_fuzz import _run  # noqa: E402
+
+for polish in ([True, False] if len(sys.argv) < 2 else [sys.argv[1] == "polished"]):
+    print(json.dumps(_run(polish)[0], indent=1))
