@@ -63,6 +63,7 @@ SIGNATURES = {
                                             vp, vp, vp, vp]),
     "crm_test_contract_kr_t": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               vp, vp, vp, vp]),
+    "crm_test_eigh": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp]),
     "crm_test_eigvalsh": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "crm_test_davies": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]),
 }

@@ -47,8 +47,10 @@ struct GemmProblem {
     long ldx, lde, ldy, ldc;
     int M, N;         // logical extents (stores are predicated on them)
     int k0;           // KR only
-    int pad_;
+    int flags;        // GEMM_SUBTRACT: C -= X'Y instead of C = X'Y (not for split launches)
+    long cells;       // > 0: this problem's own contraction length (multiple of GEMM_BK, <= the launch's)
 };
+constexpr int GEMM_SUBTRACT = 1;
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an
 // XCD and its L2), so the workgroups of one residue class take a contiguous run of tile ids --

@@ -1,0 +1,237 @@
+// Back-transformation of the tridiagonal eigenvectors, Z <- Q Z with Q = H_0 H_1 ... H_{dim-2}, in compact-WY
+// blocks of BT_NB reflectors (LAPACK dormtr / dlarft): per block
+//     Q_p = I - V T V',   Z <- Z - V (T (V' Z))
+// three contractions on the FP64 matrix pipe (V' Z over the rows, T through its transpose, the update with
+// GEMM_SUBTRACT), T from the block's Gram matrix V'V by the dlarft recurrence (one workgroup per block).
+// Plus the driver of the whole eigen-solver and its allocation.
+#include "eigh.h"
+
+namespace crm {
+namespace {
+
+__global__ void bt_transpose_kernel(const double* __restrict__ src, long ld_src, long rows, long cols,
+                                    double* __restrict__ dst, long ld_dst, long slab_src, long slab_dst) {
+    __shared__ double tile[32][33];
+    const double* S = src + (long)blockIdx.z * slab_src;
+    double* D = dst + (long)blockIdx.z * slab_dst;
+    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const long r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? S[r * ld_src + c] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const long c = c0 + i, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) D[c * ld_dst + r] = tile[threadIdx.x][i];
+    }
+}
+
+// T (upper triangular, nbk x nbk) of the block of reflectors j0 .. j0 + nbk - 1 from S = V'V and tau:
+//   T[i][i] = tau_i,  T[0:i, i] = -tau_i T[0:i, 0:i] S[0:i, i]            (dlarft, forward, columnwise)
+// written TRANSPOSED (Tt[m][l] = T[l][m], leading dimension BT_NB) for the contraction kernel.
+__global__ __launch_bounds__(BT_NB) void bt_larft_kernel(const double* __restrict__ S_all, const double* __restrict__ tau_all,
+                                                         long ld, int nblocks, long dim, double* __restrict__ Tt_all) {
+    extern __shared__ double T[];   // [BT_NB][BT_NB + 1]
+    __shared__ double col[BT_NB];
+    const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const long j0 = (long)p * BT_NB;
+    const int nbk = (int)((dim - 1 - j0) < BT_NB ? (dim - 1 - j0) : BT_NB);   // reflectors 0 .. dim - 2
+    const double* S = S_all + ((long)b * nblocks + p) * BT_NB * BT_NB;
+    const double* tau = tau_all + (long)b * ld + j0;
+    double* Tt = Tt_all + ((long)b * nblocks + p) * BT_NB * BT_NB;
+    constexpr int LT = BT_NB + 1;
+    for (int idx = tid; idx < BT_NB * LT; idx += BT_NB) T[idx] = 0.0;
+    __syncthreads();
+    for (int i = 0; i < nbk; i++) {
+        const double ti = tau[i];
+        // col[l] = -tau_i * sum_{m < i} T[l][m] S[m][i]   for l < i   (T upper triangular: m >= l)
+        double acc = 0.0;
+        if (tid < i) {
+            for (int m = tid; m < i; m++) acc += T[tid * LT + m] * S[(long)m * BT_NB + i];
+            col[tid] = -ti * acc;
+        }
+        __syncthreads();
+        if (tid < i) T[tid * LT + i] = col[tid];
+        if (tid == i) T[i * LT + i] = ti;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < BT_NB * BT_NB; idx += BT_NB) {
+        const int m = idx / BT_NB, l = idx - m * BT_NB;
+        Tt[idx] = T[l * LT + m];
+    }
+}
+
+}  // namespace
+
+int launch_transpose(hipStream_t st, const double* src, long ld_src, long rows, long cols, double* dst, long ld_dst) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), 1);
+    hipLaunchKernelGGL(bt_transpose_kernel, grid, dim3(32, 8), 0, st, src, ld_src, rows, cols, dst, ld_dst, 0L, 0L);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+static int transpose_batch(hipStream_t st, int B, const double* src, double* dst, long slab, long ld, long rows, long cols) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(bt_transpose_kernel, grid, dim3(32, 8), 0, st, src, ld, rows, cols, dst, ld, slab, slab);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int eigh_alloc(EighWork& w, int batch, long dim) {
+    w.batch = batch;
+    w.dim = dim;
+    w.dimp = round_up(dim, 128);
+    w.ld = w.dimp;
+    w.slab = w.dimp * w.ld + 256;
+    const size_t mat = sizeof(double) * (size_t)batch * w.slab;
+    for (DevBuf* b : {&w.A, &w.Vt, &w.Vc, &w.QA, &w.QB}) CRM_TRY(b->ensure(mat));
+    for (DevBuf* b : {&w.d, &w.e, &w.tau, &w.lam}) CRM_TRY(b->ensure(sizeof(double) * (size_t)batch * w.ld));
+    return CRM_OK;
+}
+
+void eigh_free(EighWork& w) {
+    for (DevBuf* b : {&w.A, &w.Vt, &w.Vc, &w.QA, &w.QB, &w.d, &w.e, &w.tau, &w.lam, &w.small}) b->release();
+}
+
+// Qt: rows = eigenvectors of the tridiagonal (sorted); returns *Zt: rows = eigenvectors of A.
+int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) {
+    hipStream_t st = ctx->stream;
+    const long dim = w.dim, ld = w.ld, dimp = w.dimp, slab = w.slab;
+    const int B = w.batch;
+    double* other = Qt == w.QA.as<double>() ? w.QB.as<double>() : w.QA.as<double>();
+    if (dim < 2) {   // no reflectors
+        *Zt_out = Qt;
+        return CRM_OK;
+    }
+    // Z (column j = eigenvector j) in the A slab, Vc = Vt'
+    double* Z = w.A.as<double>();
+    double* Vc = w.Vc.as<double>();
+    const double* Vt = w.Vt.as<double>();
+    CRM_HIP(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)B * slab, st));
+    CRM_HIP(hipMemsetAsync(Vc, 0, sizeof(double) * (size_t)B * slab, st));
+    CRM_TRY(transpose_batch(st, B, Qt, Z, slab, ld, dim, dim));
+    CRM_TRY(transpose_batch(st, B, Vt, Vc, slab, ld, dim, dim));
+    const int nblocks = (int)((dim - 1 + BT_NB - 1) / BT_NB);
+    // scratch: S and Tt per (matrix, block), W1 / W2 per matrix, problem records
+    const size_t tt = (size_t)B * nblocks * BT_NB * BT_NB;
+    const size_t wsz = (size_t)BT_NB * ld + 256;
+    const size_t need = sizeof(double) * (2 * tt + 2 * (size_t)B * wsz) + sizeof(GemmProblem) * (size_t)B * (nblocks + 3);
+    CRM_TRY(w.small.ensure(need));
+    double* S = w.small.as<double>();
+    double* Tt = S + tt;
+    double* W1 = Tt + tt;
+    double* W2 = W1 + (size_t)B * wsz;
+    GemmProblem* d_probs = reinterpret_cast<GemmProblem*>(W2 + (size_t)B * wsz);
+    std::vector<GemmProblem> probs((size_t)B * nblocks);
+    // S_p = V_p' V_p for every block (one 128 x 128 tile each, split over the rows)
+    for (int b = 0; b < B; b++)
+        for (int p = 0; p < nblocks; p++) {
+            GemmProblem g{};
+            const long j0 = (long)p * BT_NB;
+            g.X = Vc + (size_t)b * slab + j0; g.ldx = ld;
+            g.Y = g.X; g.ldy = ld;
+            g.C = S + ((size_t)b * nblocks + p) * BT_NB * BT_NB; g.ldc = BT_NB;
+            g.M = BT_NB; g.N = BT_NB;
+            probs[(size_t)b * nblocks + p] = g;
+        }
+    CRM_HIP(hipMemsetAsync(S, 0, sizeof(double) * 2 * tt, st));
+    CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * probs.size(), hipMemcpyHostToDevice, st));
+    CRM_TRY(launch_gemm_tn(ctx, d_probs, (int)probs.size(), BT_NB, BT_NB, dimp, false, 0, 1, 0));
+    CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * BT_NB * (BT_NB + 1))));
+    hipLaunchKernelGGL(bt_larft_kernel, dim3(nblocks, B), dim3(BT_NB), sizeof(double) * BT_NB * (BT_NB + 1), st, S,
+                       w.tau.as<double>(), ld, nblocks, dim, Tt);
+    CRM_HIP(hipGetLastError());
+    CRM_HIP(hipStreamSynchronize(st));
+    // blocks from the last to the first
+    GemmProblem* d_p3 = d_probs + (size_t)B * nblocks;
+    std::vector<GemmProblem> p3(3 * (size_t)B);
+    for (int p = nblocks - 1; p >= 0; p--) {
+        const long j0 = (long)p * BT_NB;
+        const long r0 = j0 / 16 * 16;              // the block's vectors vanish above row j0 + 1
+        for (int b = 0; b < B; b++) {
+            GemmProblem g{};
+            // W1 (BT_NB x dim) = V_p' Z   over the rows r0 .. dimp
+            g.X = Vc + (size_t)b * slab + (size_t)r0 * ld + j0; g.ldx = ld;
+            g.Y = Z + (size_t)b * slab + (size_t)r0 * ld; g.ldy = ld;
+            g.C = W1 + (size_t)b * wsz; g.ldc = ld;
+            g.M = BT_NB; g.N = (int)dim;
+            p3[b] = g;
+            // W2 = T W1  ==  Tt' W1
+            GemmProblem h{};
+            h.X = Tt + ((size_t)b * nblocks + p) * BT_NB * BT_NB; h.ldx = BT_NB;
+            h.Y = W1 + (size_t)b * wsz; h.ldy = ld;
+            h.C = W2 + (size_t)b * wsz; h.ldc = ld;
+            h.M = BT_NB; h.N = (int)dim;
+            p3[B + b] = h;
+            // Z[r0:, :] -= V_p W2  ==  (Vt rows j0 .., columns r0 ..)' W2
+            GemmProblem u{};
+            u.X = Vt + (size_t)b * slab + (size_t)j0 * ld + r0; u.ldx = ld;
+            u.Y = W2 + (size_t)b * wsz; u.ldy = ld;
+            u.C = Z + (size_t)b * slab + (size_t)r0 * ld; u.ldc = ld;
+            u.M = (int)(dim - r0); u.N = (int)dim;
+            u.flags = GEMM_SUBTRACT;
+            p3[2 * B + b] = u;
+        }
+        CRM_HIP(hipMemcpyAsync(d_p3, p3.data(), sizeof(GemmProblem) * p3.size(), hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3, B, BT_NB, (int)dim, dimp - r0, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3 + B, B, BT_NB, (int)dim, BT_NB, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3 + 2 * B, B, (int)(dim - r0), (int)dim, BT_NB, false, 0, 1, 0));
+        CRM_HIP(hipStreamSynchronize(st));   // p3 is rewritten for the next block
+    }
+    // rows = eigenvectors again
+    CRM_HIP(hipMemsetAsync(other, 0, sizeof(double) * (size_t)B * slab, st));
+    CRM_TRY(transpose_batch(st, B, Z, other, slab, ld, dim, dim));
+    CRM_HIP(hipStreamSynchronize(st));
+    *Zt_out = other;
+    return CRM_OK;
+}
+
+int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt) {
+    CRM_TRY(eigh_tridiagonalise(ctx, w));
+    double* Qt = nullptr;
+    CRM_TRY(eigh_dc(ctx, w, lam_host, &Qt));
+    CRM_TRY(eigh_back_transform(ctx, w, Qt, Zt));
+    return CRM_OK;
+}
+
+}  // namespace crm
+
+// ---- test hook: the solver on host matrices ---------------------------------------------------------------------
+extern "C" int crm_test_eigh(crm_ctx* ctx, int batch, int dim, const double* A, double* lam, double* Z, int stage,
+                             double* d_out, double* e_out) {
+    using namespace crm;
+    if (!ctx || batch < 1 || dim < 1 || !A || !lam) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    EighWork w;
+    struct Guard { EighWork& w; ~Guard() { eigh_free(w); } } guard{w};
+    CRM_TRY(eigh_alloc(w, batch, dim));
+    CRM_HIP(hipMemsetAsync(w.A.ptr, 0, sizeof(double) * (size_t)batch * w.slab, st));
+    for (int b = 0; b < batch; b++)
+        CRM_HIP(hipMemcpy2DAsync(w.A.as<double>() + (size_t)b * w.slab, w.ld * sizeof(double), A + (size_t)b * dim * dim,
+                                 dim * sizeof(double), dim * sizeof(double), dim, hipMemcpyHostToDevice, st));
+    CRM_TRY(eigh_tridiagonalise(ctx, w));
+    if (d_out) CRM_HIP(hipMemcpy2DAsync(d_out, dim * sizeof(double), w.d.ptr, w.ld * sizeof(double), dim * sizeof(double), batch,
+                                        hipMemcpyDeviceToHost, st));
+    if (e_out) CRM_HIP(hipMemcpy2DAsync(e_out, dim * sizeof(double), w.e.ptr, w.ld * sizeof(double), dim * sizeof(double), batch,
+                                        hipMemcpyDeviceToHost, st));
+    CRM_HIP(hipStreamSynchronize(st));
+    if (stage == 1) return CRM_OK;
+    double* Qt = nullptr;
+    CRM_TRY(eigh_dc(ctx, w, lam, &Qt));
+    double* Zt = Qt;
+    if (stage != 2) CRM_TRY(eigh_back_transform(ctx, w, Qt, &Zt));
+    if (Z) {
+        // Z[b] (dim x dim, row-major) with COLUMN j = eigenvector j: transpose of the row storage
+        std::vector<double> rows((size_t)dim * dim);
+        for (int b = 0; b < batch; b++) {
+            CRM_HIP(hipMemcpy2D(rows.data(), dim * sizeof(double), Zt + (size_t)b * w.slab, w.ld * sizeof(double),
+                                dim * sizeof(double), dim, hipMemcpyDeviceToHost));
+            double* out = Z + (size_t)b * dim * dim;
+            for (int j = 0; j < dim; j++)
+                for (int r = 0; r < dim; r++) out[(size_t)r * dim + j] = rows[(size_t)j * dim + r];
+        }
+    }
+    return CRM_OK;
+}

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
 
     const long cell_begin = (long)blockIdx.y * cells_per_split;
     // (the last slice of a split over the cell axis may be shorter)
-    const int stages = (int)(std::min(cells_per_split, cells_total - cell_begin) / GEMM_BK);
+    const long cells_mine = P.cells > 0 ? P.cells : cells_total;
+    const int stages = (int)(std::min(cells_per_split, cells_mine - cell_begin) / GEMM_BK);
 
     // ---- LDS carve-up (two stages of every tile) --------------------------------------
     const int nb = KR ? kr_variants_per_tile(k0) : 0;
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
 #pragma unroll
                 for (int j = 0; j < NT; j++) {
                     const int n = n0 + wn * (BN / 2) + j * 16 + l15;
-                    if (n < P.N) Cb[(long)m * P.ldc + n] = acc[i][j][reg];
+                    if (n < P.N) {
+                        double* cp = Cb + (long)m * P.ldc + n;
+                        *cp = (P.flags & GEMM_SUBTRACT) ? *cp - acc[i][j][reg] : acc[i][j][reg];
+                    }
                 }
             }
         }

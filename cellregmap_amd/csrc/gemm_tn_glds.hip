@@ -80,7 +80,8 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
     const int l15 = lane & 15, lq = lane >> 4;
     const long cell_begin = (long)slice * cells_per_split;
     // (the last slice of a split over the cell axis may be shorter)
-    const int stages = (int)(std::min(cells_per_split, cells_total - cell_begin) / GEMM_BK);
+    const long cells_mine = P.cells > 0 ? P.cells : cells_total;
+    const int stages = (int)(std::min(cells_per_split, cells_mine - cell_begin) / GEMM_BK);
 
     // ---- LDS carve-up ------------------------------------------------------------------------
     const int nb = KR ? glds_kr_variants(k0) : 0;
@@ -318,7 +319,10 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
 #pragma unroll
                 for (int j = 0; j < NT; j++) {
                     const int n = n0 + wn * WCOLS + j * 16 + l15;
-                    if (n < P.N) Cb[(long)m * P.ldc + n] = acc[i][j][reg];
+                    if (n < P.N) {
+                        double* cp = Cb + (long)m * P.ldc + n;
+                        *cp = (P.flags & GEMM_SUBTRACT) ? *cp - acc[i][j][reg] : acc[i][j][reg];
+                    }
                 }
             }
         }

@@ -36,6 +36,14 @@ int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* l
 int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const double* lambda,
                     double* pvalue, int* ifault, double* liu);
 
+/* The background constructor's symmetric eigen-solver on `batch` host matrices A (dim x dim each, row-major,
+ * tight): lam (batch x dim, ascending), Z (batch x dim x dim, column j = eigenvector j; may be NULL).
+ * stage 0: the whole solver; 1: tridiagonalisation only (d_out / e_out: batch x dim diagonals and
+ * sub-diagonals, e[dim - 1] unused); 2: tridiagonal eigenproblem without the back-transformation (Z then
+ * holds the eigenvectors of the tridiagonal matrix). */
+int crm_test_eigh(crm_ctx* ctx, int batch, int dim, const double* A, double* lam, double* Z, int stage,
+                  double* d_out, double* e_out);
+
 #ifdef __cplusplus
 }
 #endif

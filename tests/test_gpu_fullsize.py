@@ -215,8 +215,9 @@ def test_config4_per_gpu_shape_64_genes_against_one_panel():
         opv, oinfo = o.scan_interaction(c.G[:, pick])
         assert_allclose(info["rho1"][g, pick], oinfo["rho1"], atol=1e-12)
         assert np.all(np.abs(pv[g, pick] - opv) <= P_RTOL * opv + P_ATOL), (g, np.c_[pv[g, pick], opv])
-        for k in ("e2", "g2", "eps2"):
-            assert_allclose(info[k][g, pick], oinfo[k], rtol=1e-5, atol=1e-12)
+        total = oinfo["e2"] + oinfo["g2"] + oinfo["eps2"]
+        for k in ("e2", "g2", "eps2"):  # (a component at the boundary, v0 -> 0, only has absolute accuracy)
+            assert np.all(np.abs(info[k][g, pick] - oinfo[k]) <= 1e-5 * oinfo[k] + 1e-6 * total)
         del o
 
 
@@ -240,7 +241,9 @@ def test_config5_hundred_thousand_cells():
     assert max(crm._bg.rank(i) for i in range(11)) >= 10_000
     dense = GenotypePanel(c.G, groups=None)
     pv, info, st = crm.scan_interaction(dense, return_stats=True)
-    assert np.all(np.isfinite(pv)) and np.all((pv > 0) & (pv <= 1))
+    # (at 100 000 cells the planted effects are beyond the range of a double: Q / lambda ~ 2 500, p = 0.0 from
+    # Davies and from the Liu fall-back alike)
+    assert np.all(np.isfinite(pv)) and np.all((pv >= 0) & (pv <= 1))
     # planted GxC variants (10, 11) come out on top
     assert set(np.argsort(pv)[:2]) == {10, 11}
 

@@ -3,7 +3,9 @@ procedure: 30-600 cells, 1-128 contexts, 1-14 covariate columns, the three backg
 permutation hooks (tests/fuzz_cases.py).  Two tiers:
 
   * polished (both sides refine the null-fit optimum on the analytic derivative): the sharp test of the
-    algebra -- Q to 1e-9, p to 1e-7 relative (+ Davies' own absolute accuracy floor);
+    algebra -- Q to 1e-9, lml to 1e-11, rho* identical; p to 2e-6 relative: Davies' method integrates to
+    acc = 1e-6 and its truncation point / step count come out of discrete searches (AS 155 findu, ctff), so
+    two roundings of the same (Q, lambda) differ by up to ~1e-6 relative (measured worst 5.7e-7);
   * verbatim (the reference's Brent search, rtol = atol = 1e-6, both sides): every variant inside the
     envelope that tests/test_oracle_spread.py measures between two roundings of the ORACLE's own
     objective (Q 2e-5, p 5e-5), and at most a few percent of the variants beyond the north-star
@@ -82,7 +84,7 @@ def test_fuzz_polished_procedure():
     assert s["rho_star_differs"] <= 0.01 * s["variant_scans"], s
     assert s["worst_rel_lml_where_rho_differs"] < 1e-11, s       # ... and only on ties
     assert s["worst_rel_Q"] < 1e-9, s
-    assert np.all(a[same, 2] <= 1e-7 * a[same, 5] + 1e-9), s   # 1e-9: what Davies' acc = 1e-6 integration leaves
+    assert np.all(a[same, 2] <= 2e-6 * a[same, 5] + P_ATOL), s
     assert s["worst_rel_lml"] < 1e-11, s
 
 

@@ -22,6 +22,21 @@ P_RTOL, P_ATOL = 1e-5, 1e-13
 Q_RTOL = 1e-6
 
 
+def _assert_fit_info_matches(info, oinfo, pv, opv):
+    """rho* and the variance components against the oracle.  Where the background explains nothing
+    (v0 -> 0, delta -> 1) the covariance is v1 I whatever rho is: every grid point has the same likelihood
+    and the reference's strict '>' (cellregmap/_cellregmap.py:354) is decided by rounding noise -- there
+    rho* may differ, the p-value must not."""
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+    total = oinfo["e2"] + oinfo["g2"] + oinfo["eps2"]
+    flat = (oinfo["e2"] + oinfo["g2"] <= 1e-6 * total) & (info["e2"] + info["g2"] <= 1e-6 * total)
+    same = info["rho1"] == oinfo["rho1"]
+    assert np.all(same | flat), np.c_[info["rho1"], oinfo["rho1"], oinfo["e2"] + oinfo["g2"], total]
+    assert_allclose(info["eps2"], oinfo["eps2"], rtol=1e-5)
+    for k in ("e2", "g2"):  # (a component at the boundary only has absolute accuracy)
+        assert np.all(~same | (np.abs(info[k] - oinfo[k]) <= 1e-5 * oinfo[k] + 1e-6 * total))
+
+
 def _cohort(donors, cells, k, p, seed):
     from cellregmap_amd.synth import make_cohort
 
@@ -384,16 +399,12 @@ def test_many_phenotypes_against_the_oracle(genotypes):
         pv, info = scan_interaction_many(crms, panel, **hooks)
         for i in range(Y.shape[1]):
             opv, oinfo = ocrm.OracleCellRegMap(Y[:, i], c.E, W=W, Ls=oLs).scan_interaction(G, **hooks)
-            assert_allclose(info["rho1"][i], oinfo["rho1"], atol=1e-12)
-            for k in ("e2", "g2", "eps2"):
-                assert_allclose(info[k][i], oinfo[k], rtol=1e-5, atol=1e-12)
-            assert np.all(np.abs(pv[i] - opv) <= P_RTOL * opv + P_ATOL), (i, np.c_[pv[i], opv])
+            _assert_fit_info_matches({k: v[i] for k, v in info.items()}, oinfo, pv[i], opv)
     # the functional wrapper: one run_interaction per column of Y
     pv2, info2 = run_interaction_many(Y, c.E, G, W=W, hK=c.hK)
     for i in range(Y.shape[1]):
         opv, oinfo = ocrm.run_interaction(Y[:, i], c.E, G, W=W, hK=c.hK)
-        assert_allclose(info2["rho1"][i], oinfo["rho1"], atol=1e-12)
-        assert np.all(np.abs(pv2[i] - opv) <= P_RTOL * opv + P_ATOL)
+        _assert_fit_info_matches({k: v[i] for k, v in info2.items()}, oinfo, pv2[i], opv)
 
 
 def test_many_phenotypes_must_share_covariates_and_contexts_by_content():
@@ -436,7 +447,8 @@ def test_boolean_permutation_index_selects_rows_like_numpy():
     ref, _ = crm.scan_interaction(c.G)
     mask = np.ones(c.y.size, bool)
     assert np.array_equal(crm.scan_interaction(c.G, idx_E=mask)[0], ref)
-    assert np.array_equal(scan_interaction_many([crm], c.G, idx_G=mask)[0][0], ref)
+    # (the genotype hook runs the dense / mixed-table path instead of the collapsed one: equal to rounding)
+    assert_allclose(scan_interaction_many([crm], c.G, idx_G=mask)[0][0], ref, rtol=1e-6)
     with pytest.raises(ValueError):
         crm.scan_interaction(c.G, idx_E=mask[:-1])
 
