@@ -20,7 +20,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}",
             "-Wall", "-Wno-unused-function"]
-LDLIBS = ["-lrocsolver", "-lrocblas"]
+LDLIBS = []  # no vendor BLAS / solver: every kernel of the path is in csrc/
 
 
 def _sources():

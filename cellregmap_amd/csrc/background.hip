@@ -4,22 +4,19 @@
 // numpy_sugar.economic_qs_linear (in-tree twin cellregmap/_math.py:238-256).
 //
 // cols < n  (the reference's thin-SVD branch): the cols x cols Gram matrix of [E1, B] is formed
-//   once with the FP64-MFMA contraction kernel, rescaled per rho, diagonalised (rocSOLVER
-//   dsyevd -- a once-per-background library call, not on the per-variant path), and
-//   Q0 = hS V L^-1/2 is formed by the contraction kernel again; two Newton-Schulz steps
+//   once with the FP64-MFMA contraction kernel, rescaled per rho, diagonalised -- all grid points in
+//   one batch by the hand-written solver of eigh*.hip (tridiagonalisation, divide & conquer,
+//   back-transformation) -- and Q0 = hS V L^-1/2 is formed by the contraction kernel again; two Newton-Schulz steps
 //   (contractions only) restore orthonormality of the columns that belong to small
 //   eigenvalues.  Columns with eigenvalue <= rel_tol * max are dropped: they are inert in
 //   every bilinear form of the path (weight (1-d) S + d == d, cancelled by the complement
 //   term) whereas the reference's SVD keeps them with S0 ~ 1e-29.
 // cols >= n (the reference's eigh branch): Sigma(rho) itself (n x n) is diagonalised and
 //   eigenvalues below sqrt(machine eps) are dropped, exactly as _math.py:204-235 does.
-#include <rocsolver/rocsolver.h>
-
-#include <chrono>
-#include <thread>
-
 #include <algorithm>
+#include <chrono>
 
+#include "eigh.h"
 #include "nullfit.h"
 #include "objects.h"
 
@@ -27,15 +24,6 @@ using namespace crm;
 
 namespace crm {
 namespace {
-
-#define CRM_ROC(call)                                                                         \
-    do {                                                                                      \
-        rocblas_status s__ = (call);                                                          \
-        if (s__ != rocblas_status_success) {                                                  \
-            set_error("%s:%d: %s -> rocblas status %d", __FILE__, __LINE__, #call, (int)s__); \
-            return CRM_ERR_HIP;                                                               \
-        }                                                                                     \
-    } while (0)
 
 __global__ void transpose_kernel(const double* __restrict__ src, long ld_src, long rows, long cols,
                                  double* __restrict__ dst, long ld_dst) {
@@ -264,157 +252,84 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         CRM_BG(contract(ctx, E1t, np, E1t, np, S1, dimp, (int)n, (int)n, k1p));
         if (kb > 0) CRM_BG(contract(ctx, Bt, np, Bt, np, S2, dimp, (int)n, (int)n, kbp));
     }
-    // pass 1: eigen-decompositions; ranks decide the common leading dimension
-    // (Q0 buffers are allocated after all ranks are known)
+    // pass 1: eigen-decompositions of all grid points at once (eigh*.hip); ranks decide the common leading
+    // dimension (Q0 buffers are allocated after all ranks are known)
     std::vector<DevBuf> Mbuf(nrho);
     struct MGuard {
         std::vector<DevBuf>& v;
         ~MGuard() { for (auto& b : v) b.release(); }
     } mguard{Mbuf};
     long rmax = 1;
-    // One host thread per grid point, each with its own stream, solver handle and work matrix: a
-    // dsyevd call is a long chain of small kernels (tridiagonalisation panels), launch-bound on one
-    // stream; the chains of the grid points are independent and overlap on the device.
-    // (streams and solver handles are created here, one after the other: library initialisation is
-    // not something to race on)
-    struct Lane {
-        hipStream_t st = nullptr;
-        rocblas_handle h = nullptr;
-    };
-    struct Lanes {
-        std::vector<Lane> v;
-        ~Lanes() {
-            for (auto& l : v) {
-                if (l.h) rocblas_destroy_handle(l.h);
-                if (l.st) (void)hipStreamDestroy(l.st);
-            }
-        }
-    } lanes;
-    lanes.v.resize(nrho);
-    for (int i = 0; i < nrho; i++) {
-        if (hipStreamCreateWithFlags(&lanes.v[i].st, hipStreamNonBlocking) != hipSuccess) {
-            set_error("background: could not create a stream for grid point %d", i);
-            return fail(CRM_ERR_HIP);
-        }
-        if (rocblas_create_handle(&lanes.v[i].h) != rocblas_status_success ||
-            rocblas_set_stream(lanes.v[i].h, lanes.v[i].st) != rocblas_status_success) {
-            set_error("background: could not create a solver handle for grid point %d", i);
-            return fail(CRM_ERR_HIP);
-        }
-    }
-    auto decompose = [&](int i) -> int {
-        CRM_HIP(hipSetDevice(ctx->device));
-        hipStream_t ws = lanes.v[i].st;
-        rocblas_handle wh = lanes.v[i].h;
-        ScopedBuf wCr, wW, wE, wInfo, wKeep;
-        CRM_TRY(wCr.ensure(sizeof(double) * dimp * dimp));
-        CRM_TRY(wW.ensure(sizeof(double) * dimp));
-        CRM_TRY(wE.ensure(sizeof(double) * dimp));
-        CRM_TRY(wInfo.ensure(sizeof(int) * 4));
-        CRM_TRY(wKeep.ensure(sizeof(int) * dimp));
-        std::vector<double> hW(dim);
-        std::vector<int> keep;
-        const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
-        if (thin) {
-            dim3 grid((unsigned)((cols + 255) / 256), (unsigned)cols);
-            hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, ws, dC.as<double>(), cp, (int)cols, k1,
-                               a, b, wCr.as<double>(), dimp);
-        } else {
-            // Sigma(rho) = rho E1 E1' + (1 - rho) B B'
-            dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
-            hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, ws, dG.as<double>(),
-                               dG.as<double>() + dimp * dimp, dimp, (int)n, rho[i], 1.0 - rho[i],
-                               wCr.as<double>());
-        }
-        CRM_HIP(hipGetLastError());
-        // symmetric eigen-decomposition: eigenvalues ascending in wW, eigenvectors as columns
-        // (column-major) of wCr
-        rocblas_status rs = rocsolver_dsyevd(wh, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)dim,
-                                             wCr.as<double>(), (rocblas_int)dimp, wW.as<double>(),
-                                             wE.as<double>(), wInfo.as<int>());
-        if (rs != rocblas_status_success) {
-            set_error("rocsolver_dsyevd failed with status %d", (int)rs);
-            return CRM_ERR_HIP;
-        }
-        int info = 0;
-        CRM_HIP(hipMemcpyAsync(hW.data(), wW.ptr, sizeof(double) * dim, hipMemcpyDeviceToHost, ws));
-        CRM_HIP(hipMemcpyAsync(&info, wInfo.ptr, sizeof(int), hipMemcpyDeviceToHost, ws));
-        CRM_HIP(hipStreamSynchronize(ws));
-        if (info != 0) {
-            set_error("background: eigen-decomposition did not converge at rho=%g (info %d)", rho[i], info);
-            return CRM_ERR_NUMERIC;
-        }
-        if (thin) {
-            const double cut = rel_tol * std::max(hW[dim - 1], 0.0);
-            for (long j = dim - 1; j >= 0; j--)  // descending, like singular values
-                if (hW[j] > cut && hW[j] > 0.0) keep.push_back((int)j);
-        } else {
-            const double eps_small = 1.4901161193847656e-08;  // sqrt(machine eps), _math.py:204
-            for (long j = 0; j < dim; j++)                    // ascending, like eigh
-                if (hW[j] >= eps_small) keep.push_back((int)j);
-        }
-        const int r = (int)keep.size();
-        bg->r[i] = r;
-        S0_host[i].resize(r);
-        for (int j = 0; j < r; j++) S0_host[i][j] = hW[keep[j]];
-        // keep what pass 2 needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
-        const long ldm = round_up(std::max(r, 1), 128);
-        CRM_TRY(Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
-        CRM_HIP(hipMemsetAsync(Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, ws));
-        if (r > 0) {
-            CRM_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, ws));
-            if (thin) {
-                dim3 grid((unsigned)((r + 255) / 256), (unsigned)cols);
-                hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, ws, wCr.as<double>(), dimp,
-                                   wW.as<double>(), wKeep.as<int>(), r, (int)cols, k1, a, b,
-                                   Mbuf[i].as<double>(), ldm);
-            } else {
-                dim3 grid((unsigned)((r + 255) / 256), (unsigned)n);
-                hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, ws, wCr.as<double>(), dimp,
-                                   wKeep.as<int>(), r, n, Mbuf[i].as<double>(), ldm);
-            }
-            CRM_HIP(hipGetLastError());
-        }
-        CRM_HIP(hipStreamSynchronize(ws));
-        return CRM_OK;
-    };
-    CRM_BG_HIP(hipStreamSynchronize(st));  // the Gram matrices the workers read
+    CRM_BG_HIP(hipStreamSynchronize(st));
     lap("half factor + Gram");
     {
-        std::vector<int> rcs(nrho, CRM_OK);
-        std::vector<std::string> errs(nrho);
-        std::vector<std::thread> workers;
-        for (int i = 0; i < nrho; i++) bg->rho[i] = rho[i];
-        // the first one alone (it pays the solver's one-time kernel loading), the rest side by side.
-        // CRM_SETUP_THREADS=1 keeps everything on the calling thread; so does a rocprofiler tool in
-        // the process (rocprofv3's kernel trace segfaulted in 2 of 3 runs with launches coming from
-        // eleven threads at once; never without the tool).
-        const char* tenv = getenv("CRM_SETUP_THREADS");
-        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY_CTOR");
-        const bool serial = tenv ? atoi(tenv) <= 1 : profiled;
-        rcs[0] = decompose(0);
-        if (rcs[0] != CRM_OK) errs[0] = last_error_text();
-        for (int i = 1; i < nrho && rcs[0] == CRM_OK; i++) {
-            if (serial) {
-                rcs[i] = decompose(i);
-                if (rcs[i] != CRM_OK) errs[i] = last_error_text();
+        EighWork ew;
+        struct EGuard { EighWork& w; ~EGuard() { eigh_free(w); } } eguard{ew};
+        CRM_BG(eigh_alloc(ew, nrho, dim));
+        CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nrho * ew.slab, st));
+        for (int i = 0; i < nrho; i++) {
+            bg->rho[i] = rho[i];
+            const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
+            double* Ai = ew.A.as<double>() + (size_t)i * ew.slab;
+            if (thin) {
+                dim3 grid((unsigned)((cols + 255) / 256), (unsigned)cols);
+                hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)cols, k1, a, b,
+                                   Ai, ew.ld);
             } else {
-                workers.emplace_back([&, i]() {
-                    rcs[i] = decompose(i);
-                    if (rcs[i] != CRM_OK) errs[i] = last_error_text();
-                });
+                // Sigma(rho) = rho E1 E1' + (1 - rho) B B'
+                dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+                hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, st, dG.as<double>(),
+                                   dG.as<double>() + dimp * dimp, dimp, (int)n, rho[i], 1.0 - rho[i], Ai);
             }
         }
-        for (auto& w : workers) w.join();
+        CRM_BG_HIP(hipGetLastError());
+        std::vector<double> lam((size_t)nrho * dim);
+        double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
+        CRM_BG(eigh_batched(ctx, ew, lam.data(), &Zt));
+        lap("eigen-decompositions");
+        ScopedBuf wKeep, wLam;
+        CRM_BG(wKeep.ensure(sizeof(int) * dimp));
+        CRM_BG(wLam.ensure(sizeof(double) * dimp));
         for (int i = 0; i < nrho; i++) {
-            if (rcs[i] != CRM_OK) {
-                set_error("%s", errs[i].c_str());
-                return fail(rcs[i]);
+            const double* hW = &lam[(size_t)i * dim];   // ascending
+            const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
+            std::vector<int> keep;
+            if (thin) {
+                const double cut = rel_tol * std::max(hW[dim - 1], 0.0);
+                for (long j = dim - 1; j >= 0; j--)  // descending, like singular values
+                    if (hW[j] > cut && hW[j] > 0.0) keep.push_back((int)j);
+            } else {
+                const double eps_small = 1.4901161193847656e-08;  // sqrt(machine eps), _math.py:204
+                for (long j = 0; j < dim; j++)                    // ascending, like eigh
+                    if (hW[j] >= eps_small) keep.push_back((int)j);
             }
-            rmax = std::max<long>(rmax, bg->r[i]);
+            const int r = (int)keep.size();
+            bg->r[i] = r;
+            rmax = std::max<long>(rmax, r);
+            S0_host[i].resize(r);
+            for (int j = 0; j < r; j++) S0_host[i][j] = hW[keep[j]];
+            // keep what pass 2 needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
+            const long ldm = round_up(std::max(r, 1), 128);
+            CRM_BG(Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
+            CRM_BG_HIP(hipMemsetAsync(Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
+            if (r > 0) {
+                const double* Vi = Zt + (size_t)i * ew.slab;
+                CRM_BG_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
+                CRM_BG_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * dim, hipMemcpyHostToDevice, st));
+                if (thin) {
+                    dim3 grid((unsigned)((r + 255) / 256), (unsigned)cols);
+                    hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wLam.as<double>(),
+                                       wKeep.as<int>(), r, (int)cols, k1, a, b, Mbuf[i].as<double>(), ldm);
+                } else {
+                    dim3 grid((unsigned)((r + 255) / 256), (unsigned)n);
+                    hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wKeep.as<int>(), r, n,
+                                       Mbuf[i].as<double>(), ldm);
+                }
+                CRM_BG_HIP(hipGetLastError());
+            }
+            CRM_BG_HIP(hipStreamSynchronize(st));   // keep / hW are reused by the next grid point
         }
     }
-    lap("eigen-decompositions");
     // pass 2: Q0 buffers with the common leading dimension
     bg->ldq = round_up(rmax, 128);
     const long ldq = bg->ldq;

@@ -4,6 +4,8 @@
 // three contractions on the FP64 matrix pipe (V' Z over the rows, T through its transpose, the update with
 // GEMM_SUBTRACT), T from the block's Gram matrix V'V by the dlarft recurrence (one workgroup per block).
 // Plus the driver of the whole eigen-solver and its allocation.
+#include <chrono>
+
 #include "eigh.h"
 
 namespace crm {
@@ -188,10 +190,22 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
 }
 
 int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt) {
+    const bool trace = getenv("CRM_TRACE_SETUP") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[crm eigh %d x %ld] %-24s %.3f s\n", w.batch, w.dim, what, std::chrono::duration<double>(now - t0).count());
+        t0 = now;
+    };
     CRM_TRY(eigh_tridiagonalise(ctx, w));
+    lap("tridiagonalisation");
     double* Qt = nullptr;
     CRM_TRY(eigh_dc(ctx, w, lam_host, &Qt));
+    lap("divide & conquer");
     CRM_TRY(eigh_back_transform(ctx, w, Qt, Zt));
+    lap("back-transformation");
     return CRM_OK;
 }
 

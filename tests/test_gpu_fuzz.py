@@ -51,7 +51,10 @@ def _run(polish):
                 pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
                 same = info["rho1"] == oinfo["rho1"]
                 for j in range(G.shape[1]):
-                    rows.append((abs(st["Q"][j] - ost["Q"][j]) / abs(ost["Q"][j]), abs(pv[j] - opv[j]) / opv[j],
+                    # (Q against max(Q, E[Q] under the null = tr F): a score vector that nearly vanishes, p ~ 1,
+                    # leaves Q itself ill-conditioned)
+                    qscale = max(abs(ost["Q"][j]), float(np.trace(ost["F"][j])))
+                    rows.append((abs(st["Q"][j] - ost["Q"][j]) / qscale, abs(pv[j] - opv[j]) / opv[j],
                                  abs(pv[j] - opv[j]), abs(st["lml"][j] - ost["lml"][j]) / abs(ost["lml"][j]),
                                  bool(same[j]), opv[j]))
     finally:

@@ -39,7 +39,8 @@ def _spread(a, b):
     pa, ia, sa = a
     pb, ib, sb = b
     same = ia["rho1"] == ib["rho1"]
-    q = np.abs(sa["Q"][same] - sb["Q"][same]) / np.abs(sa["Q"][same])
+    trF = np.array([np.trace(F) for F in sa["F"]])
+    q = np.abs(sa["Q"][same] - sb["Q"][same]) / np.maximum(np.abs(sa["Q"][same]), trF[same])  # as tests/test_gpu_fuzz.py
     p = np.abs(pa[same] - pb[same]) / pa[same]
     return q, p, int((~same).sum())
 
