@@ -170,6 +170,64 @@ def _make_background_dense(E1, B, rho, device, rel_tol=0.0, cache=True):
     return bg
 
 
+class BackgroundBuilder:
+    """The constructor's three phases (``crm_background_begin / _complete / _seal``) for a process that owns
+    only the grid points flagged in ``mine``; the others arrive through ``import_slot``
+    (``cellregmap_amd.distributed.sharded_background`` drives several of these, one per GPU)."""
+
+    SLOTS = {"Q0": 0, "S0": 1, "Mix": 2}
+
+    def __init__(self, E1, B, rho, device=0, mine=None, rel_tol=0.0):
+        lib = _lib.load()
+        self.device = device
+        self.rho = _lib.f64(rho)
+        nrho = self.rho.shape[0]
+        flags = np.ones(nrho, np.int32) if mine is None else np.ascontiguousarray(mine, dtype=np.int32)
+        E1c = _lib.f64(E1)
+        h = ctypes.c_void_p()
+        if isinstance(B, HadamardHalves):
+            _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
+                                                B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.us), B.us.shape[1],
+                                                _lib.ptr(B.hK), B.hK.shape[1], nrho, _lib.ptr(self.rho), _lib.ptr(flags),
+                                                float(rel_tol), ctypes.byref(h)))
+        else:
+            Bc = None if B is None else _lib.f64(B)
+            _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(Bc),
+                                                0 if Bc is None else Bc.shape[1], None, 0, None, 0, nrho,
+                                                _lib.ptr(self.rho), _lib.ptr(flags), float(rel_tol), ctypes.byref(h)))
+        self._bg = _Background(h, self.rho, device)   # (owns the handle from here on)
+        self.nrho = nrho
+
+    def rank(self, i):
+        """Rank of an owned grid point after ``begin``; -1 for the others."""
+        return _lib.load().crm_background_rank(self._bg.handle, i)
+
+    def complete(self, ranks):
+        ranks = np.ascontiguousarray(ranks, dtype=np.int32)
+        _lib.check(_lib.load().crm_background_complete(self._bg.handle, _lib.ptr(ranks)))
+
+    def layout(self):
+        """Slot sizes in doubles: {"Q0": n_pad * ldq, "S0": ldq, "Mix": ldh * ldq (absent without mixing matrices)}."""
+        n_pad, ldq, ldh, mix = ctypes.c_long(), ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+        _lib.check(_lib.load().crm_background_layout(self._bg.handle, ctypes.byref(n_pad), ctypes.byref(ldq),
+                                                     ctypes.byref(ldh), ctypes.byref(mix)))
+        out = {"Q0": n_pad.value * ldq.value, "S0": ldq.value}
+        if mix.value:
+            out["Mix"] = ldh.value * ldq.value
+        return out
+
+    def export_slot(self, i, what, tensor):
+        """Copy slot ``what`` of grid point i into ``tensor`` (float64, on this GPU)."""
+        _lib.check(_lib.load().crm_background_export(self._bg.handle, i, self.SLOTS[what], ctypes.c_void_p(tensor.data_ptr())))
+
+    def import_slot(self, i, what, tensor):
+        _lib.check(_lib.load().crm_background_import(self._bg.handle, i, self.SLOTS[what], ctypes.c_void_p(tensor.data_ptr())))
+
+    def seal(self):
+        _lib.check(_lib.load().crm_background_seal(self._bg.handle))
+        return self._bg
+
+
 def background_from_qs(qs_list, rho, device=0):
     """Background from precomputed ``((Q0,), S0)`` pairs (one per rho), e.g. LAPACK's."""
     lib = _lib.load()

@@ -30,6 +30,13 @@ SIGNATURES = {
     "crm_background_create_hadamard": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_int, vp,
                                                       ctypes.c_int, ctypes.c_int, vp, ctypes.c_double,
                                                       ctypes.POINTER(vp)]),
+    "crm_background_begin": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long, vp, ctypes.c_int, vp,
+                                            ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.POINTER(vp)]),
+    "crm_background_complete": (ctypes.c_int, [vp, vp]),
+    "crm_background_layout": (ctypes.c_int, [vp, c_long_p, c_long_p, c_long_p, c_int_p]),
+    "crm_background_export": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "crm_background_import": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "crm_background_seal": (ctypes.c_int, [vp]),
     "crm_background_destroy": (None, [vp]),
     "crm_background_rank": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_background_read": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),

@@ -146,10 +146,50 @@ __global__ void hadamard_halves_kernel(const double* __restrict__ U, int k2, con
 }  // namespace
 }  // namespace crm
 
+// ---- the constructor in three phases -----------------------------------------------------------------
+// begin    : upload the half factor H = [E1, B], its Gram matrix (thin branch) or E1E1' and BB' (eigh
+//            branch), eigen-decompositions of the grid points this process owns -> their ranks
+// complete : given the ranks of ALL grid points (they fix the common leading dimension): buffers for every
+//            grid point, Q0 = H Mix (+ orthonormality polish) for the owned ones
+// seal     : spectra of all grid points known (owned ones computed, the others imported): decide whether the
+//            rotations may go through the mixing matrices, drop the builder
+// One process: begin(all) -> complete -> seal.  Several processes (one per GPU): every rank owns a share of the
+// grid points, the ranks are all-gathered, and Q0 / S0 / Mix of each grid point are broadcast by its owner
+// through crm_background_export / _import (cellregmap_amd/distributed.py).
+struct crm_background_builder {
+    Scratch S;
+    std::vector<DevBuf> Mbuf;                  // per grid point: mixing matrix (thin) or eigenvectors (eigh)
+    std::vector<std::vector<double>> S0_host;  // kept eigenvalues per grid point
+    std::vector<int> mine;
+    long n = 0, np = 0, cols = 0, cp = 0, dim = 0, dimp = 0;
+    int k1 = 0;
+    bool thin = true, completed = false;
+    double rel_tol = 1e-12;
+    ~crm_background_builder() {
+        for (auto& b : Mbuf) b.release();
+    }
+};
+
+namespace {
+struct SetupTrace {
+    hipStream_t st;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit SetupTrace(hipStream_t s) : st(s), on(getenv("CRM_TRACE_SETUP") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[crm background] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 // B given explicitly (kb columns), or as Hadamard factors U (n x k2) and hK (n x m) with kb = k2 * m
-static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
-                                  const double* U, int k2, const double* hK, int m, int nrho,
-                                  const double* rho, double rel_tol, crm_background** out) {
+static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb, const double* U,
+                            int k2, const double* hK, int m, int nrho, const double* rho, const int* mine_flags,
+                            double rel_tol, crm_background** out) {
     if (!ctx || !out || n <= 0 || !E1 || k1 < 1 || kb < 0 || (kb > 0 && !B && !(U && hK)) || nrho < 1 || !rho)
         return CRM_ERR_ARG;
     if (nrho > CRM_MAX_RHO) {
@@ -160,52 +200,27 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     if (rel_tol <= 0.0) rel_tol = 1e-12;
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool trace = getenv("CRM_TRACE_SETUP") != nullptr;
-    auto t_mark = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!trace) return;
-        (void)hipStreamSynchronize(st);
-        auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[crm background] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_mark).count());
-        t_mark = now;
-    };
+    SetupTrace trace(st);
     const long cols = k1 + kb;
     const long np = round_up(n, CELL_PAD);
     const long cp = round_up(cols, 128);
     const bool thin = n > cols;  // economic_qs_linear: rows > cols -> SVD branch
 
-
-    Scratch S;
-    DevBuf &dH = S.bufs[0], &dHt = S.bufs[1], &dC = S.bufs[2], &dMt = S.bufs[9],
-           &dG = S.bufs[10], &dErr = S.bufs[11], &dQt = S.bufs[12];
-    // H = [E1, B] (cells x cols) and its transpose
-    CRM_TRY(dH.ensure(sizeof(double) * np * cp));
-    CRM_HIP(hipMemsetAsync(dH.ptr, 0, sizeof(double) * np * cp, st));
-    CRM_HIP(hipMemcpy2DAsync(dH.ptr, cp * sizeof(double), E1, k1 * sizeof(double), k1 * sizeof(double), n,
-                             hipMemcpyHostToDevice, st));
-    if (kb > 0 && B) {
-        CRM_HIP(hipMemcpy2DAsync(dH.as<double>() + k1, cp * sizeof(double), B, kb * sizeof(double),
-                                 kb * sizeof(double), n, hipMemcpyHostToDevice, st));
-    } else if (kb > 0) {
-        ScopedBuf dU, dK;
-        CRM_TRY(dU.ensure(sizeof(double) * n * k2));
-        CRM_TRY(dK.ensure(sizeof(double) * n * m));
-        CRM_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
-        CRM_HIP(hipMemcpyAsync(dK.ptr, hK, sizeof(double) * n * m, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(hadamard_halves_kernel, dim3((unsigned)n), dim3(256), 0, st, dU.as<double>(), k2,
-                           dK.as<double>(), m, n, dH.as<double>(), cp, k1);
-        CRM_HIP(hipGetLastError());
-        CRM_HIP(hipStreamSynchronize(st));
-    }
-    CRM_TRY(dHt.ensure(sizeof(double) * cp * np));
-    CRM_HIP(hipMemsetAsync(dHt.ptr, 0, sizeof(double) * cp * np, st));
-    CRM_TRY(transpose(st, dH.as<double>(), cp, n, cols, dHt.as<double>(), np));
-
     crm_background* bg = new crm_background();
+    crm_background_builder* bb = new crm_background_builder();
+    bg->builder = bb;
     bg->ctx = ctx;
     bg->n = n;
     bg->n_pad = np;
     bg->nrho = nrho;
+    bb->n = n; bb->np = np; bb->cols = cols; bb->cp = cp; bb->k1 = k1; bb->thin = thin; bb->rel_tol = rel_tol;
+    bb->Mbuf.resize(nrho);
+    bb->S0_host.resize(nrho);
+    for (int i = 0; i < nrho; i++) {
+        bg->rho[i] = rho[i];
+        bg->r[i] = -1;
+        if (!mine_flags || mine_flags[i]) bb->mine.push_back(i);
+    }
     auto fail = [&](int code) {
         crm_background_destroy(bg);
         return code;
@@ -223,17 +238,39 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
             return fail(CRM_ERR_HIP);                                                       \
         }                                                                                   \
     } while (0)
+    DevBuf &dH = bb->S.bufs[0], &dHt = bb->S.bufs[1], &dC = bb->S.bufs[2], &dMt = bb->S.bufs[9], &dG = bb->S.bufs[10];
+    // H = [E1, B] (cells x cols) and its transpose
+    CRM_BG(dH.ensure(sizeof(double) * np * cp));
+    CRM_BG_HIP(hipMemsetAsync(dH.ptr, 0, sizeof(double) * np * cp, st));
+    CRM_BG_HIP(hipMemcpy2DAsync(dH.ptr, cp * sizeof(double), E1, k1 * sizeof(double), k1 * sizeof(double), n,
+                                hipMemcpyHostToDevice, st));
+    if (kb > 0 && B) {
+        CRM_BG_HIP(hipMemcpy2DAsync(dH.as<double>() + k1, cp * sizeof(double), B, kb * sizeof(double),
+                                    kb * sizeof(double), n, hipMemcpyHostToDevice, st));
+    } else if (kb > 0) {
+        ScopedBuf dU, dK;
+        CRM_BG(dU.ensure(sizeof(double) * n * k2));
+        CRM_BG(dK.ensure(sizeof(double) * n * m));
+        CRM_BG_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
+        CRM_BG_HIP(hipMemcpyAsync(dK.ptr, hK, sizeof(double) * n * m, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(hadamard_halves_kernel, dim3((unsigned)n), dim3(256), 0, st, dU.as<double>(), k2,
+                           dK.as<double>(), m, n, dH.as<double>(), cp, k1);
+        CRM_BG_HIP(hipGetLastError());
+        CRM_BG_HIP(hipStreamSynchronize(st));
+    }
+    CRM_BG(dHt.ensure(sizeof(double) * cp * np));
+    CRM_BG_HIP(hipMemsetAsync(dHt.ptr, 0, sizeof(double) * cp * np, st));
+    CRM_BG(transpose(st, dH.as<double>(), cp, n, cols, dHt.as<double>(), np));
 
-    const long dim = thin ? cols : n;       // order of the matrix that gets diagonalised
+    const long dim = thin ? cols : n;       // order of the matrices that get diagonalised
     const long dimp = round_up(dim, 128);
-    std::vector<std::vector<double>> S0_host(nrho);
-
+    bb->dim = dim; bb->dimp = dimp;
     if (thin) {
         // Gram matrix of the unscaled half factor, once
         CRM_BG(dC.ensure(sizeof(double) * cp * cp));
+        CRM_BG_HIP(hipMemsetAsync(dC.ptr, 0, sizeof(double) * cp * cp, st));   // (its padding is an operand later)
         CRM_BG(contract(ctx, dH.as<double>(), cp, dH.as<double>(), cp, dC.as<double>(), cp, (int)cols, (int)cols, np));
-    }
-    if (!thin) {
+    } else {
         // E1 E1' and B B' (n x n), contraction over the column axis = rows of Ht; row blocks are
         // copied into zero-padded scratch so that their counts are multiples of the stage depth
         const long k1p = round_up(k1, GEMM_BK), kbp = round_up(std::max<long>(kb, 1), GEMM_BK);
@@ -252,25 +289,19 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
         CRM_BG(contract(ctx, E1t, np, E1t, np, S1, dimp, (int)n, (int)n, k1p));
         if (kb > 0) CRM_BG(contract(ctx, Bt, np, Bt, np, S2, dimp, (int)n, (int)n, kbp));
     }
-    // pass 1: eigen-decompositions of all grid points at once (eigh*.hip); ranks decide the common leading
-    // dimension (Q0 buffers are allocated after all ranks are known)
-    std::vector<DevBuf> Mbuf(nrho);
-    struct MGuard {
-        std::vector<DevBuf>& v;
-        ~MGuard() { for (auto& b : v) b.release(); }
-    } mguard{Mbuf};
-    long rmax = 1;
     CRM_BG_HIP(hipStreamSynchronize(st));
-    lap("half factor + Gram");
-    {
+    trace.lap("half factor + Gram");
+    // eigen-decompositions of the owned grid points, all at once (eigh*.hip)
+    const int nmine = (int)bb->mine.size();
+    if (nmine > 0) {
         EighWork ew;
         struct EGuard { EighWork& w; ~EGuard() { eigh_free(w); } } eguard{ew};
-        CRM_BG(eigh_alloc(ew, nrho, dim));
-        CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nrho * ew.slab, st));
-        for (int i = 0; i < nrho; i++) {
-            bg->rho[i] = rho[i];
+        CRM_BG(eigh_alloc(ew, nmine, dim));
+        CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nmine * ew.slab, st));
+        for (int q = 0; q < nmine; q++) {
+            const int i = bb->mine[q];
             const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
-            double* Ai = ew.A.as<double>() + (size_t)i * ew.slab;
+            double* Ai = ew.A.as<double>() + (size_t)q * ew.slab;
             if (thin) {
                 dim3 grid((unsigned)((cols + 255) / 256), (unsigned)cols);
                 hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)cols, k1, a, b,
@@ -283,15 +314,16 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
             }
         }
         CRM_BG_HIP(hipGetLastError());
-        std::vector<double> lam((size_t)nrho * dim);
+        std::vector<double> lam((size_t)nmine * dim);
         double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
         CRM_BG(eigh_batched(ctx, ew, lam.data(), &Zt));
-        lap("eigen-decompositions");
+        trace.lap("eigen-decompositions");
         ScopedBuf wKeep, wLam;
         CRM_BG(wKeep.ensure(sizeof(int) * dimp));
         CRM_BG(wLam.ensure(sizeof(double) * dimp));
-        for (int i = 0; i < nrho; i++) {
-            const double* hW = &lam[(size_t)i * dim];   // ascending
+        for (int q = 0; q < nmine; q++) {
+            const int i = bb->mine[q];
+            const double* hW = &lam[(size_t)q * dim];   // ascending
             const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
             std::vector<int> keep;
             if (thin) {
@@ -305,37 +337,64 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
             }
             const int r = (int)keep.size();
             bg->r[i] = r;
-            rmax = std::max<long>(rmax, r);
-            S0_host[i].resize(r);
-            for (int j = 0; j < r; j++) S0_host[i][j] = hW[keep[j]];
-            // keep what pass 2 needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
+            bb->S0_host[i].resize(r);
+            for (int j = 0; j < r; j++) bb->S0_host[i][j] = hW[keep[j]];
+            // keep what `complete` needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
             const long ldm = round_up(std::max(r, 1), 128);
-            CRM_BG(Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
-            CRM_BG_HIP(hipMemsetAsync(Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
+            CRM_BG(bb->Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
+            CRM_BG_HIP(hipMemsetAsync(bb->Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
             if (r > 0) {
-                const double* Vi = Zt + (size_t)i * ew.slab;
+                const double* Vi = Zt + (size_t)q * ew.slab;
                 CRM_BG_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
                 CRM_BG_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * dim, hipMemcpyHostToDevice, st));
                 if (thin) {
                     dim3 grid((unsigned)((r + 255) / 256), (unsigned)cols);
                     hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wLam.as<double>(),
-                                       wKeep.as<int>(), r, (int)cols, k1, a, b, Mbuf[i].as<double>(), ldm);
+                                       wKeep.as<int>(), r, (int)cols, k1, a, b, bb->Mbuf[i].as<double>(), ldm);
                 } else {
                     dim3 grid((unsigned)((r + 255) / 256), (unsigned)n);
                     hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wKeep.as<int>(), r, n,
-                                       Mbuf[i].as<double>(), ldm);
+                                       bb->Mbuf[i].as<double>(), ldm);
                 }
                 CRM_BG_HIP(hipGetLastError());
             }
             CRM_BG_HIP(hipStreamSynchronize(st));   // keep / hW are reused by the next grid point
         }
     }
-    // pass 2: Q0 buffers with the common leading dimension
+    *out = bg;
+    return CRM_OK;
+}
+
+// ranks of all grid points known: buffers for every grid point; Q0 = H Mix and the polish for the owned ones
+static int background_complete(crm_background* bg, const int* r_all) {
+    crm_background_builder* bb = bg->builder;
+    if (!bb || bb->completed) {
+        set_error("background: complete called out of order");
+        return CRM_ERR_ARG;
+    }
+    crm_ctx* ctx = bg->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    SetupTrace trace(st);
+    const long n = bb->n, np = bb->np, cols = bb->cols, cp = bb->cp;
+    const bool thin = bb->thin;
+    const int nrho = bg->nrho;
+    long rmax = 1;
+    for (int i = 0; i < nrho; i++) {
+        const int r = r_all ? r_all[i] : bg->r[i];
+        if (r < 0 || (bg->r[i] >= 0 && bg->r[i] != r)) {
+            set_error("background: rank of grid point %d missing or inconsistent (%d vs %d)", i, r, bg->r[i]);
+            return CRM_ERR_ARG;
+        }
+        bg->r[i] = r;
+        rmax = std::max<long>(rmax, r);
+    }
     bg->ldq = round_up(rmax, 128);
     const long ldq = bg->ldq;
+    DevBuf &dH = bb->S.bufs[0], &dHt = bb->S.bufs[1], &dC = bb->S.bufs[2], &dMt = bb->S.bufs[9], &dG = bb->S.bufs[10],
+           &dErr = bb->S.bufs[11], &dQt = bb->S.bufs[12], &dT1 = bb->S.bufs[3];
     dG.release();
     dMt.release();
-    dC.release();
     if (thin) {
         // keep the half factor: T(rho) = Q0(rho)'G is later taken as Mix(rho)' (H'G), see scan.hip
         bg->H = dH;
@@ -345,88 +404,146 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
     } else {
         dH.release();
     }
-    CRM_BG(dG.ensure(sizeof(double) * ldq * ldq * 2));
-    CRM_BG(dQt.ensure(sizeof(double) * ldq * np));
-    CRM_BG(dErr.ensure(sizeof(double) * ((ldq + 255) / 256) * ldq));
+    CRM_TRY(dG.ensure(sizeof(double) * ldq * ldq * 2));
+    CRM_TRY(dQt.ensure(sizeof(double) * ldq * std::max(np, cp)));
+    CRM_TRY(dErr.ensure(sizeof(double) * ((ldq + 255) / 256) * ldq));
+    if (thin) {
+        CRM_TRY(dT1.ensure(sizeof(double) * cp * ldq));
+        CRM_HIP(hipMemsetAsync(dT1.ptr, 0, sizeof(double) * cp * ldq, st));
+    }
+    CRM_HIP(hipMemsetAsync(dG.ptr, 0, sizeof(double) * ldq * ldq * 2, st));
     for (int i = 0; i < nrho; i++) {
-        const int r = bg->r[i];
-        CRM_BG(bg->Q0[i].ensure(sizeof(double) * np * ldq));
-        CRM_BG(bg->S0[i].ensure(sizeof(double) * ldq));
-        CRM_BG_HIP(hipMemsetAsync(bg->Q0[i].ptr, 0, sizeof(double) * np * ldq, st));
-        CRM_BG_HIP(hipMemsetAsync(bg->S0[i].ptr, 0, sizeof(double) * ldq, st));
-        if (r == 0) continue;
-        CRM_BG_HIP(hipMemcpyAsync(bg->S0[i].ptr, S0_host[i].data(), sizeof(double) * r, hipMemcpyHostToDevice, st));
-        const long ldm = round_up(r, 128);
-        if (!thin) {
-            CRM_BG_HIP(hipMemcpy2DAsync(bg->Q0[i].ptr, ldq * sizeof(double), Mbuf[i].ptr, ldm * sizeof(double),
-                                        r * sizeof(double), n, hipMemcpyDeviceToDevice, st));
-        } else {
-            // Q0 = H M  ==  Ht' M  (contraction over the cols axis)
-            CRM_BG(contract(ctx, dHt.as<double>(), np, Mbuf[i].as<double>(), ldm, bg->Q0[i].as<double>(), ldq,
-                            (int)n, r, cp));
-        }
-        CRM_BG_HIP(hipStreamSynchronize(st));
+        CRM_TRY(bg->Q0[i].ensure(sizeof(double) * np * ldq));
+        CRM_TRY(bg->S0[i].ensure(sizeof(double) * ldq));
+        CRM_HIP(hipMemsetAsync(bg->Q0[i].ptr, 0, sizeof(double) * np * ldq, st));
+        CRM_HIP(hipMemsetAsync(bg->S0[i].ptr, 0, sizeof(double) * ldq, st));
         if (thin) {
-            CRM_BG(bg->Mix[i].ensure(sizeof(double) * cp * ldq));
-            CRM_BG_HIP(hipMemsetAsync(bg->Mix[i].ptr, 0, sizeof(double) * cp * ldq, st));
-            CRM_BG_HIP(hipMemcpy2DAsync(bg->Mix[i].ptr, ldq * sizeof(double), Mbuf[i].ptr, ldm * sizeof(double),
-                                        r * sizeof(double), cols, hipMemcpyDeviceToDevice, st));
-            CRM_BG_HIP(hipStreamSynchronize(st));
+            CRM_TRY(bg->Mix[i].ensure(sizeof(double) * cp * ldq));
+            CRM_HIP(hipMemsetAsync(bg->Mix[i].ptr, 0, sizeof(double) * cp * ldq, st));
         }
-        Mbuf[i].release();
-        // Newton-Schulz polish of the orthonormality: Q0 <- Q0 (1.5 I - 0.5 Q0'Q0).  The Gram route
-        // loses it for small eigenvalues (defect ~ eps * S_max / S_j) and the library eigenvectors
-        // of the n x n route carry ~1e-13; the path's complement terms (u'v - (Q0'u)'(Q0'v)) / d see
-        // any defect directly.
-        double* Gq = dG.as<double>();
-        double* N = Gq + ldq * ldq;
-        for (int pass = 0; pass < 4; pass++) {
-            CRM_BG(contract(ctx, bg->Q0[i].as<double>(), ldq, bg->Q0[i].as<double>(), ldq, Gq, ldq, r, r, np));
-            dim3 grid((unsigned)((r + 255) / 256), (unsigned)r);
-            CRM_BG_HIP(hipMemsetAsync(N, 0, sizeof(double) * ldq * ldq, st));
-            hipLaunchKernelGGL(newton_schulz_kernel, grid, dim3(256), 0, st, Gq, ldq, r, N, ldq, dErr.as<double>());
-            CRM_BG_HIP(hipGetLastError());
-            std::vector<double> herr((size_t)grid.x * grid.y);
-            CRM_BG_HIP(hipMemcpyAsync(herr.data(), dErr.ptr, sizeof(double) * herr.size(), hipMemcpyDeviceToHost, st));
-            CRM_BG_HIP(hipStreamSynchronize(st));
-            double err = 0.0;
-            for (double e : herr) err = std::max(err, e);
-            if (!(err < 0.5)) {
-                set_error("background: Q0 lost orthonormality at rho=%g (defect %g)", rho[i], err);
-                return fail(CRM_ERR_NUMERIC);
+    }
+    double* Gq = dG.as<double>();
+    double* N = Gq + ldq * ldq;
+    auto defect_and_correction = [&](int r, double* err_out) -> int {
+        // N = 1.5 I - 0.5 G, err = max |G - I|
+        dim3 grid((unsigned)((r + 255) / 256), (unsigned)r);
+        CRM_HIP(hipMemsetAsync(N, 0, sizeof(double) * ldq * ldq, st));
+        hipLaunchKernelGGL(newton_schulz_kernel, grid, dim3(256), 0, st, Gq, ldq, r, N, ldq, dErr.as<double>());
+        CRM_HIP(hipGetLastError());
+        std::vector<double> herr((size_t)grid.x * grid.y);
+        CRM_HIP(hipMemcpyAsync(herr.data(), dErr.ptr, sizeof(double) * herr.size(), hipMemcpyDeviceToHost, st));
+        CRM_HIP(hipStreamSynchronize(st));
+        double err = 0.0;
+        for (double e : herr) err = std::max(err, e);
+        *err_out = err;
+        return CRM_OK;
+    };
+    for (int i : bb->mine) {
+        const int r = bg->r[i];
+        if (r == 0) continue;
+        CRM_HIP(hipMemcpyAsync(bg->S0[i].ptr, bb->S0_host[i].data(), sizeof(double) * r, hipMemcpyHostToDevice, st));
+        const long ldm = round_up(r, 128);
+        if (thin) {
+            double* Mix = bg->Mix[i].as<double>();
+            CRM_HIP(hipMemcpy2DAsync(Mix, ldq * sizeof(double), bb->Mbuf[i].ptr, ldm * sizeof(double), r * sizeof(double),
+                                     cols, hipMemcpyDeviceToDevice, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            bb->Mbuf[i].release();
+            // Newton-Schulz polish of the orthonormality, in the space of the half factor's columns:
+            // Q0'Q0 = Mix' (H'H) Mix with the Gram matrix C = H'H at hand, so a pass costs three products of
+            // order cols^2 r instead of n r^2; Q0 = H Mix is then formed once.  The Gram route loses
+            // orthonormality for small eigenvalues (defect ~ eps * S_max / S_j) and the path's complement
+            // terms (u'v - (Q0'u)'(Q0'v)) / d see any defect directly.
+            for (int pass = 0; pass < 3; pass++) {
+                CRM_TRY(contract(ctx, dC.as<double>(), cp, Mix, ldq, dT1.as<double>(), ldq, (int)cols, r, cp));   // C Mix
+                CRM_TRY(contract(ctx, Mix, ldq, dT1.as<double>(), ldq, Gq, ldq, r, r, cp));                         // Mix' C Mix
+                double err = 0.0;
+                CRM_TRY(defect_and_correction(r, &err));
+                if (!(err < 0.5)) {
+                    set_error("background: Q0 lost orthonormality at rho=%g (defect %g)", bg->rho[i], err);
+                    return CRM_ERR_NUMERIC;
+                }
+                bg->ortho_defect[i] = err;
+                if (err < 2e-14 || pass == 2) break;
+                // Mix <- Mix N : contraction over r with X = Mix' (r x cols)
+                CRM_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * cp, st));
+                CRM_TRY(transpose(st, Mix, ldq, cols, r, dQt.as<double>(), cp));
+                CRM_TRY(contract(ctx, dQt.as<double>(), cp, N, ldq, Mix, ldq, (int)cols, r, round_up(r, GEMM_BK)));
             }
-            bg->ortho_defect[i] = err;
-            if (err < 2e-14 || pass == 2) break;
-            // Q0 <- Q0 N : contraction over r with X = Q0' (r x cells)
-            CRM_BG_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * np, st));
-            CRM_BG(transpose(st, bg->Q0[i].as<double>(), ldq, n, r, dQt.as<double>(), np));
-            CRM_BG(contract(ctx, dQt.as<double>(), np, N, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, round_up(r, GEMM_BK)));
-            if (thin) {
-                // the same correction on the mixing matrix keeps Q0 == H Mix:  Mix <- Mix N
-                CRM_BG_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * std::min(np, cp), st));
-                CRM_BG(transpose(st, bg->Mix[i].as<double>(), ldq, cols, r, dQt.as<double>(), cp));
-                CRM_BG(contract(ctx, dQt.as<double>(), cp, N, ldq, bg->Mix[i].as<double>(), ldq, (int)cols, r,
-                                round_up(r, GEMM_BK)));
+            // Q0 = H Mix  ==  Ht' Mix  (contraction over the cols axis)
+            CRM_TRY(contract(ctx, dHt.as<double>(), np, Mix, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, cp));
+        } else {
+            CRM_HIP(hipMemcpy2DAsync(bg->Q0[i].ptr, ldq * sizeof(double), bb->Mbuf[i].ptr, ldm * sizeof(double),
+                                     r * sizeof(double), n, hipMemcpyDeviceToDevice, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            bb->Mbuf[i].release();
+            // eigenvectors of the n x n route: orthonormal to ~1e-14 sqrt(n) as they come; one check, and a
+            // correction if ever needed
+            for (int pass = 0; pass < 3; pass++) {
+                CRM_TRY(contract(ctx, bg->Q0[i].as<double>(), ldq, bg->Q0[i].as<double>(), ldq, Gq, ldq, r, r, np));
+                double err = 0.0;
+                CRM_TRY(defect_and_correction(r, &err));
+                if (!(err < 0.5)) {
+                    set_error("background: Q0 lost orthonormality at rho=%g (defect %g)", bg->rho[i], err);
+                    return CRM_ERR_NUMERIC;
+                }
+                bg->ortho_defect[i] = err;
+                if (err < 2e-14 || pass == 2) break;
+                // Q0 <- Q0 N : contraction over r with X = Q0' (r x cells)
+                CRM_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * np, st));
+                CRM_TRY(transpose(st, bg->Q0[i].as<double>(), ldq, n, r, dQt.as<double>(), np));
+                CRM_TRY(contract(ctx, dQt.as<double>(), np, N, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, round_up(r, GEMM_BK)));
             }
         }
     }
-    CRM_BG_HIP(hipStreamSynchronize(st));
-    lap("Q0 = H Mix + polish");
+    CRM_HIP(hipStreamSynchronize(st));
+    trace.lap("Q0 = H Mix + polish");
+    bb->completed = true;
+    return CRM_OK;
+}
+
+static int background_seal(crm_background* bg) {
+    crm_background_builder* bb = bg->builder;
+    if (!bb || !bb->completed) {
+        set_error("background: seal called out of order");
+        return CRM_ERR_ARG;
+    }
+    CRM_HIP(hipSetDevice(bg->ctx->device));
     // the mixing-matrix route amplifies rounding by sqrt(S_max / S_min): use it only for spectra
     // whose kept part is well conditioned
-    bg->fast_T = thin;
-    for (int i = 0; i < nrho && bg->fast_T; i++) {
-        if (bg->r[i] == 0) continue;
+    bg->fast_T = bb->thin;
+    std::vector<double> s0;
+    for (int i = 0; i < bg->nrho && bg->fast_T; i++) {
+        const int r = bg->r[i];
+        if (r == 0) continue;
+        s0.resize(r);
+        CRM_HIP(hipMemcpy(s0.data(), bg->S0[i].ptr, sizeof(double) * r, hipMemcpyDeviceToHost));  // (imported ones too)
         double smax = 0.0, smin = 1e300;
-        for (double v : S0_host[i]) { smax = std::max(smax, v); smin = std::min(smin, v); }
+        for (double v : s0) { smax = std::max(smax, v); smin = std::min(smin, v); }
         if (!(smax <= 1e6 * smin)) bg->fast_T = false;
     }
     if (!bg->fast_T) {
         bg->H.release();
-        for (int i = 0; i < nrho; i++) bg->Mix[i].release();
+        for (int i = 0; i < bg->nrho; i++) bg->Mix[i].release();
     }
+    delete bb;
+    bg->builder = nullptr;
+    return CRM_OK;
+}
 #undef CRM_BG
 #undef CRM_BG_HIP
+
+static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
+                                  const double* U, int k2, const double* hK, int m, int nrho,
+                                  const double* rho, double rel_tol, crm_background** out) {
+    crm_background* bg = nullptr;
+    CRM_TRY(background_begin(ctx, n, E1, k1, B, kb, U, k2, hK, m, nrho, rho, nullptr, rel_tol, &bg));
+    int rc = background_complete(bg, nullptr);
+    if (rc == CRM_OK) rc = background_seal(bg);
+    if (rc != CRM_OK) {
+        crm_background_destroy(bg);
+        return rc;
+    }
     *out = bg;
     return CRM_OK;
 }
@@ -444,3 +561,63 @@ extern "C" int crm_background_create_hadamard(crm_ctx* ctx, long n, const double
     if (!U || !hK || k2 < 1 || m < 1) return CRM_ERR_ARG;
     return background_create_core(ctx, n, E1, k1, nullptr, (long)k2 * m, U, k2, hK, m, nrho, rho, rel_tol, out);
 }
+
+// ---- the same constructor split over several processes (one per GPU) ------------------------------------------
+extern "C" int crm_background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
+                                    const double* U, int k2, const double* hK, int m, int nrho, const double* rho,
+                                    const int* mine, double rel_tol, crm_background** out) {
+    if (kb > 0 && !B && !(U && hK && k2 >= 1 && m >= 1 && (long)k2 * m == kb)) return CRM_ERR_ARG;
+    return background_begin(ctx, n, E1, k1, B, kb, U, k2, hK, m, nrho, rho, mine, rel_tol, out);
+}
+
+extern "C" int crm_background_complete(crm_background* bg, const int* ranks) {
+    if (!bg || !ranks) return CRM_ERR_ARG;
+    return background_complete(bg, ranks);
+}
+
+extern "C" int crm_background_seal(crm_background* bg) {
+    if (!bg) return CRM_ERR_ARG;
+    return background_seal(bg);
+}
+
+extern "C" int crm_background_layout(const crm_background* bg, long* n_pad, long* ldq, long* ldh, int* has_mix) {
+    if (!bg || !bg->builder || !bg->builder->completed) return CRM_ERR_ARG;
+    if (n_pad) *n_pad = bg->n_pad;
+    if (ldq) *ldq = bg->ldq;
+    if (ldh) *ldh = bg->builder->thin ? bg->builder->cp : 0;
+    if (has_mix) *has_mix = bg->builder->thin ? 1 : 0;
+    return CRM_OK;
+}
+
+// what: 0 = Q0 (n_pad x ldq), 1 = S0 (ldq), 2 = Mix (ldh x ldq); device-to-device copies on the context's stream
+static int background_slot(const crm_background* bg, int i, int what, void** ptr, size_t* bytes) {
+    if (!bg || !bg->builder || !bg->builder->completed || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
+    const DevBuf* b = what == 0 ? &bg->Q0[i] : what == 1 ? &bg->S0[i] : what == 2 ? &bg->Mix[i] : nullptr;
+    if (!b || !b->ptr) return CRM_ERR_ARG;
+    *ptr = b->ptr;
+    *bytes = what == 0 ? sizeof(double) * bg->n_pad * bg->ldq
+                       : what == 1 ? sizeof(double) * bg->ldq : sizeof(double) * bg->builder->cp * bg->ldq;
+    return CRM_OK;
+}
+
+extern "C" int crm_background_export(const crm_background* bg, int i, int what, void* dst_device) {
+    void* p = nullptr;
+    size_t bytes = 0;
+    if (!dst_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(bg->ctx->device));
+    CRM_HIP(hipMemcpyAsync(dst_device, p, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
+    CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
+    return CRM_OK;
+}
+
+extern "C" int crm_background_import(crm_background* bg, int i, int what, const void* src_device) {
+    void* p = nullptr;
+    size_t bytes = 0;
+    if (!src_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(bg->ctx->device));
+    CRM_HIP(hipMemcpyAsync(p, src_device, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
+    CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
+    return CRM_OK;
+}
+
+void crm_background_builder_free(crm_background_builder* b) { delete b; }

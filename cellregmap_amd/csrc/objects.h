@@ -22,8 +22,12 @@ struct crm_donor_tables {
     void release() { TZ.release(); Bd.release(); Z2.release(); Z3.release(); }
 };
 
+struct crm_background_builder;   // state of a constructor in progress (background.hip)
+void crm_background_builder_free(crm_background_builder*);
+
 // Sigma(rho) = Q0 diag(S0) Q0' for every grid point (cellregmap/_cellregmap.py:95-131).
 struct crm_background {
+    crm_background_builder* builder = nullptr;   // non-null between `begin` and `seal`
     crm_ctx* ctx = nullptr;
     long n = 0, n_pad = 0;
     int nrho = 0;

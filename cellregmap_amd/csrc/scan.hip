@@ -113,6 +113,7 @@ void crm_background_destroy(crm_background* bg) {
         t->release();
         delete t;
     }
+    if (bg->builder) crm_background_builder_free(bg->builder);
     delete bg;
 }
 
@@ -137,6 +138,10 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
                     int k0, crm_gene** out) {
     if (!bg || !y || !W || !E0 || !out) return CRM_ERR_ARG;
     *out = nullptr;
+    if (bg->builder) {
+        set_error("gene: the background is still under construction (crm_background_seal not called)");
+        return CRM_ERR_ARG;
+    }
     if (c < 1 || c > CRM_MAX_COV_WIDE) {
         set_error("gene: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV_WIDE);
         return CRM_ERR_UNSUPPORTED;

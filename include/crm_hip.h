@@ -62,6 +62,27 @@ int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const 
 int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k1, const double* U, int k2,
                                    const double* hK, int m, int nrho, const double* rho, double rel_tol,
                                    crm_background** out);
+/* The same constructor split over several processes, one per GPU (the grid points are decomposed
+ * by different ranks, the results exchanged over RCCL; cellregmap_amd/distributed.py drives it):
+ *   begin    -- H = [E1, B] (B explicit, or U / hK as in crm_background_create_hadamard when B == NULL), Gram
+ *               matrix, eigen-decompositions of the grid points with mine[i] != 0 (NULL: all); afterwards
+ *               crm_background_rank(bg, i) is the rank of an owned grid point, -1 otherwise
+ *   complete -- ranks[i] of ALL grid points (they fix the common leading dimension): buffers for every grid
+ *               point, Q0 / S0 / Mix computed for the owned ones
+ *   layout   -- n_pad, ldq, ldh (0 when there are no mixing matrices): slot sizes in doubles are
+ *               Q0 n_pad * ldq, S0 ldq, Mix ldh * ldq
+ *   export / import -- copy slot `what` (0 Q0, 1 S0, 2 Mix) of grid point i to / from DEVICE memory of the
+ *               same GPU (e.g. a torch tensor's data_ptr()) -- the owner exports and broadcasts, the others import
+ *   seal     -- all slots filled: finish (the object is then an ordinary background)
+ * crm_background_create* == begin(all) + complete + seal. */
+int crm_background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb, const double* U,
+                         int k2, const double* hK, int m, int nrho, const double* rho, const int* mine,
+                         double rel_tol, crm_background** out);
+int crm_background_complete(crm_background* bg, const int* ranks);
+int crm_background_layout(const crm_background* bg, long* n_pad, long* ldq, long* ldh, int* has_mix);
+int crm_background_export(const crm_background* bg, int i, int what, void* dst_device);
+int crm_background_import(crm_background* bg, int i, int what, const void* src_device);
+int crm_background_seal(crm_background* bg);
 void crm_background_destroy(crm_background* bg);
 /* Introspection / read-back (tests): rank at grid point i; copy of S0 / Q0 (n x r, ld r). */
 int crm_background_rank(const crm_background* bg, int i);

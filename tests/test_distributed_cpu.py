@@ -121,3 +121,101 @@ def test_two_rank_multi_gene_gather_equals_single_process():
             assert np.array_equal(pv[gi], ref_pv)
             for k in ref_info:
                 assert np.array_equal(info[k][gi], ref_info[k])
+
+
+class _NumpyBuilder:
+    """Stand-in for the HIP library's ``BackgroundBuilder`` in the protocol test: the same three phases
+    (owned grid points decomposed by the oracle's economic_qs_linear, common leading dimension from the ranks
+    of all, slots exported / imported as flat float64 tensors), no GPU."""
+
+    def __init__(self, E1, B, rho, mine):
+        from oracle.sugar import economic_qs_linear
+
+        self.rho, self.mine, self.n = list(rho), list(mine), E1.shape[0]
+        self.qs = {}
+        for i, r in enumerate(self.rho):
+            if self.mine[i]:
+                (Q0,), S0 = economic_qs_linear(np.concatenate([np.sqrt(r) * E1, np.sqrt(1 - r) * B], axis=1), return_q1=False)
+                keep = S0 > 1e-12 * S0.max()
+                self.qs[i] = (Q0[:, keep], S0[keep])
+        self.slots = None
+        self.decomposed = sorted(self.qs)
+
+    def rank(self, i):
+        return self.qs[i][0].shape[1] if i in self.qs else -1
+
+    def complete(self, ranks):
+        self.ranks = [int(r) for r in ranks]
+        assert all(r >= 0 for r in self.ranks)
+        self.ldq = max(self.ranks) + 3      # some padding, like the device's round_up(rmax, 128)
+        self.slots = {}
+        for i in range(len(self.rho)):
+            Q = np.zeros((self.n, self.ldq))
+            S = np.zeros(self.ldq)
+            if i in self.qs:
+                Q[:, : self.ranks[i]], S[: self.ranks[i]] = self.qs[i]
+            self.slots[i] = {"Q0": Q, "S0": S}
+
+    def layout(self):
+        return {"Q0": self.n * self.ldq, "S0": self.ldq}
+
+    def export_slot(self, i, what, tensor):
+        assert self.mine[i]
+        tensor.numpy()[:] = self.slots[i][what].ravel()
+
+    def import_slot(self, i, what, tensor):
+        assert not self.mine[i]
+        self.slots[i][what][...] = tensor.numpy().reshape(self.slots[i][what].shape)
+
+    def seal(self):
+        return self
+
+
+def _ctor_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cellregmap_amd.distributed import sharded_background
+        from cellregmap_amd.synth import make_cohort
+
+        c = make_cohort(6, 10, 3, 4, seed=13)
+        rho = np.linspace(0, 1, 11)
+        b = sharded_background(c.E, c.hK, rho, builder=lambda mine: _NumpyBuilder(c.E, c.hK, rho, mine))
+        q.put((rank, b.decomposed, b.ranks, {i: (s["Q0"].copy(), s["S0"].copy()) for i, s in b.slots.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_constructor_two_ranks():
+    """Rank r decomposes the grid points i % 2 == r; after the exchange both ranks hold all eleven
+    decompositions, identical to a single process's."""
+    import torch.multiprocessing as mp
+
+    from cellregmap_amd.distributed import sharded_background
+    from cellregmap_amd.synth import make_cohort
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ctor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = make_cohort(6, 10, 3, 4, seed=13)
+    rho = np.linspace(0, 1, 11)
+    ref = sharded_background(c.E, c.hK, rho, builder=lambda mine: _NumpyBuilder(c.E, c.hK, rho, mine))  # world of one
+    assert ref.decomposed == list(range(11))
+    assert results[0][1] == [0, 2, 4, 6, 8, 10] and results[1][1] == [1, 3, 5, 7, 9]
+    for rank, _, ranks, slots in results:
+        assert ranks == ref.ranks
+        for i in range(11):
+            assert np.array_equal(slots[i][0], ref.slots[i]["Q0"]) and np.array_equal(slots[i][1], ref.slots[i]["S0"])

@@ -505,3 +505,56 @@ def test_decaying_spectrum_background(mode):
         _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 0))
     ppv, pinfo, pst = OracleCellRegMap(y, E, W=W, polish=True, **okw).scan_interaction(G, return_stats=True)
     _compare(pv, info, st, ppv, pinfo, pst, tight=True)
+
+
+@pytest.mark.parametrize("mode", ["C-thin", "C-eigh", "B"])
+def test_constructor_in_phases_with_exchanged_grid_points(mode):
+    """The multi-GPU constructor on one GPU: two builders own the even / odd grid points, exchange their
+    slots through device tensors (what RCCL broadcasts between ranks) and must both end up with the
+    background a single constructor builds -- bit for bit -- and with the same scan results."""
+    import torch
+
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
+    from cellregmap_amd._engine import _RHO_GRID, BackgroundBuilder
+
+    if mode == "C-eigh":
+        c = _cohort(12, 10, 10, 12, seed=3)
+    elif mode == "C-thin":
+        c = _cohort(6, 40, 4, 12, seed=4)
+    else:
+        c = _cohort(10, 20, 5, 12, seed=5)
+    B = get_L_values(c.hK, c.E) if mode.startswith("C") else c.hK
+    kw = {"Ls": B} if mode.startswith("C") else {"hK": c.hK}
+    even = np.arange(11) % 2 == 0
+    a = BackgroundBuilder(c.E, B, _RHO_GRID, mine=even)
+    b = BackgroundBuilder(c.E, B, _RHO_GRID, mine=~even)
+    assert [a.rank(i) >= 0 for i in range(11)] == list(even)
+    ranks = [a.rank(i) if even[i] else b.rank(i) for i in range(11)]
+    a.complete(ranks)
+    b.complete(ranks)
+    layout = a.layout()
+    assert layout == b.layout() and ("Mix" in layout) == (mode != "C-eigh")
+    for what, size in layout.items():
+        buf = torch.empty(size, dtype=torch.float64, device="cuda:0")
+        for i in range(11):
+            src, dst = (a, b) if even[i] else (b, a)
+            src.export_slot(i, what, buf)
+            torch.cuda.synchronize()
+            dst.import_slot(i, what, buf)
+    bga, bgb = a.seal(), b.seal()
+    ref = CellRegMap(c.y, c.E, W=c.W, **kw)
+    n = c.y.size
+    for i in range(11):
+        Q0, S0 = ref._bg.read(i, n)
+        for bg in (bga, bgb):
+            q, s = bg.read(i, n)
+            assert np.array_equal(s, S0) and np.array_equal(q, Q0)
+    panel = GenotypePanel(c.G, groups=None)
+    pv, info = ref.scan_interaction(panel)
+    for bg in (bga, bgb):
+        pv2, info2 = CellRegMap(c.y, c.E, W=c.W, background=bg, **kw).scan_interaction(panel)
+        assert np.array_equal(pv2, pv) and np.array_equal(info2["rho1"], info["rho1"])
+    # an unsealed background is refused
+    half = BackgroundBuilder(c.E, B, _RHO_GRID, mine=even)
+    with pytest.raises(Exception, match="under construction"):
+        CellRegMap(c.y, c.E, W=c.W, background=half._bg, **kw).scan_interaction(panel)
