@@ -511,7 +511,8 @@ def test_decaying_spectrum_background(mode):
 def test_constructor_in_phases_with_exchanged_grid_points(mode):
     """The multi-GPU constructor on one GPU: two builders own the even / odd grid points, exchange their
     slots through device tensors (what RCCL broadcasts between ranks) and must both end up with the
-    background a single constructor builds -- bit for bit -- and with the same scan results."""
+    background a single constructor builds (to rounding: the batch size picks the contraction kernel's tile
+    width) and with the same scan results."""
     import torch
 
     from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
@@ -544,16 +545,25 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
     bga, bgb = a.seal(), b.seal()
     ref = CellRegMap(c.y, c.E, W=c.W, **kw)
     n = c.y.size
+    probe = np.random.default_rng(0).normal(size=(n, 3))
     for i in range(11):
         Q0, S0 = ref._bg.read(i, n)
+        want = Q0 @ (S0[:, None] * (Q0.T @ probe))
         for bg in (bga, bgb):
             q, s = bg.read(i, n)
-            assert np.array_equal(s, S0) and np.array_equal(q, Q0)
+            assert_allclose(s, S0, rtol=1e-10, atol=1e-12 * S0.max())
+            assert np.abs(q.T @ q - np.eye(q.shape[1])).max() < 1e-12
+            assert np.abs(q @ (s[:, None] * (q.T @ probe)) - want).max() <= 1e-11 * np.abs(want).max()
+            # both builders hold the SAME bytes for every grid point: what one computed, the other imported
+        qa, sa = bga.read(i, n)
+        qb, sb = bgb.read(i, n)
+        assert np.array_equal(qa, qb) and np.array_equal(sa, sb)
     panel = GenotypePanel(c.G, groups=None)
     pv, info = ref.scan_interaction(panel)
     for bg in (bga, bgb):
         pv2, info2 = CellRegMap(c.y, c.E, W=c.W, background=bg, **kw).scan_interaction(panel)
-        assert np.array_equal(pv2, pv) and np.array_equal(info2["rho1"], info["rho1"])
+        assert np.array_equal(info2["rho1"], info["rho1"])
+        assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
     # an unsealed background is refused
     half = BackgroundBuilder(c.E, B, _RHO_GRID, mine=even)
     with pytest.raises(Exception, match="under construction"):
