@@ -258,9 +258,11 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
         CRM_BG_HIP(hipGetLastError());
         CRM_BG_HIP(hipStreamSynchronize(st));
     }
+    trace.lap("  upload of the half factor");
     CRM_BG(dHt.ensure(sizeof(double) * cp * np));
     CRM_BG_HIP(hipMemsetAsync(dHt.ptr, 0, sizeof(double) * cp * np, st));
     CRM_BG(transpose(st, dH.as<double>(), cp, n, cols, dHt.as<double>(), np));
+    trace.lap("  transpose");
 
     const long dim = thin ? cols : n;       // order of the matrices that get diagonalised
     const long dimp = round_up(dim, 128);
@@ -297,6 +299,7 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
         EighWork ew;
         struct EGuard { EighWork& w; ~EGuard() { eigh_free(w); } } eguard{ew};
         CRM_BG(eigh_alloc(ew, nmine, dim));
+        trace.lap("  eigen workspace");
         CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nmine * ew.slab, st));
         for (int q = 0; q < nmine; q++) {
             const int i = bb->mine[q];
@@ -316,6 +319,7 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
         CRM_BG_HIP(hipGetLastError());
         std::vector<double> lam((size_t)nmine * dim);
         double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
+        trace.lap("  scaled Gram matrices");
         CRM_BG(eigh_batched(ctx, ew, lam.data(), &Zt));
         trace.lap("eigen-decompositions");
         ScopedBuf wKeep, wLam;
@@ -361,6 +365,7 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
             CRM_BG_HIP(hipStreamSynchronize(st));   // keep / hW are reused by the next grid point
         }
     }
+    trace.lap("  mixing matrices");
     *out = bg;
     return CRM_OK;
 }
@@ -422,6 +427,7 @@ static int background_complete(crm_background* bg, const int* r_all) {
             CRM_HIP(hipMemsetAsync(bg->Mix[i].ptr, 0, sizeof(double) * cp * ldq, st));
         }
     }
+    trace.lap("  buffers of the grid points");
     double* Gq = dG.as<double>();
     double* N = Gq + ldq * ldq;
     auto defect_and_correction = [&](int r, double* err_out) -> int {

@@ -64,7 +64,11 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
     ``B``: what the constructor concatenates behind sqrt(rho) E1 -- ``None`` (mode A), hK (mode B), the
     ``HadamardHalves`` of ``get_L_values`` or their concatenation (mode C).
     ``builder``: factory ``mine -> object with rank / complete / layout / export_slot / import_slot / seal``
-    (tests inject a numpy one); default: the HIP library's ``BackgroundBuilder``."""
+    (tests inject a numpy one); default: the HIP library's ``BackgroundBuilder``.
+
+    Order of initialisation in a process that uses torch on the GPU and this library: torch first
+    (``torch.cuda.set_device`` / ``init_process_group(..., device_id=...)``), then the first call into the
+    library -- both then share one HIP runtime and device pointers can be handed across."""
     import torch
     import torch.distributed as dist
 

@@ -513,10 +513,26 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
     slots through device tensors (what RCCL broadcasts between ranks) and must both end up with the
     background a single constructor builds (to rounding: the batch size picks the contraction kernel's tile
     width) and with the same scan results."""
-    import torch
+    import ctypes
 
     from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
     from cellregmap_amd._engine import _RHO_GRID, BackgroundBuilder
+
+    # device buffers from the HIP runtime the library itself runs on (a torch tensor's data_ptr() is the same
+    # kind of pointer; torch is kept out of this process because it has to initialise the GPU BEFORE the
+    # library does, and other tests of the session have used the library already)
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    class DeviceBuffer:
+        def __init__(self, doubles):
+            self.ptr = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(8 * doubles)) == 0
+
+        def data_ptr(self):
+            return self.ptr.value
+
+        def free(self):
+            hip.hipFree(self.ptr)
 
     if mode == "C-eigh":
         c = _cohort(12, 10, 10, 12, seed=3)
@@ -536,12 +552,12 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
     layout = a.layout()
     assert layout == b.layout() and ("Mix" in layout) == (mode != "C-eigh")
     for what, size in layout.items():
-        buf = torch.empty(size, dtype=torch.float64, device="cuda:0")
+        buf = DeviceBuffer(size)
         for i in range(11):
             src, dst = (a, b) if even[i] else (b, a)
             src.export_slot(i, what, buf)
-            torch.cuda.synchronize()
             dst.import_slot(i, what, buf)
+        buf.free()
     bga, bgb = a.seal(), b.seal()
     ref = CellRegMap(c.y, c.E, W=c.W, **kw)
     n = c.y.size
