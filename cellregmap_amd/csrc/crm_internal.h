@@ -44,6 +44,8 @@ struct crm_ctx {
     int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
     bool collapse = true;  // use the donor-collapsed path for grouped panels
+    void (*progress)(long done, long total, void* user) = nullptr;  // called after every block of a scan
+    void* progress_user = nullptr;
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     crm::GemmTune tune;   // contraction kernel variant (test hooks only change it)
     crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form

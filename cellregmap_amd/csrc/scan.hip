@@ -310,6 +310,111 @@ int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, con
     return CRM_OK;
 }
 
+}  // extern "C"
+
+namespace crm {
+// One workgroup per variant: mean and standard deviation of the EXPANDED column (every donor's dosage weighted by
+// its number of cells; population variance, as numpy's std / the reference simulator's column_normalize,
+// cellregmap/_simulate.py:50-54), then the standardised donor-level column in float64.
+__global__ __launch_bounds__(256) void standardise_dosages_kernel(const signed char* __restrict__ D, long ldd, long m, long p,
+                                                                  const double* __restrict__ cells_of, double n, int standardise,
+                                                                  double* __restrict__ Gd, long ldg, int* __restrict__ flags) {
+    __shared__ double red[2][4];
+    const long j = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    for (long d = tid; d < m; d += blockDim.x) {
+        const double g = (double)D[d * ldd + j], w = cells_of[d];
+        s1 += w * g;
+        s2 += w * g * g;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double mean = s1 / n;
+    double var = 0.0;   // second pass in the centred form (the raw-moment difference cancels for rare alleles)
+    for (long d = tid; d < m; d += blockDim.x) {
+        const double c = (double)D[d * ldd + j] - mean;
+        var += cells_of[d] * c * c;
+    }
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = var;
+    __syncthreads();
+    var = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+    const double sd = sqrt(var);
+    if (standardise && !(sd > 0.0)) {
+        if (tid == 0) atomicOr(&flags[0], 1);   // monomorphic column: the reference's normalisation divides by zero
+        return;
+    }
+    for (long d = tid; d < m; d += blockDim.x) {
+        const double g = (double)D[d * ldd + j];
+        Gd[d * ldg + j] = standardise ? (g - mean) / sd : g;
+    }
+}
+}  // namespace crm
+
+extern "C" int crm_panel_create_grouped_i8(crm_ctx* ctx, long n, const int* group, long m, const signed char* dosage,
+                                           long ldd, long p, int standardise, crm_panel** out) {
+    if (!ctx || !group || !dosage || !out || n <= 0 || m <= 0 || p <= 0 || ldd < p) return CRM_ERR_ARG;
+    *out = nullptr;
+    std::vector<double> cells_of(m, 0.0);
+    for (long i = 0; i < n; i++) {
+        if (group[i] < 0 || group[i] >= m) {
+            set_error("grouped panel: group index %d at cell %ld outside [0, %ld)", group[i], i, m);
+            return CRM_ERR_ARG;
+        }
+        cells_of[group[i]] += 1.0;
+    }
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    crm_panel* P = new crm_panel();
+    auto fail = [&](int code) { crm_panel_destroy(P); return code; };
+    P->ctx = ctx;
+    P->uid = next_panel_uid();
+    P->n = n;
+    P->n_pad = round_up(n, CELL_PAD);
+    P->p = p;
+    P->ld = round_up(p, 128);
+    P->grouped = true;
+    P->m = m;
+    P->m_pad = round_up(m, GEMM_BK);
+    P->ldz = round_up(m, 128) + 128;
+    ScopedBuf dD, dCells, dFlags;
+    int rc = P->Gd.ensure(sizeof(double) * P->m_pad * P->ld);
+    if (rc == CRM_OK) rc = P->group.ensure(sizeof(int) * n);
+    if (rc == CRM_OK) rc = P->Z.ensure(sizeof(double) * P->n_pad * P->ldz);
+    if (rc == CRM_OK) rc = dD.ensure((size_t)m * p);
+    if (rc == CRM_OK) rc = dCells.ensure(sizeof(double) * m);
+    if (rc == CRM_OK) rc = dFlags.ensure(sizeof(int));
+    if (rc != CRM_OK) return fail(rc);
+    int h_flag = 0;
+    if (hipMemsetAsync(P->Gd.ptr, 0, sizeof(double) * P->m_pad * P->ld, st) != hipSuccess ||
+        hipMemsetAsync(dFlags.ptr, 0, sizeof(int), st) != hipSuccess ||
+        hipMemcpy2DAsync(dD.ptr, p, dosage, ldd, p, m, hipMemcpyHostToDevice, st) != hipSuccess ||   // 1 byte per dosage over PCIe
+        hipMemcpyAsync(dCells.ptr, cells_of.data(), sizeof(double) * m, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(P->group.ptr, group, sizeof(int) * n, hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(CRM_ERR_HIP);
+    hipLaunchKernelGGL(standardise_dosages_kernel, dim3((unsigned)p), dim3(256), 0, st, dD.as<signed char>(), p, m, p,
+                       dCells.as<double>(), (double)n, standardise ? 1 : 0, P->Gd.as<double>(), P->ld, dFlags.as<int>());
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(&h_flag, dFlags.ptr, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return fail(CRM_ERR_HIP);
+    P->group_key = content_key(group, sizeof(int) * n, (unsigned long)m);
+    rc = launch_indicator(st, P->group.as<int>(), n, P->n_pad, (int)m, P->Z.as<double>(), P->ldz);
+    if (rc != CRM_OK) return fail(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(CRM_ERR_HIP);
+    if (h_flag) {
+        set_error("panel: a monomorphic variant cannot be standardised (zero variance)");
+        return fail(CRM_ERR_NUMERIC);
+    }
+    *out = P;
+    return CRM_OK;
+}
+
+extern "C" {
 // Upload an expanded genotype matrix, check it for non-finite entries and -- when a candidate
 // grouping is given (group_hint[i] in [0, m_hint), rep_rows[d] = a row carrying group d) -- verify ON THE
 // DEVICE that every cell equals its group's representative in every variant; if so the panel is stored
@@ -1024,6 +1129,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // the per-gene device buffers (Z1, Q, F, pv) are reused by the next gene
             CRM_HIP(hipStreamSynchronize(st));
         }
+        if (ctx->progress) ctx->progress(done + nb, count, ctx->progress_user);   // (the reference's tqdm, :340)
     }
     return CRM_OK;
 }

@@ -107,52 +107,68 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
     return b.seal()
 
 
-def scan_interaction_distributed(crm, G, idx_E=None, idx_G=None, group=None, scan=None):
+def _my_columns(G, p_total, rank, world):
+    """This rank's shard of the panel: either cut from the full matrix (``p_total is None``), or ``G`` IS the
+    shard already -- ``variant_shard(p_total, rank, world)`` columns, loaded by the rank itself so that no
+    rank ever holds the whole n x p matrix in host memory (8 GB at BASELINE config 3)."""
+    if p_total is None:
+        G = np.asarray(G)
+        p = G.shape[1]
+        first, count = variant_shard(p, rank, world)
+        return p, np.ascontiguousarray(G[:, first:first + count], dtype=float)
+    first, count = variant_shard(p_total, rank, world)
+    if hasattr(G, "shape") and G.shape[1] != count:
+        raise ValueError(f"rank {rank} holds {G.shape[1]} columns, its shard of {p_total} variants has {count}")
+    return int(p_total), G
+
+
+def scan_interaction_distributed(crm, G, idx_E=None, idx_G=None, group=None, scan=None, p_total=None):
     """``crm.scan_interaction`` over this rank's shard of the columns of ``G`` followed by the
     gather; returns the reference's ``(pvalues, info)`` for all variants on every rank.
 
+    ``G``: the full n x p matrix on every rank, or -- with ``p_total`` -- only this rank's shard
+    (``variant_shard(p_total, rank, world)``; array or ``GenotypePanel``).
     ``scan`` overrides the per-shard call (tests inject the CPU oracle)."""
     import torch.distributed as dist
 
-    G = np.asarray(G, float)
-    p = G.shape[1]
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
+    p, mine = _my_columns(G, p_total, rank, world)
     first, count = variant_shard(p, rank, world)
     fn = scan if scan is not None else crm.scan_interaction
     if count > 0:
-        pv, info = fn(np.ascontiguousarray(G[:, first:first + count]), idx_E, idx_G)
+        pv, info = fn(mine, idx_E, idx_G)
     else:
         pv, info = np.empty(0), {k: np.empty(0) for k in ("rho1", "e2", "g2", "eps2")}
     full = gather_variant_results({"pv": pv, **info}, p, group)
     return full.pop("pv"), full
 
 
-def scan_interaction_many_distributed(crms, G, idx_E=None, idx_G=None, group=None, scan_many=None):
+def scan_interaction_many_distributed(crms, G, idx_E=None, idx_G=None, group=None, scan_many=None, p_total=None):
     """BASELINE config 4's shape: several genes (``CellRegMap`` objects sharing one background) against
     one panel, the variants sharded over the ranks.  Every rank runs ``scan_interaction_many`` -- all
     genes, its shard of the columns of ``G`` -- so the phenotype-free work of a variant is done once,
     on one GPU; the gather returns ``(pvalues (genes x p), info of (genes x p) arrays)`` on every rank.
 
+    ``G`` / ``p_total``: as in ``scan_interaction_distributed``.
     ``scan_many`` overrides the per-shard call (tests inject the CPU oracle)."""
     import torch.distributed as dist
 
     from ._engine import scan_interaction_many
 
-    G = np.asarray(G, float)
-    p = G.shape[1]
     ng = len(crms)
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
+    p, mine = _my_columns(G, p_total, rank, world)
     first, count = variant_shard(p, rank, world)
     keys = ("rho1", "e2", "g2", "eps2")
     fn = scan_many if scan_many is not None else scan_interaction_many
     if count > 0:
-        pv, info = fn(crms, np.ascontiguousarray(G[:, first:first + count]), idx_E, idx_G)
+        pv, info = fn(crms, mine, idx_E, idx_G)
     else:
         pv, info = np.empty((ng, 0)), {k: np.empty((ng, 0)) for k in keys}
     local = {}

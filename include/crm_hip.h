@@ -103,6 +103,14 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
  * genotype permutation hook (idx_G) falls back to the dense path by expanding blocks on the fly. */
 int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
                              long p, crm_panel** out);
+/* Compact ingest of a donor-constant panel: `dosage` holds one signed byte per (donor, variant) -- allele counts
+ * 0 / 1 / 2, m x p row-major with leading dimension ldd -- i.e. n / m x 8 times less data over PCIe than the
+ * expanded float64 matrix "Genotypes (expanded)" of _cellregmap.py:488,561.  standardise != 0: every variant is
+ * centred and scaled on the device by the mean and (population) standard deviation of its EXPANDED column, donors
+ * weighted by their cell counts (what the reference's callers do on the host before expanding); a monomorphic
+ * variant is then an error (CRM_ERR_NUMERIC).  The panel behaves like one from crm_panel_create_grouped. */
+int crm_panel_create_grouped_i8(crm_ctx* ctx, long n, const int* group, long m, const signed char* dosage, long ldd,
+                                long p, int standardise, crm_panel** out);
 /* Upload an expanded n x p matrix; reject non-finite entries (CRM_ERR_NUMERIC: the reference's LMM
  * raises ValueError on them) and, given a candidate grouping (group_hint[i] in [0, m_hint),
  * rep_rows[d] = index of a cell of group d), verify on the device that every cell equals its group's
@@ -156,6 +164,10 @@ int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const
 /* Block size (variants per internal batch); 0 restores the default (automatic: up to 4096 variants of
  * the interaction scan while its largest work buffer stays within 16 GB; 1024 for the association scans). */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
+/* Progress of the scans on this context: `callback(done, total, user)` is called on the calling thread after
+ * every internal block of variants (the reference shows a tqdm bar over variants, _cellregmap.py:270,340);
+ * NULL switches it off. */
+int crm_set_progress_callback(crm_ctx* ctx, void (*callback)(long done, long total, void* user), void* user);
 /* on = 1 (default): for backgrounds built on the device with a well-conditioned kept spectrum
  * (S_max <= 1e6 S_min), the rotations G'Q0(rho) of the dense scan are taken as Mix(rho)'(H'G) with
  * Q0(rho) = H Mix(rho) -- one n-length product instead of one per grid point.  on = 0: always the

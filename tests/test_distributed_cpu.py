@@ -37,6 +37,13 @@ def _worker(rank, world, port, q):
         c = make_cohort(6, 10, 3, 7, seed=13)  # 7 variants over 2 ranks: ragged shards (4 + 3)
         ocrm = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK)
         pv, info = scan_interaction_distributed(None, c.G, scan=ocrm.scan_interaction)
+        # the same with every rank holding only its own columns
+        from cellregmap_amd.distributed import variant_shard
+
+        f, cnt = variant_shard(7, rank, world)
+        pv2, info2 = scan_interaction_distributed(None, np.ascontiguousarray(c.G[:, f:f + cnt]), scan=ocrm.scan_interaction,
+                                                  p_total=7)
+        assert np.array_equal(pv, pv2) and all(np.array_equal(info[k], info2[k]) for k in info)
         q.put((rank, pv, info))
     finally:
         dist.destroy_process_group()

@@ -127,3 +127,56 @@ def test_device_side_group_verification():
     pv_auto, _ = crm.scan_interaction(panel)
     pv_dense, _ = crm.scan_interaction(GenotypePanel(G2, groups=None))
     assert np.array_equal(pv_auto, pv_dense)
+
+
+def test_int8_dosage_ingest_standardised_on_the_device():
+    """Donor-level allele counts as int8 + donor index (compact ingest): the device standardises
+    every variant by the moments of its expanded column; results equal the float64 route where the host does that."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from cellregmap_amd.synth import donor_genotypes
+
+    rng = np.random.default_rng(12)
+    donors = 9
+    cells_of = rng.integers(5, 30, size=donors)                # ragged donors
+    donor_of_cell = np.repeat(np.arange(donors), cells_of)
+    n = donor_of_cell.size
+    D, _ = donor_genotypes(donors, 40, rng)                    # int8 allele counts, no monomorphic column
+    E = rng.normal(size=(n, 4))
+    hK = np.zeros((n, donors)); hK[np.arange(n), donor_of_cell] = 1.0
+    Gx = D[donor_of_cell].astype(float)
+    y = 0.5 * Gx[:, 3] * E[:, 0] + E @ rng.normal(size=4) * 0.3 + rng.normal(size=n)
+    Gs = (Gx - Gx.mean(0)) / Gx.std(0)                         # the host route: standardise the expanded matrix
+    crm = CellRegMap(y, E, hK=hK)
+    ref_pv, ref_info = crm.scan_interaction(GenotypePanel(Gs, groups=None))
+    panel = GenotypePanel.from_dosages(D, donor_of_cell)
+    assert panel.n_groups == donors and panel.shape == (n, 40)
+    pv, info = crm.scan_interaction(panel)
+    assert np.array_equal(info["rho1"], ref_info["rho1"])
+    assert np.all(np.abs(pv - ref_pv) <= 1e-5 * ref_pv + 1e-13)
+    # against the float64 donor-level route the difference is rounding only
+    pv2, _ = crm.scan_interaction(GenotypePanel.from_donors(Gs[np.r_[0, np.cumsum(cells_of)[:-1]]], donor_of_cell))
+    assert np.all(np.abs(pv - pv2) <= 1e-7 * pv2 + 1e-13)
+    # raw counts on request; a monomorphic variant cannot be standardised
+    raw, _ = crm.scan_interaction(GenotypePanel.from_dosages(D, donor_of_cell, standardize=False))
+    assert np.all(np.isfinite(raw))
+    D2 = D.copy(); D2[:, 5] = 1
+    with pytest.raises(ValueError, match="monomorphic"):
+        GenotypePanel.from_dosages(D2, donor_of_cell)
+
+
+def test_progress_callback_reports_every_block():
+    from cellregmap_amd import CellRegMap, _engine, _lib
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 20, 3, 300, seed=8)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib = _lib.load()
+    _lib.check(lib.crm_set_block_variants(_engine._context(0), 128))
+    seen = []
+    try:
+        pv, _ = crm.scan_interaction(c.G, progress=lambda done, total: seen.append((done, total)))
+    finally:
+        _lib.check(lib.crm_set_block_variants(_engine._context(0), 0))
+    assert seen == [(128, 300), (256, 300), (300, 300)]
+    pv2, _ = crm.scan_interaction(c.G, progress=True)          # tqdm bar on stderr
+    assert np.array_equal(pv, pv2)
