@@ -13,9 +13,9 @@ extern "C" {
 /* Contraction kernel variant for subsequent launches on this context: tile_width 0 = chosen per
  * launch, 64 or 128 forced; lds_dma = 1 lets 128-wide launches use the direct-to-LDS kernel. */
 int crm_test_set_contraction(crm_ctx* ctx, int tile_width, int lds_dma);
-/* every > 0: Khatri-Rao launches of more than 1024 tiles run as 8 x 64 persistent workgroups that walk
- * contiguous tile runs per XCD and re-align (bounded wait) every `every` generations -- 5x less L2-fabric
- * traffic, 0.7 % slower; 0 (default): one workgroup per tile. */
+/* every > 0 (default 1): Khatri-Rao launches of more than 1024 tiles run as 8 x 64 persistent workgroups that walk
+ * contiguous tile runs per XCD and re-align (bounded wait) every `every` generations -- 7.5x less L2-fabric
+ * traffic, 0.65 % slower; 0: one workgroup per tile. */
 int crm_test_set_contraction_sync(crm_ctx* ctx, int every);
 /* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
 int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,

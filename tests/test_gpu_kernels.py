@@ -103,7 +103,7 @@ def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
     try:
         _lib.check(lib.crm_test_contract_kr(h, cells, B, k0, N, _lib.ptr(G), _lib.ptr(E), _lib.ptr(Y), _lib.ptr(C)))
     finally:
-        _lib.check(lib.crm_test_set_contraction_sync(h, 0))
+        _lib.check(lib.crm_test_set_contraction_sync(h, 1))   # the default
     KR = (G[:, :, None] * E[:, None, :]).reshape(cells, B * k0)
     assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
 
