@@ -1,4 +1,6 @@
 // Context, error text, device-buffer helpers and the contraction test hooks of the C-ABI.
+#include <dlfcn.h>
+
 #include <cstdarg>
 
 #include "crm_internal.h"
@@ -17,6 +19,36 @@ void set_error(const char* fmt, ...) {
 }
 
 const char* last_error_text() { return g_error.c_str(); }
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() {
+    static Roctx r;   // (only looked up when ranges are asked for: CRM_ROCTX=1 or a rocprofiler tool in the process)
+    return r;
+}
+bool ranges_on() {
+    static const bool on = getenv("CRM_ROCTX") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_LIBRARY_CTOR");
+    return on;
+}
+}  // namespace
+
+void trace_push(const char* name) {
+    if (ranges_on() && roctx().push) roctx().push(name);
+}
+void trace_pop() {
+    if (ranges_on() && roctx().pop) roctx().pop();
+}
 
 int DevBuf::ensure(size_t need) {
     if (need <= bytes) return CRM_OK;

@@ -201,6 +201,7 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     SetupTrace trace(st);
+    TraceRange range("crm background begin");
     const long cols = k1 + kb;
     const long np = round_up(n, CELL_PAD);
     const long cp = round_up(cols, 128);
@@ -381,6 +382,7 @@ static int background_complete(crm_background* bg, const int* r_all) {
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     SetupTrace trace(st);
+    TraceRange range("crm background complete");
     const long n = bb->n, np = bb->np, cols = bb->cols, cp = bb->cp;
     const bool thin = bb->thin;
     const int nrho = bg->nrho;

@@ -36,6 +36,15 @@ const char* last_error_text();
 
 inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 
+// Named ranges for rocprofv3 --marker-trace (rocprofiler-sdk roctx), resolved at run time: without the library
+// in the process they are no-ops.  Around the phases of the constructor and of every block of a scan.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+    explicit TraceRange(const char* name) { trace_push(name); }
+    ~TraceRange() { trace_pop(); }
+};
+
 // ---- contraction kernel (gemm_tn.hip) ------------------------------------------
 // C[z][M x N] = X[z]' * Y[z]  with the contraction over the cell axis (rows of X, Y).
 // Khatri-Rao form: X[i, b*k0 + j] = Gs[i, b] * E[i, j] is formed on the fly.

@@ -199,12 +199,21 @@ int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt) {
         fprintf(stderr, "[crm eigh %d x %ld] %-24s %.3f s\n", w.batch, w.dim, what, std::chrono::duration<double>(now - t0).count());
         t0 = now;
     };
-    CRM_TRY(eigh_tridiagonalise(ctx, w));
+    {
+        TraceRange r("crm eigh tridiagonalisation");
+        CRM_TRY(eigh_tridiagonalise(ctx, w));
+    }
     lap("tridiagonalisation");
     double* Qt = nullptr;
-    CRM_TRY(eigh_dc(ctx, w, lam_host, &Qt));
+    {
+        TraceRange r("crm eigh divide & conquer");
+        CRM_TRY(eigh_dc(ctx, w, lam_host, &Qt));
+    }
     lap("divide & conquer");
-    CRM_TRY(eigh_back_transform(ctx, w, Qt, Zt));
+    {
+        TraceRange r("crm eigh back-transformation");
+        CRM_TRY(eigh_back_transform(ctx, w, Qt, Zt));
+    }
     lap("back-transformation");
     return CRM_OK;
 }

@@ -588,3 +588,20 @@ int eigh_dc(crm_ctx* ctx, EighWork& w, double* lam_host, double** Qt_out) {
 }
 
 }  // namespace crm
+
+// ---- test hook (host only: no GPU touched): the deflation plan of one merge ------------------------------------------
+extern "C" int crm_test_dc_plan(const double* lam, const double* z, int n1, int n, double beta, int* k, double* rho,
+                                int* rows, double* dl, double* w, int* nrot, double* rots) {
+    if (!lam || !z || n1 < 1 || n <= n1 || !k || !rho || !rows || !dl || !w || !nrot || !rots) return CRM_ERR_ARG;
+    crm::MergePlan P;
+    crm::plan_merge(lam, z, n1, n, beta, P);
+    *k = P.k;
+    *rho = P.rho;
+    for (int i = 0; i < P.k; i++) { rows[i] = P.nondefl[i]; dl[i] = P.dl[i]; w[i] = P.w[i]; }
+    for (size_t i = 0; i < P.defl.size(); i++) { rows[P.k + i] = P.defl[i]; dl[P.k + i] = P.lam_defl[i]; w[P.k + i] = 0.0; }
+    *nrot = (int)P.rots.size();
+    for (size_t i = 0; i < P.rots.size(); i++) {
+        rots[4 * i] = P.rots[i].a; rots[4 * i + 1] = P.rots[i].b; rots[4 * i + 2] = P.rots[i].c; rots[4 * i + 3] = P.rots[i].s;
+    }
+    return CRM_OK;
+}

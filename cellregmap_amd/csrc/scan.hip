@@ -883,6 +883,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         const int nb = (int)std::min<long>(BLK, count - done);
         const long col0 = first + done;
         double* Gb = ctx->ws_Gb.as<double>();
+        TraceRange range_block("crm scan block");
         // 1. aligned copy of the block (and its row-permuted twin for the test direction); in
         //    collapsed mode the "block" is the donor dosage slab (m_pad rows)
         double* Gt = Gb;
@@ -936,6 +937,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, nrho, nb, (int)ldq, fastT ? bg->ldh : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
+        trace_push("crm null fits");
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             NullFitArgs fa{};
@@ -953,6 +955,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             CRM_TRY(launch_nullfit(st, fa, nb));
         }
+        trace_pop();
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
         CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));

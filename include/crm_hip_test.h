@@ -44,6 +44,14 @@ int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const doubl
 int crm_test_eigh(crm_ctx* ctx, int batch, int dim, const double* A, double* lam, double* Z, int stage,
                   double* d_out, double* e_out);
 
+/* Host-only (no GPU needed): the deflation plan of one divide-and-conquer merge of the eigen-solver -- eigenvalues
+ * lam[n] of the two halves (n1 + n2), z[n] = last / first components of their eigenvectors, coupling beta.  Returns
+ * k surviving poles, the rho of the normalised secular problem, rows[n] (local source rows: k survivors in pole order,
+ * then the deflated ones), dl / w (poles and normalised update vector for the first k; deflated eigenvalues behind),
+ * and the Givens rotations (a, b, c, s) x nrot that were applied. */
+int crm_test_dc_plan(const double* lam, const double* z, int n1, int n, double beta, int* k, double* rho, int* rows,
+                     double* dl, double* w, int* nrot, double* rots);
+
 #ifdef __cplusplus
 }
 #endif
