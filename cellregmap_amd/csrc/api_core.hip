@@ -193,7 +193,7 @@ int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* 
 
 // ---- single-kernel hooks -------------------------------------------------------------
 int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
-    if (!c || (tile_width != 0 && tile_width != 64 && tile_width != 128)) return CRM_ERR_ARG;
+    if (!c || (tile_width != 0 && tile_width != 64 && tile_width != 128 && tile_width != 160)) return CRM_ERR_ARG;
     c->tune.bn = tile_width;
     c->tune.glds = lds_dma ? 1 : 0;
     return CRM_OK;

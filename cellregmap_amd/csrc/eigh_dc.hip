@@ -168,16 +168,25 @@ __global__ __launch_bounds__(256) void dc_gather_rows_kernel(const double* __res
     for (int c = D.s + threadIdx.x; c < D.t; c += blockDim.x) out[c] = in[c];
 }
 
-// One root per thread.  dl: poles of the node in ascending order at [s, s + k); w: normalised update vector.
+// One root per WAVEFRONT: the 64 lanes share the sums over the poles (terms i = lane, lane + 64, ...; butterfly
+// totals, identical on all lanes, so the iteration is wave-uniform) -- a root of the top-level merge sums over
+// ~5 000 poles per evaluation, and one thread per root left most of the chip idle behind chains of divisions.
+// dl: poles of the node in ascending order at [s, s + k); w: normalised update vector.
 // Root j lies in (dl_j, dl_j+1) (the last one in (dl_k-1, dl_k-1 + rho)); it is represented as
 // dl[origin] + tau with the origin at the nearer pole.
+__device__ inline double wave_total(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void dc_secular_kernel(const DcDesc* __restrict__ desc, int nnodes, long ld,
                                                          const double* __restrict__ dl_all,
                                                          const double* __restrict__ w_all, int* __restrict__ org_all,
                                                          double* __restrict__ tau_all, double* __restrict__ lam_next) {
     const int b = blockIdx.z;
     const DcDesc D = desc[(long)b * nnodes + blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int k = D.k;
     if (j >= k) return;
     const double* __restrict__ dl = dl_all + (long)b * ld + D.s;
@@ -193,8 +202,9 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const DcDesc* __restric
     } else {
         const double gap = dl[j + 1] - dl[j];
         const double mid = 0.5 * gap, dj = dl[j];
-        double g = 1.0;
-        for (int i = 0; i < k; i++) g += rho * w[i] * w[i] / ((dl[i] - dj) - mid);
+        double g = 0.0;
+        for (int i = lane; i < k; i += 64) g += rho * w[i] * w[i] / ((dl[i] - dj) - mid);
+        g = 1.0 + wave_total(g);
         if (g > 0.0) { o = j; lo = 0.0; hi = mid; }
         else { o = j + 1; lo = -mid; hi = 0.0; }
     }
@@ -202,18 +212,13 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const DcDesc* __restric
     double tau = 0.5 * (lo + hi);
     for (int it = 0; it < 400; it++) {
         double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
-        for (int i = 0; i <= j; i++) {
+        for (int i = lane; i < k; i += 64) {
             const double rd = 1.0 / ((dl[i] - dorg) - tau);
             const double t = rho * w[i] * w[i] * rd;
-            psi += t;
-            dpsi += t * rd;
+            if (i <= j) { psi += t; dpsi += t * rd; }
+            else { phi += t; dphi += t * rd; }
         }
-        for (int i = j + 1; i < k; i++) {
-            const double rd = 1.0 / ((dl[i] - dorg) - tau);
-            const double t = rho * w[i] * w[i] * rd;
-            phi += t;
-            dphi += t * rd;
-        }
+        psi = wave_total(psi); dpsi = wave_total(dpsi); phi = wave_total(phi); dphi = wave_total(dphi);
         const double g = 1.0 + psi + phi;
         const double err = 8.0 * DC_EPS * (1.0 + fabs(psi) + fabs(phi)) + DC_EPS * fabs(tau) * (dpsi + dphi);
         if (fabs(g) <= err) break;
@@ -252,9 +257,11 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const DcDesc* __restric
         if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);   // (also catches NaN / infinity)
         tau = nw;
     }
-    org_all[(long)b * ld + D.s + j] = o;
-    tau_all[(long)b * ld + D.s + j] = tau;
-    lam_next[(long)b * ld + D.s + j] = dorg + tau;
+    if (lane == 0) {
+        org_all[(long)b * ld + D.s + j] = o;
+        tau_all[(long)b * ld + D.s + j] = tau;
+        lam_next[(long)b * ld + D.s + j] = dorg + tau;
+    }
 }
 
 // zhat_i^2 = prod_j (lam_j - dl_i) / (rho prod_{j != i} (dl_j - dl_i)), sign of w_i
@@ -552,7 +559,7 @@ int eigh_dc(crm_ctx* ctx, EighWork& w, double* lam_host, double** Qt_out) {
                            dRowNode.as<int>(), dDesc.as<DcDesc>(), nn, dSrc.as<int>(), dim);
         if (kmax > 0) {
             const dim3 grid((unsigned)((kmax + 255) / 256), nn, B);
-            hipLaunchKernelGGL(dc_secular_kernel, grid, dim3(256), 0, st, dDesc.as<DcDesc>(), nn, ld, dDl.as<double>(),
+            hipLaunchKernelGGL(dc_secular_kernel, dim3((unsigned)((kmax + 3) / 4), nn, B), dim3(256), 0, st, dDesc.as<DcDesc>(), nn, ld, dDl.as<double>(),
                                dW.as<double>(), dOrg.as<int>(), dTau.as<double>(), lamn);
             hipLaunchKernelGGL(dc_zhat_kernel, grid, dim3(256), 0, st, dDesc.as<DcDesc>(), nn, ld, dDl.as<double>(),
                                dW.as<double>(), dOrg.as<int>(), dTau.as<double>(), dZhat.as<double>());

@@ -299,12 +299,15 @@ int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m
     // (62.2 vs 60.1 TFLOP/s at config 3); 64-wide tiles (three per CU) fill the chip better when a
     // launch has few tiles (skinny side contractions: 50.5 vs 42.1 TFLOP/s at M = 1024, N = 5120)
     int bn = ctx->tune.bn;
-    if (bn != 64 && bn != 128) {
+    if (bn != 64 && bn != 128 && bn != 160) {
         const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
         bn = tiles128 < 1024 ? 64 : 128;
-        // narrow outputs (modes A / B: N = k1 + m columns): 64-wide tiles when they waste less padding
+        // narrow outputs (modes A / B: N = k1 + m columns): 64-wide tiles when they waste less padding, one 160-wide
+        // tile for 129 .. 160 columns (mode B at config 3: 150 columns fill it to 94 %, three 64-wide tiles to 78 %)
         if (khatri_rao && ((max_n + 63) / 64) * 64 * 100 <= ((max_n + 127) / 128) * 128 * 85) bn = 64;
+        if (khatri_rao && ctx->tune.glds && max_n > 128 && max_n <= 160 && (long)mt * nz * ksplit >= 256) bn = 160;
     }
+    if (bn == 160 && !(khatri_rao && ctx->tune.glds)) bn = 128;
     const int nt = (max_n + bn - 1) / bn;
     if (ctx->tune.glds && (bn == 128 || khatri_rao)) {
         if (khatri_rao && (k0 < 1 || k0 > 128)) {

@@ -59,7 +59,7 @@ struct GldsGeno {
 template <bool KR, int KRQ, int ECQ, bool TR, int BN>
 __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, int mtile, int ntile, int slice,
                                           long cells_per_split, long cells_total, long split_stride, int k0) {
-    static_assert(BN == 128 || (BN == 64 && KR), "64-wide tiles are built for the Khatri-Rao form");
+    static_assert(BN == 128 || ((BN == 64 || BN == 160) && KR), "64- and 160-wide tiles are built for the Khatri-Rao form");
     constexpr int LD = BN;
     // Wave tile: 64 x 64 (wavefronts 2 x 2) for the plain product -- fewest fragment reads per MFMA; 32 x
     // 128 (wavefronts 4 x 1) for the Khatri-Rao form -- per k-step two operand products instead of four
@@ -104,6 +104,19 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
     const unsigned y_lane = BN == 128 ? 8u * (unsigned)((lane ^ ((wave & 1) << 3)) * 2)
                                       : (unsigned)(lane >> 5) * (unsigned)(P.ldy * 8) +
                                             16u * (unsigned)((lane & 31) ^ ((lane >> 5) << 3));
+    // 160-wide tiles (outputs of 129 .. 160 columns, e.g. mode B's k1 + m = 150): a stage of the Y tile is 16 rows x
+    // 1280 bytes = 20 wave-instructions of 64 consecutive 16-byte pieces of the dense LDS image, 5 per wavefront;
+    // piece p sits in row p / 80 (1280 bytes = 5 bank windows, so the odd-row granule swap works as for 128)
+    constexpr int YQ = BN == 160 ? 5 : 1;
+    unsigned y_piece[YQ];
+    if (BN == 160) {
+#pragma unroll
+        for (int q = 0; q < YQ; q++) {
+            const int p = (wave + 4 * q) * 64 + lane;
+            const int r = p / 80, g = p - r * 80;
+            y_piece[q] = 8u * (unsigned)(r * (int)P.ldy + ((g ^ ((r & 1) << 3)) << 1));
+        }
+    }
     constexpr int ECN = ECQ > 0 ? ECQ : 1;
     unsigned e_lane[ECN];
     unsigned g_lane[KRQ];
@@ -129,8 +142,18 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         unsigned yl = y_lane;
         asm volatile("" : "+v"(yl));
         constexpr int YROWS = BN == 128 ? 1 : 2;  // rows per wave-instruction
+        if (BN == 160) {
+            gptr_t ybase = scalar_ptr(Yg + roff * P.ldy);
 #pragma unroll
-        for (int q = 0; q < GEMM_BK / (4 * YROWS); q++) {
+            for (int q = 0; q < YQ; q++) {
+                unsigned yo_q = y_piece[q];
+                asm volatile("" : "+v"(yo_q));
+                __builtin_amdgcn_global_load_lds(at_bytes(ybase, yo_q), (lptr_t)(Ys + BUF * GEMM_BK * LD + (wave + 4 * q) * 128), 16,
+                                                 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (BN == 160 ? 0 : GEMM_BK / (4 * YROWS)); q++) {
             const int r = (wave + 4 * q) * YROWS;
             gptr_t yrow = scalar_ptr(Yg + (roff + r) * P.ldy);
             __builtin_amdgcn_global_load_lds(at_bytes(yrow, yl), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
@@ -382,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmPro
 
 int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out, int bn) {
-    if (bn != 128 && !(bn == 64 && khatri_rao && !transposed_out)) {
+    if (bn != 128 && !((bn == 64 || bn == 160) && khatri_rao && !transposed_out)) {
         set_error("contraction: %d-wide LDS-DMA tiles are not built for this form", bn);
         return CRM_ERR_UNSUPPORTED;
     }
@@ -430,9 +453,19 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, false, 64>), grid, dim3(256), lds, st,  \
                                probs_dev, mt, cps, cells, split_stride, k0);                              \
     } while (0)
+#define CRM_GLDS_160(Q)                                                                                       \
+    do {                                                                                                      \
+        if (small)                                                                                            \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, false, 160>), grid, dim3(256), lds, st,       \
+                               probs_dev, mt, cps, cells, split_stride, k0);                                  \
+        else                                                                                                  \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, false, 160>), grid, dim3(256), lds, st, \
+                               probs_dev, mt, cps, cells, split_stride, k0);                                  \
+    } while (0)
 #define CRM_GLDS(Q)                              \
     do {                                         \
         if (bn == 64) CRM_GLDS_64(Q);            \
+        else if (bn == 160) CRM_GLDS_160(Q);     \
         else if (transposed_out) CRM_GLDS_T(Q, true); \
         else CRM_GLDS_T(Q, false);               \
     } while (0)
@@ -443,6 +476,7 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
             default: CRM_GLDS(4); break;
         }
 #undef CRM_GLDS
+#undef CRM_GLDS_160
 #undef CRM_GLDS_64
 #undef CRM_GLDS_T
     } else {

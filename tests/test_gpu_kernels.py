@@ -21,7 +21,7 @@ def ctx():
 
 # (tile width, LDS-DMA): auto; register-staged 64- and 128-wide; LDS-DMA 128-wide; LDS-DMA with 64-wide
 # tiles for the Khatri-Rao form (plain products fall back to the register-staged 64-wide kernel)
-VARIANTS = [(0, 1), (64, 0), (128, 0), (128, 1), (64, 1)]
+VARIANTS = [(0, 1), (64, 0), (128, 0), (128, 1), (64, 1), (160, 1)]   # 160: Khatri-Rao form only (plain: 128)
 
 
 @pytest.fixture(params=VARIANTS, ids=lambda v: f"tile{v[0]}-dma{v[1]}")
