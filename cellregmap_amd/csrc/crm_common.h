@@ -90,6 +90,8 @@ int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m
                    long cells, bool khatri_rao, int k0, int ksplit, long split_stride);
 // number of slices along the cell axis for a launch that would otherwise have `blocks_without_split` workgroups
 int split_for(long cells_pad, long blocks_without_split);
+int contraction_tile_width(const crm_ctx* ctx, int mt, int max_n, int nz, int ksplit, bool khatri_rao);
+int kr_split_for(const crm_ctx* ctx, long row_tiles, int max_n, int nz, long cells_pad, int max_split);
 int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out = false,
                         int bn = 128);

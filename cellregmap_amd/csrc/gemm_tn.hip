@@ -271,6 +271,42 @@ int split_for(long cells_pad, long blocks_without_split) {
     return (int)((stages + per - 1) / per);
 }
 
+// Output-tile width of a launch: 128-wide tiles (two workgroups per CU) give the Khatri-Rao operand the most MFMAs per
+// LDS read; 64-wide tiles (three per CU) fill the chip better when a launch has few tiles or a narrow output.
+int contraction_tile_width(const crm_ctx* ctx, int mt, int max_n, int nz, int ksplit, bool khatri_rao) {
+    int bn = ctx->tune.bn;
+    if (bn != 64 && bn != 128 && bn != 160) {
+        const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
+        bn = tiles128 < 1024 ? 64 : 128;
+        // narrow outputs (modes A / B: N = k1 + m columns): 64-wide tiles when they waste less padding, one 160-wide
+        // tile for 129 .. 160 columns (mode B at config 3: 150 columns fill it to 94 %, three 64-wide tiles to 78 %)
+        if (khatri_rao && ((max_n + 63) / 64) * 64 * 100 <= ((max_n + 127) / 128) * 128 * 85) bn = 64;
+        if (khatri_rao && ctx->tune.glds && max_n > 128 && max_n <= 160 && (long)mt * nz * ksplit >= 256) bn = 160;
+    }
+    if (bn == 160 && !(khatri_rao && ctx->tune.glds)) bn = 128;
+    return bn;
+}
+
+// Slices along the cell axis for a Khatri-Rao launch of `tiles128` row tiles x column tiles: a launch of a few rounds
+// of workgroups loses the unfilled part of its last round (mode B at config 3: 1600 workgroups on 512 slots = 3.1
+// rounds, a quarter of the time in a round that is 12 % full); cutting the cell axis makes the rounds shorter.
+int kr_split_for(const crm_ctx* ctx, long row_tiles, int max_n, int nz, long cells_pad, int max_split) {
+    const int bn = contraction_tile_width(ctx, (int)std::min<long>(row_tiles, 1 << 20), max_n, nz, 1, true);
+    const long slots = 256L * (bn == 64 ? 3 : 2);
+    const long tiles = row_tiles * ((max_n + bn - 1) / bn);
+    if (tiles <= 0 || tiles > 6 * slots) return 1;
+    const long stages = cells_pad / GEMM_BK;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int ks : {1, 2, 3, 4, 6, 8}) {
+        if (ks > max_split || stages / ks < 32) break;
+        const long w = tiles * ks, rounds = (w + slots - 1) / slots;
+        const double eff = (double)w / (double)(rounds * slots);
+        if (eff > best_eff + (ks == 1 ? 0.0 : 0.04)) { best_eff = eff; best = ks; }
+    }
+    return best;
+}
+
 int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
@@ -295,19 +331,7 @@ int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m
         return CRM_ERR_ARG;
     }
     const int mt = (max_m + GEMM_BM - 1) / GEMM_BM;
-    // 128-wide tiles (two workgroups per CU) give the Khatri-Rao operand the most MFMAs per LDS read
-    // (62.2 vs 60.1 TFLOP/s at config 3); 64-wide tiles (three per CU) fill the chip better when a
-    // launch has few tiles (skinny side contractions: 50.5 vs 42.1 TFLOP/s at M = 1024, N = 5120)
-    int bn = ctx->tune.bn;
-    if (bn != 64 && bn != 128 && bn != 160) {
-        const long tiles128 = (long)mt * ((max_n + 127) / 128) * nz * ksplit;
-        bn = tiles128 < 1024 ? 64 : 128;
-        // narrow outputs (modes A / B: N = k1 + m columns): 64-wide tiles when they waste less padding, one 160-wide
-        // tile for 129 .. 160 columns (mode B at config 3: 150 columns fill it to 94 %, three 64-wide tiles to 78 %)
-        if (khatri_rao && ((max_n + 63) / 64) * 64 * 100 <= ((max_n + 127) / 128) * 128 * 85) bn = 64;
-        if (khatri_rao && ctx->tune.glds && max_n > 128 && max_n <= 160 && (long)mt * nz * ksplit >= 256) bn = 160;
-    }
-    if (bn == 160 && !(khatri_rao && ctx->tune.glds)) bn = 128;
+    const int bn = contraction_tile_width(ctx, mt, max_n, nz, ksplit, khatri_rao);
     const int nt = (max_n + bn - 1) / bn;
     if (ctx->tune.glds && (bn == 128 || khatri_rao)) {
         if (khatri_rao && (k0 < 1 || k0 > 128)) {

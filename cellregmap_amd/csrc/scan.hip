@@ -997,6 +997,19 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         int nz = 0, max_m = 0, max_n = 1;
         double kr_flops = 0.0;
+        // few-round launches of the direct Khatri-Rao route: slices along the cell axis (see kr_split_for)
+        int kr_split = 1;
+        const size_t a_slab = (size_t)max_pairs * k0 * ldA;
+        if (!collapsed && !via_H) {
+            long row_tiles = 0;
+            int nzz = 0, mn = 1;
+            for (int i = 0; i < nrho; i++)
+                if (cnt[i] > 0) { row_tiles += ((long)cnt[i] * k0 + GEMM_BM - 1) / GEMM_BM; nzz++; mn = std::max(mn, bg->r[i]); }
+            const int cap = (int)std::min<size_t>(8, ((size_t)16 << 30) / std::max<size_t>(sizeof(double) * a_slab, 1));
+            kr_split = kr_split_for(ctx, row_tiles, mn, 1, np, std::max(cap, 1));
+            (void)nzz;
+            if (kr_split > 1) CRM_TRY(ctx->ws_A.ensure(sizeof(double) * a_slab * kr_split));
+        }
         for (int i = 0; i < nrho; i++) {
             if (cnt[i] == 0) continue;
             GemmProblem p{};
@@ -1052,8 +1065,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
         else if (via_H)
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
-        else
-            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, 1, 0));
+        else {
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, kr_split, (long)a_slab));
+            CRM_TRY(launch_reduce_splits(st, ctx->ws_A.as<double>(), (long)npairs * k0 * ldA, kr_split, (long)a_slab));
+        }
         if (timing) {
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
             ctx->timed_used++;
