@@ -207,14 +207,14 @@ class BackgroundBuilder:
         _lib.check(_lib.load().crm_background_complete(self._bg.handle, _lib.ptr(ranks)))
 
     def layout(self):
-        """Slot sizes in doubles: {"Q0": n_pad * ldq, "S0": ldq, "Mix": ldh * ldq (absent without mixing matrices)}."""
+        """Slots to exchange and their sizes in doubles: {"S0": ldq, "Mix": ldh * ldq} when the background keeps its
+        half factor (thin branch), else {"Q0": n_pad * ldq, "S0": ldq}."""
         n_pad, ldq, ldh, mix = ctypes.c_long(), ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
         _lib.check(_lib.load().crm_background_layout(self._bg.handle, ctypes.byref(n_pad), ctypes.byref(ldq),
                                                      ctypes.byref(ldh), ctypes.byref(mix)))
-        out = {"Q0": n_pad.value * ldq.value, "S0": ldq.value}
-        if mix.value:
-            out["Mix"] = ldh.value * ldq.value
-        return out
+        if mix.value:   # thin branch: every rank holds H and forms Q0 = H Mix itself, on first use
+            return {"S0": ldq.value, "Mix": ldh.value * ldq.value}
+        return {"Q0": n_pad.value * ldq.value, "S0": ldq.value}
 
     def export_slot(self, i, what, tensor):
         """Copy slot ``what`` of grid point i into ``tensor`` (float64, on this GPU)."""

@@ -121,6 +121,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
                                         nb, Gb, ldb, (int)ldb));
         CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, ld_gW));
         GemmProblem p{};
+        CRM_TRY(crm_background_require_q0(bg, ri));
         p.X = Gb; p.ldx = ldb; p.Y = bg->Q0[ri].as<double>(); p.ldy = ldq;
         p.C = ctx->ws_T.as<double>(); p.ldc = ldT; p.M = nb; p.N = bg->r[ri] > 0 ? bg->r[ri] : 1;
         CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, &p, sizeof p, hipMemcpyHostToDevice, st));

@@ -406,6 +406,8 @@ static int background_complete(crm_background* bg, const int* r_all) {
         // keep the half factor: T(rho) = Q0(rho)'G is later taken as Mix(rho)' (H'G), see scan.hip
         bg->H = dH;
         dH = DevBuf();
+        bg->Ht = dHt;   // (its transpose: operand of Q0 = H Mix, formed on first use)
+        dHt = DevBuf();
         bg->ldh = cp;
         bg->cols = cols;
     } else {
@@ -419,10 +421,13 @@ static int background_complete(crm_background* bg, const int* r_all) {
         CRM_HIP(hipMemsetAsync(dT1.ptr, 0, sizeof(double) * cp * ldq, st));
     }
     CRM_HIP(hipMemsetAsync(dG.ptr, 0, sizeof(double) * ldq * ldq * 2, st));
+    const bool eager = getenv("CRM_EAGER_Q0") != nullptr;
     for (int i = 0; i < nrho; i++) {
-        CRM_TRY(bg->Q0[i].ensure(sizeof(double) * np * ldq));
+        if (!thin) {   // (thin branch: Q0 = H Mix on first use, crm_background_require_q0)
+            CRM_TRY(bg->Q0[i].ensure(sizeof(double) * np * ldq));
+            CRM_HIP(hipMemsetAsync(bg->Q0[i].ptr, 0, sizeof(double) * np * ldq, st));
+        }
         CRM_TRY(bg->S0[i].ensure(sizeof(double) * ldq));
-        CRM_HIP(hipMemsetAsync(bg->Q0[i].ptr, 0, sizeof(double) * np * ldq, st));
         CRM_HIP(hipMemsetAsync(bg->S0[i].ptr, 0, sizeof(double) * ldq, st));
         if (thin) {
             CRM_TRY(bg->Mix[i].ensure(sizeof(double) * cp * ldq));
@@ -448,7 +453,7 @@ static int background_complete(crm_background* bg, const int* r_all) {
     };
     for (int i : bb->mine) {
         const int r = bg->r[i];
-        if (r == 0) continue;
+        if (r == 0) continue;   // (an empty grid point: require_q0 just allocates zeros)
         CRM_HIP(hipMemcpyAsync(bg->S0[i].ptr, bb->S0_host[i].data(), sizeof(double) * r, hipMemcpyHostToDevice, st));
         const long ldm = round_up(r, 128);
         if (thin) {
@@ -485,13 +490,12 @@ static int background_complete(crm_background* bg, const int* r_all) {
                     break;
                 }
             }
-            // Q0 = H Mix  ==  Ht' Mix  (contraction over the cols axis)
-            CRM_TRY(contract(ctx, dHt.as<double>(), np, Mix, ldq, bg->Q0[i].as<double>(), ldq, (int)n, r, cp));
         } else {
             CRM_HIP(hipMemcpy2DAsync(bg->Q0[i].ptr, ldq * sizeof(double), bb->Mbuf[i].ptr, ldm * sizeof(double),
                                      r * sizeof(double), n, hipMemcpyDeviceToDevice, st));
             CRM_HIP(hipStreamSynchronize(st));
             bb->Mbuf[i].release();
+            bg->q0_ready[i] = true;
             // eigenvectors of the n x n route: orthonormal to ~1e-14 sqrt(n) as they come; one check, and a
             // correction if ever needed
             for (int pass = 0; pass < 3; pass++) {
@@ -512,8 +516,14 @@ static int background_complete(crm_background* bg, const int* r_all) {
         }
     }
     CRM_HIP(hipStreamSynchronize(st));
-    trace.lap("Q0 = H Mix + polish");
+    trace.lap(thin ? "polish of the mixing matrices" : "Q0 + polish");
     bb->completed = true;
+    if (thin && eager) {
+        bg->fast_T = true;   // (H and Mix are in place)
+        for (int i : bb->mine) CRM_TRY(crm_background_require_q0(bg, i));
+        bg->fast_T = false;
+        trace.lap("Q0 = H Mix (eager)");
+    }
     return CRM_OK;
 }
 
@@ -537,12 +547,20 @@ static int background_seal(crm_background* bg) {
         for (double v : s0) { smax = std::max(smax, v); smin = std::min(smin, v); }
         if (!(smax <= 1e6 * smin)) bg->fast_T = false;
     }
-    if (!bg->fast_T) {
-        bg->H.release();
-        for (int i = 0; i < bg->nrho; i++) bg->Mix[i].release();
-    }
+    const bool thin = bb->thin;
     delete bb;
     bg->builder = nullptr;
+    if (!bg->fast_T) {
+        if (thin) {   // the scan will rotate with Q0 itself: form all of them now, then drop H and the mixing matrices
+            bg->fast_T = true;
+            const int rc = crm_background_require_q0(bg, -1);
+            bg->fast_T = false;
+            CRM_TRY(rc);
+        }
+        bg->H.release();
+        bg->Ht.release();
+        for (int i = 0; i < bg->nrho; i++) bg->Mix[i].release();
+    }
     return CRM_OK;
 }
 #undef CRM_BG
@@ -599,7 +617,7 @@ extern "C" int crm_background_layout(const crm_background* bg, long* n_pad, long
     if (!bg || !bg->builder || !bg->builder->completed) return CRM_ERR_ARG;
     if (n_pad) *n_pad = bg->n_pad;
     if (ldq) *ldq = bg->ldq;
-    if (ldh) *ldh = bg->builder->thin ? bg->builder->cp : 0;
+    if (ldh) *ldh = bg->builder->thin ? bg->builder->cp : 0;   // > 0: exchange S0 and Mix only, Q0 = H Mix is formed locally
     if (has_mix) *has_mix = bg->builder->thin ? 1 : 0;
     return CRM_OK;
 }
@@ -618,6 +636,10 @@ static int background_slot(const crm_background* bg, int i, int what, void** ptr
 extern "C" int crm_background_export(const crm_background* bg, int i, int what, void* dst_device) {
     void* p = nullptr;
     size_t bytes = 0;
+    if (bg && what == 0 && i >= 0 && i < bg->nrho && !bg->q0_ready[i] && bg->builder && bg->builder->thin) {
+        set_error("background: Q0 of a thin-branch grid point is not exchanged (S0 and Mix are; Q0 = H Mix is formed locally)");
+        return CRM_ERR_ARG;
+    }
     if (!dst_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(bg->ctx->device));
     CRM_HIP(hipMemcpyAsync(dst_device, p, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
@@ -632,6 +654,41 @@ extern "C" int crm_background_import(crm_background* bg, int i, int what, const 
     CRM_HIP(hipSetDevice(bg->ctx->device));
     CRM_HIP(hipMemcpyAsync(p, src_device, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
     CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
+    if (what == 0) bg->q0_ready[i] = true;
+    return CRM_OK;
+}
+
+int crm_background_require_q0(crm_background* bg, int i) {
+    if (!bg) return CRM_ERR_ARG;
+    if (i < 0) {
+        for (int q = 0; q < bg->nrho; q++) CRM_TRY(crm_background_require_q0(bg, q));
+        return CRM_OK;
+    }
+    if (i >= bg->nrho) return CRM_ERR_ARG;
+    if (bg->q0_ready[i]) return CRM_OK;
+    crm_ctx* ctx = bg->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long np = bg->n_pad, ldq = bg->ldq;
+    if (!bg->H.ptr || !bg->Mix[i].ptr) {
+        set_error("background: Q0 of grid point %d is neither present nor derivable (no half factor / mixing matrix)", i);
+        return CRM_ERR_ARG;
+    }
+    TraceRange range("crm Q0 = H Mix");
+    CRM_TRY(bg->Q0[i].ensure(sizeof(double) * np * ldq));
+    CRM_HIP(hipMemsetAsync(bg->Q0[i].ptr, 0, sizeof(double) * np * ldq, st));
+    if (bg->r[i] > 0) {
+        if (!bg->Ht.ptr) {
+            CRM_TRY(bg->Ht.ensure(sizeof(double) * bg->ldh * np));
+            CRM_HIP(hipMemsetAsync(bg->Ht.ptr, 0, sizeof(double) * bg->ldh * np, st));
+            CRM_TRY(transpose(st, bg->H.as<double>(), bg->ldh, bg->n, bg->cols, bg->Ht.as<double>(), np));
+        }
+        // Q0 = H Mix  ==  Ht' Mix  (contraction over the cols axis)
+        CRM_TRY(contract(ctx, bg->Ht.as<double>(), np, bg->Mix[i].as<double>(), ldq, bg->Q0[i].as<double>(), ldq,
+                         (int)bg->n, bg->r[i], bg->ldh));
+    }
+    CRM_HIP(hipStreamSynchronize(st));
+    bg->q0_ready[i] = true;
     return CRM_OK;
 }
 

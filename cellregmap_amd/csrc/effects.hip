@@ -149,6 +149,7 @@ extern "C" int crm_cov_solve(crm_background* bg, int rho_index, double v0, doubl
     CRM_TRY(d_out.ensure(sizeof(double) * n * m));
     CRM_TRY(d_prob.ensure(sizeof(GemmProblem)));
     CRM_TRY(upload_padded(st, d_rhs.as<double>(), ldr, np, rhs, m, n, m));
+    CRM_TRY(crm_background_require_q0(bg, rho_index));
     if (r > 0) {
         GemmProblem p{};
         p.X = d_rhs.as<double>(); p.ldx = ldr;

@@ -35,7 +35,9 @@ struct crm_background {
     int r[crm::CRM_MAX_RHO] = {0};
     double ortho_defect[crm::CRM_MAX_RHO] = {0};  // max |Q0'Q0 - I| after the polish
     long ldq = 0;                        // common leading dimension (multiple of 128)
-    crm::DevBuf Q0[crm::CRM_MAX_RHO];    // [n_pad x ldq], zero padded
+    crm::DevBuf Q0[crm::CRM_MAX_RHO];    // [n_pad x ldq], zero padded; thin branch: formed on first use (q0_ready)
+    bool q0_ready[crm::CRM_MAX_RHO] = {false};
+    crm::DevBuf Ht;                      // H' (ldh x n_pad), kept once a lazy Q0 has been formed
     crm::DevBuf S0[crm::CRM_MAX_RHO];    // [ldq]
     // thin branch with a well-conditioned kept spectrum: Q0(rho) = H Mix(rho), H = [E1, B]
     bool fast_T = false;
@@ -47,6 +49,11 @@ struct crm_background {
     std::vector<crm_donor_tables*> dt_cache;
     unsigned long dt_clock = 0;
 };
+
+// Q0(rho_i) = H Mix(rho_i) in device memory (i < 0: every grid point).  Backgrounds of the thin branch keep the
+// half factor H and the mixing matrices; the rotations of the scan go through them, and most scans select only a
+// few grid points as rho*, so Q0 -- 2 n cols r flops and n x r doubles per grid point -- is formed on first use.
+int crm_background_require_q0(crm_background* bg, int i);
 
 // One phenotype: y, W, E0 and what only depends on them.
 struct crm_gene {

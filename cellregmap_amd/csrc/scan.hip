@@ -93,6 +93,7 @@ int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, 
         if (rc == CRM_OK)
             rc = upload_padded(ctx->stream, bg->S0[i].as<double>(), bg->ldq, 1, S0[i], r[i], 1, r[i]);
         if (rc != CRM_OK) { crm_background_destroy(bg); return rc; }
+        bg->q0_ready[i] = true;
     }
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = bg;
@@ -109,6 +110,7 @@ void crm_background_destroy(crm_background* bg) {
         bg->Mix[i].release();
     }
     bg->H.release();
+    bg->Ht.release();
     for (crm_donor_tables* t : bg->dt_cache) {
         t->release();
         delete t;
@@ -124,6 +126,7 @@ int crm_background_rank(const crm_background* bg, int i) {
 
 int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0) {
     if (!bg || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
+    if (Q0) CRM_TRY(crm_background_require_q0(const_cast<crm_background*>(bg), i));
     CRM_HIP(hipSetDevice(bg->ctx->device));
     const int r = bg->r[i];
     if (Q0 && r > 0)
@@ -208,8 +211,37 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     // rotations t = Q0(rho)' [y, W] for every grid point: rows of a [(1+c) x ldq] matrix
     const int nrho = bg->nrho;
     const long ldq = bg->ldq;
-    const int ks = pick_split(np, (ldq / GEMM_BN) * nrho);
     const long slab = (long)(1 + c) * ldq;
+    if (bg->fast_T) {
+        // Q0(rho) = H Mix(rho):  t = Mix(rho)' (H'[y, W]) -- no Q0 needed
+        ScopedBuf thw;
+        const long ldh = bg->ldh;
+        if ((rc = thw.ensure(sizeof(double) * ldh * 128)) != CRM_OK) return fail(rc);
+        if ((rc = g->rot.ensure(sizeof(double) * slab * nrho)) != CRM_OK) return fail(rc);
+        if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4))) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemsetAsync(thw.ptr, 0, sizeof(double) * ldh * 128, ctx->stream));
+        CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho, ctx->stream));
+        std::vector<GemmProblem> pr(nrho + 1);
+        GemmProblem p0{};
+        p0.X = bg->H.as<double>(); p0.ldx = ldh; p0.Y = g->yW.as<double>(); p0.ldy = ldyw;
+        p0.C = thw.as<double>(); p0.ldc = 128; p0.M = (int)bg->cols; p0.N = 1 + c;
+        pr[0] = p0;
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = thw.as<double>(); p.ldx = 128; p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+            p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
+            p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            pr[1 + i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, pr.data(), sizeof(GemmProblem) * (nrho + 1), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, (int)bg->cols, 1 + c, np, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>() + 1, nrho, 1 + c, (int)ldq, ldh, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        CRM_HIP(hipStreamSynchronize(ctx->stream));
+        *out = g;
+        return CRM_OK;
+    }
+    if ((rc = crm_background_require_q0(bg, -1)) != CRM_OK) return fail(rc);
+    const int ks = pick_split(np, (ldq / GEMM_BN) * nrho);
     if ((rc = g->rot.ensure(sizeof(double) * slab * nrho * ks)) != CRM_OK) return fail(rc);
     std::vector<GemmProblem> probs(nrho);
     for (int i = 0; i < nrho; i++) {
@@ -552,6 +584,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
     const double* Z = panel->Z.as<double>();
+    if (full) CRM_TRY(crm_background_require_q0(bg, -1));   // the tables are contractions against every Q0(rho)
     if (full) {
         CRM_TRY(shared->TZ.ensure(sizeof(double) * (size_t)nrho * mp * ldq));
         CRM_TRY(shared->Bd.ensure(sizeof(double) * (size_t)nrho * mp * k0 * ldq));
@@ -914,6 +947,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         //    done once, (H'G), followed by eleven small products Mix(rho)'(H'G): 2 n cols + 2 cols sum r
         //    flops per variant instead of 2 n sum r.
         const bool fastT = !collapsed && bg->fast_T && ctx->fast_T;
+        if (!fastT && !collapsed) CRM_TRY(crm_background_require_q0(bg, -1));
         if (fastT) {
             GemmProblem p{};
             p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
@@ -997,6 +1031,9 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         int nz = 0, max_m = 0, max_n = 1;
         double kr_flops = 0.0;
+        if (!collapsed && !via_H)
+            for (int i = 0; i < nrho; i++)
+                if (cnt[i] > 0) CRM_TRY(crm_background_require_q0(bg, i));
         // few-round launches of the direct Khatri-Rao route: slices along the cell axis (see kr_split_for)
         int kr_split = 1;
         const size_t a_slab = (size_t)max_pairs * k0 * ldA;

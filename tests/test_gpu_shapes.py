@@ -60,6 +60,8 @@ def test_randomised_sweep_against_the_oracle(i, n, k0, c, p, donors, mode, perm)
     from cellregmap_amd import CellRegMap, GenotypePanel
     from oracle.crm import OracleCellRegMap
 
+    from cellregmap_amd import _engine, _lib
+
     y, E, W, G, kw = _random_problem(n, k0, c, p, donors, seed=1000 + i, mode=mode)
     idx = np.random.default_rng(i).permutation(n)
     hooks = {} if perm == "none" else ({"idx_E": idx} if perm == "E" else {"idx_G": idx})
@@ -68,8 +70,22 @@ def test_randomised_sweep_against_the_oracle(i, n, k0, c, p, donors, mode, perm)
     for groups in (None, "auto"):
         pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
         assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
-        assert_allclose(st["Q"], ost["Q"], rtol=1e-6)
+        # verbatim procedure: two roundings of the objective may end Brent's search 1e-6 apart (tests/test_oracle_spread.py
+        # measures that on the oracle alone): 5e-6 here, the sharp comparison is the polished one below
+        assert_allclose(st["Q"], ost["Q"], rtol=5e-6)
         assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
+    if c <= 8:   # (the polish is built for the register null-fit kernel)
+        lib = _lib.load()
+        _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 1))
+        try:
+            ppv, pinfo, pst = OracleCellRegMap(y, E, W=W, polish=True, **kw).scan_interaction(G, return_stats=True, **hooks)
+            for groups in (None, "auto"):
+                pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
+                assert_allclose(info["rho1"], pinfo["rho1"], atol=1e-12)
+                assert_allclose(st["Q"], pst["Q"], rtol=1e-8)
+                assert np.all(np.abs(pv - ppv) <= 2e-6 * ppv + P_ATOL), np.c_[pv, ppv]
+        finally:
+            _lib.check(lib.crm_set_null_fit_polish(_engine._context(0), 0))
 
 
 def test_sub_range_of_a_panel_through_the_c_abi():
