@@ -167,8 +167,9 @@ def main():
     t_start = time.perf_counter()
     Ls = get_L_values(cohort.hK, cohort.E)
     bg_kw = {"Ls": Ls} if args.mode == "C" else {"hK": cohort.hK}
-    if world > 1:
-        bg = sharded_background(cohort.E, Ls if args.mode == "C" else cohort.hK, _engine._RHO_GRID, device=local_rank)
+    if world > 1 or (dist is not None and os.environ.get("CRM_BENCH_FORCE_EXCHANGE")):
+        bg = sharded_background(cohort.E, Ls if args.mode == "C" else cohort.hK, _engine._RHO_GRID, device=local_rank,
+                                force_exchange=world == 1)
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, background=bg, **bg_kw)
     else:
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)

@@ -53,7 +53,7 @@ def grid_point_owner(i, world):
     return i % world
 
 
-def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_device=None):
+def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_device=None, force_exchange=False):
     """The background of ``CellRegMap(...)`` (cellregmap/_cellregmap.py:101-131: one economic
     eigendecomposition per grid point of rho) built ONCE per job instead of once per rank: rank r decomposes
     the grid points i with i % world == r, the ranks are all-gathered (they fix the common leading
@@ -85,9 +85,11 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
         def builder(flags):
             return BackgroundBuilder(E1, B, rho, device=device, mine=flags)
     b = builder(mine)
-    if world == 1:
+    if world == 1 and not (force_exchange and dist.is_available() and dist.is_initialized()):
         b.complete([b.rank(i) for i in range(nrho)])
         return b.seal()
+    # (force_exchange: a world of one still runs the collective calls and copies every slot out and back in --
+    # the whole exchange path on a single GPU)
     nccl = dist.get_backend(group) == "nccl"
     dev = tensor_device if tensor_device is not None else (torch.device("cuda", device) if nccl else torch.device("cpu"))
     ranks = torch.tensor([b.rank(i) if mine[i] else -1 for i in range(nrho)], dtype=torch.int64, device=dev)
@@ -101,7 +103,7 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
                 b.export_slot(i, what, buf)
             src = owner if group is None else dist.get_global_rank(group, owner)
             dist.broadcast(buf, src=src, group=group)
-            if owner != rank:
+            if owner != rank or force_exchange:
                 b.import_slot(i, what, buf)
         del buf
     return b.seal()
