@@ -626,6 +626,20 @@ class CellRegMap:
             return out["pv"], info, extra
         return out["pv"], info
 
+    def scan_interaction_info(self, G, idx_E=None, idx_G=None):
+        """The p-values together with chiscore's ``info`` of ``davies_pvalue(Q, F, True)`` (which the reference
+        computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault"})``."""
+        lib = _lib.load()
+        panel = self._panel(G)
+        n, p = panel.shape
+        gene = self._bind_gene()
+        iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+        pv, liu = np.empty(p), np.empty(p)
+        ifault = np.empty(p, np.int32)
+        _lib.check(lib.crm_scan_interaction_info(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
+                                                 _lib.ptr(ifault), _lib.ptr(liu)))
+        return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault}
+
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False):
         lib = _lib.load()

@@ -667,6 +667,8 @@ namespace crm {
 
 struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: count*k0, F: count*k0*k0)
     double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
+    int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
+    double* liu = nullptr;   // the modified-Liu p-value (chiscore's info["liu_pval"])
 };
 
 // One pass over variants [first, first + count) for one or several genes that share the background,
@@ -1170,6 +1172,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             if (o.Q) CRM_HIP(hipMemcpyAsync(o.Q + done, d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
             if (o.lambda) CRM_HIP(hipMemcpyAsync(o.lambda + done * k0, d_lam, sizeof(double) * nb * k0, hipMemcpyDeviceToHost, st));
             if (o.F) CRM_HIP(hipMemcpyAsync(o.F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
+            if (o.ifault) CRM_HIP(hipMemcpyAsync(o.ifault + done, d_if, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+            if (o.liu) CRM_HIP(hipMemcpyAsync(o.liu + done, d_liu, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
             for (int b = 0; b < nb; b++) {
                 const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
                 const double rho = bg->rho[f.rho_index];
@@ -1201,6 +1205,17 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
     std::vector<crm_gene*> genes{gene};
     std::vector<ScanOut> outs{{out_pvalue, out_rho1, out_e2, out_g2, out_eps2, out_Q, out_lml, out_delta,
                                out_scale, out_lambda, out_F}};
+    return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+}
+
+int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
+                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue) {
+    if (!gene || !panel) return CRM_ERR_ARG;
+    std::vector<crm_gene*> genes{gene};
+    ScanOut o{out_pvalue, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    o.ifault = out_ifault;
+    o.liu = out_liu_pvalue;
+    std::vector<ScanOut> outs{o};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
 }
 

@@ -132,6 +132,13 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
                          double* out_delta, double* out_scale, double* out_lambda, double* out_F);
 
+/* The same scan returning what chiscore.davies_pvalue(Q, F, True) reports beside the p-value (_cellregmap.py:435 asks
+ * for it and discards it): out_ifault = Davies' fault code per variant (0: converged = Is_Converged 1; 1 / 4: the
+ * integration gave up and the p-value IS the modified-Liu one, 2: round-off flagged, the integral kept; -2: no
+ * eigenvalue above the SKAT threshold, p = NaN where the reference raises), out_liu_pvalue = info["liu_pval"]. */
+int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
+                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue);
+
 /* Several phenotypes against one panel in one pass ("genes" that share the background, W and E0):
  * everything that does not depend on y -- G'Q0(rho), the Khatri-Rao contraction per (variant, rho)
  * pair selected by at least one gene, the y-free side contractions -- is computed once per block.

@@ -180,3 +180,49 @@ def test_progress_callback_reports_every_block():
     assert seen == [(128, 300), (256, 300), (300, 300)]
     pv2, _ = crm.scan_interaction(c.G, progress=True)          # tqdm bar on stderr
     assert np.array_equal(pv, pv2)
+
+
+def test_davies_info_is_surfaced():
+    """chiscore's (liu_pval, Is_Converged) beside the p-value: same scan, same p-values, the oracle's info."""
+    from cellregmap_amd import CellRegMap
+    from cellregmap_amd.synth import make_cohort
+    from oracle.crm import OracleCellRegMap
+    from oracle.davies import davies_pvalue
+
+    c = make_cohort(8, 20, 4, 20, seed=31)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    pv, _ = crm.scan_interaction(c.G)
+    pv2, info = crm.scan_interaction_info(c.G)
+    assert np.array_equal(pv, pv2)
+    assert set(info) == {"liu_pval", "Is_Converged", "ifault"} and info["ifault"].dtype == np.int32
+    _, _, ost = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G, return_stats=True)
+    for j in range(20):
+        _, oinfo = davies_pvalue(ost["Q"][j], ost["F"][j], True)
+        assert info["Is_Converged"][j] == oinfo["Is_Converged"]
+        assert abs(info["liu_pval"][j] - oinfo["liu_pval"]) <= 1e-6 * oinfo["liu_pval"] + 1e-12
+
+
+def test_null_p_values_are_not_inflated():
+    """Statistical acceptance in the spirit of cellregmap/test/test_struct_lmm2.py:210-211, 278-279 (under the null the
+    median p-value stays above 0.3 and the smallest above 0.04 over a handful of variants): here 1 500 independent
+    variants on a phenotype with context and kinship structure but no genetic effect.  The score test with estimated
+    variance components is mildly conservative on 60 donors (the p-values lean towards 1), so the check is one-sided:
+    no inflation of small p-values."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+
+    rng = np.random.default_rng(2027)
+    donors, cells, k = 60, 12, 5
+    n = donors * cells
+    donor = np.repeat(np.arange(donors), cells)
+    E = rng.normal(size=(n, k)); E = (E - E.mean(0)) / E.std(0)
+    hK = np.zeros((n, donors)); hK[np.arange(n), donor] = 1.0
+    y = E @ rng.normal(size=k) * 0.4 + hK @ rng.normal(size=donors) * 0.6 + rng.normal(size=n)
+    maf = rng.uniform(0.1, 0.5, size=1500)
+    Gd = rng.binomial(2, maf, size=(donors, 1500)).astype(float)
+    Gd = Gd[:, Gd.std(0) > 0]
+    G = ((Gd - Gd.mean(0)) / Gd.std(0))[donor]
+    pv, info = CellRegMap(y, E, hK=hK).scan_interaction(GenotypePanel(G))
+    assert np.all((pv > 0) & (pv <= 1))
+    assert np.mean(pv < 0.05) < 0.075 and np.mean(pv < 0.01) < 0.02
+    assert np.median(pv) > 0.3
+    assert pv.min() > 0.01 / pv.size      # nothing a Bonferroni threshold at 1 % would call
