@@ -93,6 +93,23 @@ __global__ void newton_schulz_kernel(const double* __restrict__ G, long ldg, int
     if (threadIdx.x == 0) err_blocks[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
 }
 
+// err = max |G[i, jj] - (i == off + jj)| over an r x ncols slab of Mix' C Mix (columns off .. off + ncols)
+__global__ void defect_slab_kernel(const double* __restrict__ G, long ldg, int r, int ncols, int off,
+                                   double* __restrict__ err_blocks) {
+    __shared__ double red[256];
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    double e = 0.0;
+    if (jj < ncols) e = fabs(G[(long)i * ldg + jj] - ((i == off + jj) ? 1.0 : 0.0));
+    red[threadIdx.x] = e;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) err_blocks[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
 // Q0[i, j] = V[i, keep[j]] from the column-major eigenvector matrix
 __global__ void gather_vectors_kernel(const double* __restrict__ V, long ldv, const int* __restrict__ keep,
                                       int r, long n, double* __restrict__ Q0, long ldq) {
@@ -467,6 +484,27 @@ static int background_complete(crm_background* bg, const int* r_all) {
             // order cols^2 r instead of n r^2; Q0 = H Mix is then formed once.  The Gram route loses
             // orthonormality for small eigenvalues (defect ~ eps * S_max / S_j) and the path's complement
             // terms (u'v - (Q0'u)'(Q0'v)) / d see any defect directly.
+            // First a look at the columns that belong to the 256 .. 383 smallest kept eigenvalues (the last ones: the defect of
+            // the Gram route is ~ eps |C| / sqrt(lambda_i lambda_j), largest there): 256 / r of the cost of a pass.
+            // Below 2e-13 the mixing matrix stays as the eigen-solver left it.
+            {
+                // (offset on a tile boundary: the operand tiles of the contraction then end with the row, ldq % 128 == 0)
+                const int off = r > 256 ? (r - 256) / 128 * 128 : 0, ns = r - off;
+                CRM_TRY(contract(ctx, dC.as<double>(), cp, Mix + off, ldq, dT1.as<double>(), ldq, (int)cols, ns, cp));
+                CRM_TRY(contract(ctx, Mix, ldq, dT1.as<double>(), ldq, Gq, ldq, r, ns, cp));
+                dim3 grid((unsigned)((ns + 255) / 256), (unsigned)r);
+                hipLaunchKernelGGL(defect_slab_kernel, grid, dim3(256), 0, st, Gq, ldq, r, ns, off, dErr.as<double>());
+                CRM_HIP(hipGetLastError());
+                std::vector<double> herr((size_t)grid.x * grid.y);
+                CRM_HIP(hipMemcpyAsync(herr.data(), dErr.ptr, sizeof(double) * herr.size(), hipMemcpyDeviceToHost, st));
+                CRM_HIP(hipStreamSynchronize(st));
+                double est = 0.0;
+                for (double e : herr) est = std::max(est, e);
+                if (trace.on) fprintf(stderr, "[crm background]     rho[%d] defect over the last %d columns: %.3g\n", i, ns, est);
+                bg->ortho_defect[i] = est;
+                if (est < 2e-13) continue;
+                if (ns < r) CRM_HIP(hipMemsetAsync(dT1.ptr, 0, sizeof(double) * cp * ldq, st));
+            }
             for (int pass = 0; pass < 3; pass++) {
                 CRM_TRY(contract(ctx, dC.as<double>(), cp, Mix, ldq, dT1.as<double>(), ldq, (int)cols, r, cp));   // C Mix
                 CRM_TRY(contract(ctx, Mix, ldq, dT1.as<double>(), ldq, Gq, ldq, r, r, cp));                         // Mix' C Mix
