@@ -146,7 +146,7 @@ def main():
         G_full = np.ascontiguousarray(full.G[:, f_first:f_first + f_count])             # ... of which it keeps its shard
         donor_of_cell = full.donor_of_cell
         del full
-    weak_blocks = max(1, min(steps, 12))
+    weak_blocks = max(1, min(steps, 12 if world == 1 else 4))   # (N ranks generate their panels side by side on one host)
     if G_full is not None and f_count >= weak_blocks * batch:
         G_weak = G_full[:, :weak_blocks * batch]
     else:
