@@ -772,14 +772,88 @@ class CellRegMap:
         return E0 @ ((rho1 * v0) * gE.T @ v)
 
 
-def scan_interaction_many(crms, G, idx_E=None, idx_G=None):
+def _cis_runs(cis_index, ngenes, p, dense_limit=1 << 26):
+    """Split the variant axis of a panel into maximal runs over which the set of phenotypes that test the
+    variant does not change.  ``cis_index[i]``: the variants of phenotype i -- a ``(start, stop)`` pair, a
+    ``slice`` or an array of column indices (any order, repeats allowed).  Returns ``(columns, runs)``:
+    ``columns[i]`` the int64 column indices of phenotype i as given, ``runs`` a list of
+    ``(first, count, genes)`` with ``genes`` the sorted phenotype numbers active on ``[first, first+count)``;
+    variants nobody asks for are in no run."""
+    if len(cis_index) != ngenes:
+        raise ValueError(f"cis_index has {len(cis_index)} entries for {ngenes} phenotypes")
+    columns = []
+    for i, sel in enumerate(cis_index):
+        if isinstance(sel, slice):
+            cols = np.arange(p, dtype=np.int64)[sel]
+        elif (isinstance(sel, tuple) and len(sel) == 2 and all(isinstance(v, (int, np.integer)) for v in sel)):
+            if not 0 <= sel[0] <= sel[1] <= p:
+                raise ValueError(f"cis_index[{i}] = {sel} is not a range inside [0, {p}]")
+            cols = np.arange(sel[0], sel[1], dtype=np.int64)
+        else:
+            cols = np.asarray(sel)
+            if cols.dtype == bool:
+                if cols.shape != (p,):
+                    raise ValueError(f"cis_index[{i}]: a boolean mask must have one entry per variant")
+                cols = np.flatnonzero(cols)
+            cols = cols.astype(np.int64, copy=False).ravel()
+            if cols.size and (cols.min() < -p or cols.max() >= p):
+                raise ValueError(f"cis_index[{i}] has a variant index outside the panel (p = {p})")
+            cols = np.where(cols < 0, cols + p, cols)
+        columns.append(cols)
+    # +1 / -1 events on the variant axis per phenotype, from the sorted distinct columns of each
+    active = np.zeros((ngenes, p), dtype=bool) if ngenes * p <= dense_limit else None
+    runs = []
+    if active is not None:
+        for i, cols in enumerate(columns):
+            active[i, cols] = True
+        if p == 0:
+            return columns, runs
+        change = np.flatnonzero((active[:, 1:] != active[:, :-1]).any(axis=0)) + 1
+        bounds = np.concatenate(([0], change, [p]))
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            genes = np.flatnonzero(active[:, a])
+            if genes.size:
+                runs.append((int(a), int(b - a), genes))
+        return columns, runs
+    # large panels x many phenotypes: sweep over the run boundaries of each phenotype instead of a dense mask
+    starts, stops = [], []
+    for i, cols in enumerate(columns):
+        u = np.unique(cols)
+        if u.size == 0:
+            continue
+        brk = np.flatnonzero(np.diff(u) > 1)
+        a = np.concatenate(([u[0]], u[brk + 1]))
+        b = np.concatenate((u[brk] + 1, [u[-1] + 1]))
+        starts += [(int(x), i) for x in a]
+        stops += [(int(x), i) for x in b]
+    events = sorted([(x, 1, i) for x, i in starts] + [(x, 0, i) for x, i in stops])
+    current, at = set(), 0
+    k = 0
+    while k < len(events):
+        x = events[k][0]
+        if current and x > at:
+            runs.append((at, x - at, np.array(sorted(current))))
+        while k < len(events) and events[k][0] == x:
+            _, opening, i = events[k]
+            (current.add if opening else current.discard)(i)
+            k += 1
+        at = x
+    return columns, runs
+
+
+def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None):
     """Interaction scans of several phenotypes against one genotype panel in a single pass.
 
     ``crms``: ``CellRegMap`` objects that share the background, ``W`` and ``E`` (e.g. built with
     ``background=crms[0]._bg``).  Work that does not depend on the phenotype is done once per block
     of variants (the reference redoes everything per gene).  Returns
     ``(pvalues, info)`` with arrays of shape (len(crms), p); row i equals
-    ``crms[i].scan_interaction(G, idx_E, idx_G)``."""
+    ``crms[i].scan_interaction(G, idx_E, idx_G)``.
+
+    ``cis_index`` (optional): one entry per phenotype naming the variants it is tested against (its cis
+    window) -- a ``(start, stop)`` pair, a slice, a boolean mask or an array of column indices.  The panel is
+    walked once; each stretch of variants is scanned for exactly the phenotypes whose window covers it.  The
+    results are then lists: entry i holds the arrays of ``crms[i].scan_interaction(G[:, cis_index[i]], ...)``."""
     lib = _lib.load()
     crms = list(crms)
     if not crms:
@@ -801,17 +875,33 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None):
     ng = len(genes)
 
     iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+    keys = ("pv", "rho1", "e2", "g2", "eps2")
+    if cis_index is not None:
+        columns, runs = _cis_runs(cis_index, ng, p)
+        full = {k: [np.full(p, np.nan) if columns[i].size else None for i in range(ng)] for k in keys}
+        for a, count, active in runs:
+            handles = (ctypes.c_void_p * len(active))(*[genes[i].value for i in active])
+            out = {k: np.empty((len(active), count)) for k in keys}
+            _lib.check(lib.crm_scan_interaction_multi(handles, len(active), panel.handle, a, count, _lib.ptr(iE),
+                                                      _lib.ptr(iG), *[_lib.ptr(out[k]) for k in keys], None))
+            for row, i in enumerate(active):
+                for k in keys:
+                    full[k][i][a:a + count] = out[k][row]
+        res = {k: [full[k][i][columns[i]] if columns[i].size else np.empty(0) for i in range(ng)] for k in keys}
+        return res["pv"], {k: res[k] for k in keys[1:]}
     handles = (ctypes.c_void_p * ng)(*[g.value for g in genes])
-    out = {k: np.empty((ng, p)) for k in ("pv", "rho1", "e2", "g2", "eps2")}
+    out = {k: np.empty((ng, p)) for k in keys}
     _lib.check(lib.crm_scan_interaction_multi(handles, ng, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),
                                               _lib.ptr(out["pv"]), _lib.ptr(out["rho1"]), _lib.ptr(out["e2"]),
                                               _lib.ptr(out["g2"]), _lib.ptr(out["eps2"]), None))
     return out["pv"], {k: out[k] for k in ("rho1", "e2", "g2", "eps2")}
 
 
-def run_interaction_many(Y, E, G, W=None, E1=None, E2=None, hK=None, *, device=0):
+def run_interaction_many(Y, E, G, W=None, E1=None, E2=None, hK=None, *, cis_index=None, device=0):
     """``run_interaction`` for the columns of ``Y`` (n x genes) with one background decomposition,
-    one genotype upload and shared per-variant work.  Returns arrays of shape (genes, p)."""
+    one genotype upload and shared per-variant work.  Returns arrays of shape (genes, p); with
+    ``cis_index`` (see ``scan_interaction_many``) lists of per-phenotype arrays over each phenotype's own
+    variants."""
     Y = np.asarray(Y, float)
     if Y.ndim != 2:
         raise ValueError("Y must be n x genes")
@@ -823,7 +913,7 @@ def run_interaction_many(Y, E, G, W=None, E1=None, E2=None, hK=None, *, device=0
     first = CellRegMap(y=Y[:, 0], E=E, W=W, E1=E1, Ls=Ls, device=device)
     crms = [first] + [CellRegMap(y=Y[:, i], E=E, W=W, E1=E1, Ls=Ls, device=device, background=first._bg)
                       for i in range(1, Y.shape[1])]
-    return scan_interaction_many(crms, G)
+    return scan_interaction_many(crms, G, cis_index=cis_index)
 
 
 def lrt_pvalues(null_lml, alt_lmls, dof=1):

@@ -407,6 +407,50 @@ def test_many_phenotypes_against_the_oracle(genotypes):
         _assert_fit_info_matches({k: v[i] for k, v in info2.items()}, oinfo, pv2[i], opv)
 
 
+@pytest.mark.parametrize("genotypes", ["dense", "donor-collapsed"])
+def test_cis_windows_of_many_phenotypes_against_the_oracle(genotypes):
+    """An eQTL-shaped run: every phenotype is tested against its own cis window of one resident panel
+    (``scan_interaction_many(Y, G, cis_index)``); each result must be what the reference's
+    per-gene call on ``G[:, window]`` gives (cellregmap/_cellregmap.py:547-587) -- checked against the oracle."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, run_interaction_many, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    c = make_cohort(8, 25, 4, 60, seed=47)
+    n, p = c.G.shape
+    rng = np.random.default_rng(5)
+    Y = np.stack([c.y, c.y[rng.permutation(n)], rng.normal(size=n), c.y + rng.normal(size=n), 1.0 - c.y,
+                  rng.normal(size=n)], axis=1)
+    G = c.G if genotypes == "donor-collapsed" else c.G + 0.05 * rng.normal(size=c.G.shape)
+    mask = np.zeros(p, bool)
+    mask[[0, 1, 2, 30, 31, 59]] = True
+    cis = [(0, 25), slice(10, 45), mask, np.array([50, 12, 12, -1, 3]), np.array([], dtype=int), (40, 60)]
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(Y[:, 0], c.E, W=c.W, Ls=Ls)
+    crms = [first] + [CellRegMap(Y[:, i], c.E, W=c.W, Ls=Ls, background=first._bg) for i in range(1, Y.shape[1])]
+    panel = GenotypePanel(G)
+    oLs = ocrm.khatri_rao_halves(c.hK, c.E)
+    idx_G = rng.permutation(n)
+    for hooks in ({}, {"idx_G": idx_G}):
+        pv, info = scan_interaction_many(crms, panel, cis_index=cis, **hooks)
+        assert len(pv) == len(cis) and pv[4].size == 0
+        for i, sel in enumerate(cis):
+            cols = np.arange(p)[sel] if isinstance(sel, slice) else (np.arange(*sel) if isinstance(sel, tuple) else sel)
+            Gi = G[:, cols]
+            assert pv[i].shape == (Gi.shape[1],)
+            if Gi.shape[1] == 0:
+                continue
+            opv, oinfo = ocrm.OracleCellRegMap(Y[:, i], c.E, W=c.W, Ls=oLs).scan_interaction(Gi, **hooks)
+            _assert_fit_info_matches({k: v[i] for k, v in info.items()}, oinfo, pv[i], opv)
+            # and what the same object gives when it scans its window alone (other launch shapes: same tolerance)
+            dpv, _ = scan_interaction_many([crms[i]], panel, cis_index=[sel], **hooks)
+            assert_allclose(dpv[0], pv[i], rtol=P_RTOL, atol=P_ATOL)
+    pv2, _ = run_interaction_many(Y, c.E, G, W=c.W, hK=c.hK, cis_index=cis)
+    pv_plain, _ = scan_interaction_many(crms, panel, cis_index=cis)
+    for i in range(len(cis)):
+        assert np.array_equal(pv2[i], pv_plain[i])
+
+
 def test_many_phenotypes_must_share_covariates_and_contexts_by_content():
     """Same shapes are not enough: the shared pass takes g'W and the context features from the first
     object (advisor finding, round 1)."""
