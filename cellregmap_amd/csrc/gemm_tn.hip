@@ -264,7 +264,10 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
 int split_for(long cells_pad, long blocks_without_split) {
     // enough workgroups to cover the 256 CUs twice, at least eight stages per slice, every slice non-empty
     const long stages = cells_pad / GEMM_BK;
-    long want = (512 + blocks_without_split - 1) / std::max<long>(blocks_without_split, 1);
+    // (long contractions: four rounds' worth, which also moves the launch onto the 128-wide LDS-DMA tiles -- measured
+    // +2 % on a mode-B step at config 3; nothing to gain at 5 000 cells)
+    const long target = cells_pad >= 16384 ? 1024 : 512;
+    long want = (target + blocks_without_split - 1) / std::max<long>(blocks_without_split, 1);
     want = std::min<long>(std::min<long>(want, 64), std::max<long>(stages / 8, 1));
     if (want <= 1) return 1;
     const long per = (stages + want - 1) / want;

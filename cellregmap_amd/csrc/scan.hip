@@ -805,9 +805,15 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* dZ1 = ctx->ws_Z.as<double>();
     double* dZ2 = dZ1 + z1_sz * ks1;
     double* dZ3 = dZ2 + z2_sz * ks2;
+    // H'G of step 3: few output tiles (cols x block) against a long contraction (cells) -- slices along the cell axis
+    // until the launch fills the chip twice with 128-wide tiles (mode B at config 3: 64 tiles, cfg3 mode C: 320)
+    int ks_h = 1;
+    const long th_slab = (long)bg->ldh * ldb;
     if (bg->fast_T) {
-        CRM_TRY(ctx->ws_TH.ensure(sizeof(double) * (size_t)bg->ldh * ldb));
-        CRM_HIP(hipMemsetAsync(ctx->ws_TH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ldb, st));
+        const long tiles_h = (long)((bg->cols + GEMM_BM - 1) / GEMM_BM) * ((BLK + 127) / 128);
+        while (tiles_h * ks_h < 1024 && ks_h < 16 && np / GEMM_BK / (ks_h + 1) >= 16) ks_h++;
+        CRM_TRY(ctx->ws_TH.ensure(sizeof(double) * (size_t)th_slab * ks_h));
+        CRM_HIP(hipMemsetAsync(ctx->ws_TH.ptr, 0, sizeof(double) * (size_t)th_slab, st));
     }
     CRM_TRY(ctx->ws_F.ensure(sizeof(double) * (size_t)BLK * k0 * k0));
     CRM_TRY(ctx->ws_Gext.ensure(sizeof(double) * (size_t)BLK * KT * KT));
@@ -955,7 +961,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
             p.C = ctx->ws_TH.as<double>(); p.ldc = ldb; p.M = (int)bg->cols; p.N = nb;
             CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)bg->cols, nb, np, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)bg->cols, nb, np, false, 0, ks_h, th_slab));
+            CRM_TRY(launch_reduce_splits(st, ctx->ws_TH.as<double>(), (long)bg->cols * ldb, ks_h, th_slab));
         }
         for (int i = 0; i < nrho; i++) {
             GemmProblem p{};
