@@ -17,6 +17,9 @@ Legs of one run (one JSON line on rank 0):
                         scan-only and end-to-end (constructor + upload + scan + gather) rates
   config4               64 phenotypes against one panel, variants sharded (BASELINE config 4's shape)
   donor_collapsed, cpu_baseline (N = 1)
+
+CRM_BENCH_SHARE_GPU=1 python bench.py --gpus 2 ...: dry run of the N > 1 code path on a box with ONE GPU (both ranks
+on device 0, gloo instead of RCCL; flagged in the line's "data" -- not a scaling measurement).
 """
 import argparse
 import ctypes
@@ -98,13 +101,19 @@ def main():
                          f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` directly)")
     import torch
 
+    share_gpu = bool(os.environ.get("CRM_BENCH_SHARE_GPU"))
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:   # dry run of the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -169,7 +178,8 @@ def main():
     bg_kw = {"Ls": Ls} if args.mode == "C" else {"hK": cohort.hK}
     if world > 1 or (dist is not None and os.environ.get("CRM_BENCH_FORCE_EXCHANGE")):
         bg = sharded_background(cohort.E, Ls if args.mode == "C" else cohort.hK, _engine._RHO_GRID, device=local_rank,
-                                force_exchange=world == 1)
+                                force_exchange=world == 1,
+                                tensor_device=torch.device("cuda", 0) if share_gpu else None)
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, background=bg, **bg_kw)
     else:
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)
@@ -424,6 +434,8 @@ def main():
         "config4": config4,
         "donor_collapsed": collapsed,
     }
+    if share_gpu:
+        out["data"] = "synthetic; DRY RUN: all ranks share GPU 0 (CRM_BENCH_SHARE_GPU, gloo) -- exercises the N > 1 code path, not a scaling number"
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
