@@ -103,6 +103,10 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
                 b.export_slot(i, what, buf)
             src = owner if group is None else dist.get_global_rank(group, owner)
             dist.broadcast(buf, src=src, group=group)
+            if buf.is_cuda:
+                # RCCL returns once the broadcast is queued on its stream; the library copies on its own stream, and
+                # the owner's next export reuses this buffer: wait for the collective itself
+                torch.cuda.current_stream(buf.device).synchronize()
             if owner != rank or force_exchange:
                 b.import_slot(i, what, buf)
         del buf
