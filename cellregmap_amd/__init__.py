@@ -13,6 +13,7 @@ from ._engine import (
     estimate_betas,
     get_L_values,
     lrt_pvalues,
+    release_workspaces,
     run_association,
     run_association_fast,
     run_interaction,
@@ -45,5 +46,6 @@ __all__ = [
     "estimate_betas",
     "get_L_values",
     "lrt_pvalues",
+    "release_workspaces",
     "Term",
 ]

@@ -32,6 +32,12 @@ def _context(device=0):
     return _contexts[device]
 
 
+def release_workspaces(device=0):
+    """Hand the cached device work buffers of ``device``'s context back (the constructor keeps its eigen-solver
+    workspace between calls; it is released on its own when memory runs short)."""
+    _lib.check(_lib.load().crm_ctx_trim(_context(device)))
+
+
 def _economic_svd(X):
     """Thin SVD with singular values < sqrt(eps) dropped (numpy_sugar.economic_svd,
     used at _cellregmap.py:540)."""

@@ -23,6 +23,7 @@ SIGNATURES = {
     "crm_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
     "crm_ctx_destroy": (None, [vp]),
     "crm_ctx_synchronize": (ctypes.c_int, [vp]),
+    "crm_ctx_trim": (ctypes.c_int, [vp]),
     "crm_background_create_qs": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp, vp, vp,
                                                 ctypes.POINTER(vp)]),
     "crm_background_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long,

@@ -1,9 +1,12 @@
 // Context, error text, device-buffer helpers and the contraction test hooks of the C-ABI.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <mutex>
 
 #include "crm_internal.h"
+#include "eigh.h"
 
 namespace crm {
 
@@ -57,9 +60,33 @@ int DevBuf::ensure(size_t need) {
         ptr = nullptr;
         bytes = 0;
     }
-    CRM_HIP(hipMalloc(&ptr, need));
+    hipError_t e = hipMalloc(&ptr, need);
+    if (e == hipErrorOutOfMemory && trim_idle_workspaces() > 0) {
+        (void)hipGetLastError();
+        e = hipMalloc(&ptr, need);
+    }
+    if (e != hipSuccess) ptr = nullptr;
+    CRM_HIP(e);
     bytes = need;
     return CRM_OK;
+}
+
+static std::mutex g_ctx_mutex;
+static std::vector<crm_ctx*> g_contexts;
+
+static size_t trim_context(crm_ctx* c) {
+    if (!c->eigh_ws || c->eigh_ws_busy) return 0;
+    size_t freed = 0;
+    for (const DevBuf* b : {&c->eigh_ws->A, &c->eigh_ws->Vt, &c->eigh_ws->Vc, &c->eigh_ws->QA, &c->eigh_ws->QB}) freed += b->bytes;
+    eigh_free(*c->eigh_ws);
+    return freed;
+}
+
+size_t trim_idle_workspaces() {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    size_t freed = 0;
+    for (crm_ctx* c : g_contexts) freed += trim_context(c);
+    return freed;
 }
 void DevBuf::release() {
     if (ptr) (void)hipFree(ptr);
@@ -106,7 +133,20 @@ int crm_ctx_create(int device, crm_ctx** out) {
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_contexts.push_back(c);
+    }
     *out = c;
+    return CRM_OK;
+}
+
+int crm_ctx_trim(crm_ctx* c) {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    (void)trim_context(c);
     return CRM_OK;
 }
 
@@ -114,6 +154,15 @@ void crm_ctx_destroy(crm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), c), g_contexts.end());
+        if (c->eigh_ws) {
+            eigh_free(*c->eigh_ws);
+            delete c->eigh_ws;
+            c->eigh_ws = nullptr;
+        }
+    }
     for (auto* b : c->all_bufs()) b->release();
     for (auto& e : c->timed) {
         (void)hipEventDestroy(e.first);

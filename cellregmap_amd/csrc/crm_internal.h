@@ -35,6 +35,11 @@ struct ScopedBuf : DevBuf {
 int upload_padded(hipStream_t st, double* dst, long ld_dst, long rows_pad, const double* src,
                   long ld_src, long rows, long cols);
 
+struct EighWork;
+// Release the idle cached workspaces of every context (the eigen-solver's); returns the bytes handed back.
+// DevBuf::ensure calls it once before giving up on an allocation.
+size_t trim_idle_workspaces();
+
 }  // namespace crm
 
 struct crm_ctx {
@@ -49,6 +54,12 @@ struct crm_ctx {
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     crm::GemmTune tune;   // contraction kernel variant (test hooks only change it)
     crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form
+    // Work buffers of the constructor's eigen-solver, kept between constructor calls: handing 45 GB (config 5: five slabs
+    // of 11 x 10 050^2) back to the driver costs 1.3 s per call and mapping them again up to as much; per-SNP
+    // backgrounds of the effect-size path call the constructor once per variant.  Released by crm_ctx_trim,
+    // crm_ctx_destroy, or when another allocation would otherwise fail.
+    crm::EighWork* eigh_ws = nullptr;
+    bool eigh_ws_busy = false;
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;

@@ -40,6 +40,10 @@ int crm_ctx_create(int device, crm_ctx** out);
 void crm_ctx_destroy(crm_ctx* ctx);
 /* Block until all work queued on the context's stream has finished. */
 int crm_ctx_synchronize(crm_ctx* ctx);
+/* Hand the context's cached work buffers back to the device (the constructor's eigen-solver keeps its
+ * workspace between calls -- up to five matrices per owned grid point; it is also released on its own when another
+ * allocation of this library would otherwise run out of memory). */
+int crm_ctx_trim(crm_ctx* ctx);
 
 /* ---- background covariance: replaces CellRegMap.__init__'s rho loop ---------------
  * (_cellregmap.py:101-131 + numpy_sugar.economic_qs_linear, twin _math.py:238-256).

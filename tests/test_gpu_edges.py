@@ -226,3 +226,26 @@ def test_null_p_values_are_not_inflated():
     assert np.mean(pv < 0.05) < 0.075 and np.mean(pv < 0.01) < 0.02
     assert np.median(pv) > 0.3
     assert pv.min() > 0.01 / pv.size      # nothing a Bonferroni threshold at 1 % would call
+
+
+def test_cached_eigen_workspace_is_reused_and_can_be_released():
+    """The constructor keeps its eigen-solver workspace in the context between calls (crm_ctx_trim releases it):
+    a larger problem, a smaller one on the cached buffers, a release, and the first again -- bit-identical spectra."""
+    import cellregmap_amd as crm
+    from cellregmap_amd import _engine
+    from cellregmap_amd.synth import make_cohort
+
+    def spectra(c):
+        _engine._bg_cache.clear()
+        obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E))
+        return [obj._bg.read(i, c.y.size)[1] for i in range(11)]
+
+    big, small = make_cohort(10, 30, 6, 8, seed=2), make_cohort(5, 12, 3, 8, seed=3)
+    first = spectra(big)
+    on_cached = spectra(small)
+    crm.release_workspaces()
+    crm.release_workspaces()                      # idempotent
+    for a, b in zip(spectra(small), on_cached):
+        assert np.array_equal(a, b)
+    for a, b in zip(spectra(big), first):
+        assert np.array_equal(a, b)
