@@ -187,6 +187,183 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     }
 }
 
+// The same Gram with the operand rows brought in by direct-to-LDS loads (global_load_lds_dwordx4), for 16 NTL rows
+// with NTL even.  The staged kernel above spends a third of its issue slots on the way into LDS -- per chunk and
+// thread sixteen 8-byte loads with 64-bit address arithmetic, a square root and a division for sqrt(d_j), sixteen
+// products and sixteen ds_write -- none of which can overlap an FP64 MFMA, and two barriers per chunk.  Here a
+// wave-instruction carries two rows of a chunk (lanes 0-31 row q, lanes 32-63 row q + ROWS/2, 64 columns each) straight
+// into LDS, two buffers deep, one barrier per chunk; the spectrum weights go in as d_j (not sqrt d_j) on ONE operand,
+// a product per fragment read:  S S' = sum_j a_ij d_j a_i'j.  LDS image: instruction q at q * 130 doubles (its two
+// rows 64 doubles apart), so the sixteen rows of a fragment read start two 8-byte slots apart -- conflict-free like the
+// 66-double rows of the staged kernel.  A last, partial chunk is loaded through registers with per-element guards.
+typedef const double __attribute__((address_space(1))) * gram_gptr_t;
+typedef __attribute__((address_space(3))) void* gram_lptr_t;
+
+// (a __device__ function: the builtin does not exist in the host pass, which would drop the kernel's host stub)
+__device__ __forceinline__ void gram_dma16(gram_gptr_t src, double* lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds(src, (gram_lptr_t)lds_wave_uniform, 16, 0, 0);
+}
+
+template <int NTL>
+__global__ __launch_bounds__(256) void gram_ext_dma_kernel(AssembleArgs a, double* __restrict__ Gext, int KT) {
+    static_assert(NTL % 2 == 0, "row pairs of one DMA instruction must fall into different 16-row tiles");
+    constexpr int ROWS = 16 * NTL, HALF = ROWS / 2, NTILES = NTL * (NTL + 1) / 2;
+    constexpr int QLD = 130;                 // doubles per DMA instruction slot (2 x 64 + 2 of padding)
+    constexpr int BUF = HALF * QLD;          // doubles per chunk buffer
+    constexpr int IPW = HALF / 4;            // DMA instructions per wavefront and chunk
+    constexpr int KSW = CH / 16;             // k-steps per wavefront and chunk (the four wavefronts split the chunk's columns)
+    static_assert(2 * BUF >= 2 * NTILES * 256, "the accumulators of two wavefronts must fit the chunk buffers");
+    extern __shared__ double Ss[];           // [2][BUF] + d [2][64]
+    double* const dS = Ss + 2 * BUF;
+    const int b = blockIdx.x;
+    const NullFitOut fit = a.fit[b];
+    const AssembleRho R = a.rho[fit.rho_index];
+    const int r = R.r;
+    const double ratio = fit.v0 / fit.v1;
+    const long pos = a.sorted_pos[b];
+    const double* __restrict__ Arows = a.A + pos * a.k0 * a.ldA;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int k0 = a.k0, c = a.c;
+
+    // row -> pointer (rows past KT read row 0: their outputs are never stored)
+    auto row_ptr = [&](int row) -> const double* {
+        if (row >= KT) row = 0;
+        if (row < k0) return Arows + (long)row * a.ldA;
+        const int t = row - k0;
+        return t < c ? R.tW + (long)t * R.ldW : (t == c ? R.T + (long)b * R.ldT : R.ty);
+    };
+    auto row_off = [](int row) { return row < HALF ? row * QLD : (row - HALF) * QLD + 64; };
+    // this lane's source addresses (column pair 2 * (lane & 31) of the row its half-wave carries)
+    gram_gptr_t src[IPW];
+#pragma unroll
+    for (int q = 0; q < IPW; q++) {
+        const int inst = wave + 4 * q;
+        src[q] = (gram_gptr_t)(row_ptr(inst + (lane >> 5) * HALF) + 2 * (lane & 31));
+    }
+    // Every wavefront accumulates ALL upper-triangle tiles over its quarter of the columns of each chunk (an even
+    // split whatever the tile count; the fragment of a 16-row block serves as the A operand and, times d_j, as the B
+    // operand of every tile that touches the block: NTL reads and NTL products per k-step for NTILES MFMAs); the four
+    // partial sums meet through LDS once per variant, in a fixed order.
+    int f_off[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; t++) f_off[t] = row_off(16 * t + l15) + 4 * KSW * wave + lq;
+    v4d acc[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int nfull = r / CH, nchunks = (r + CH - 1) / CH;
+    auto weights = [&](int ch, int buf) __attribute__((always_inline)) {   // d_j of chunk ch (wavefront 0)
+        if (wave == 0) {
+            const int j = ch * CH + lane;
+            double d = 0.0;
+            if (j < r) {
+                const double s = ratio * R.S0[j];
+                d = s / (1.0 + s);
+            }
+            dS[buf * CH + lane] = d;
+        }
+    };
+    auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
+        if (ch < nfull) {
+#pragma unroll
+            for (int q = 0; q < IPW; q++)
+                gram_dma16(src[q] + (long)ch * CH, Ss + buf * BUF + (wave + 4 * q) * QLD);
+        } else {   // the partial chunk: guarded element loads, zeros past r
+            for (int e = tid; e < ROWS * CH; e += 256) {
+                const int row = e / CH, col = e - row * CH;
+                const int j = ch * CH + col;
+                Ss[buf * BUF + row_off(row) + col] = (j < r && row < KT) ? row_ptr(row)[j] : 0.0;
+            }
+        }
+    };
+    auto chunk_mma = [&](int buf) __attribute__((always_inline)) {
+        const double* __restrict__ S = Ss + buf * BUF;
+        const double* __restrict__ D = dS + buf * CH + 4 * KSW * wave + lq;
+        double fa[2][NTL], fb[2][NTL];
+        {
+            const double dk = D[0];
+#pragma unroll
+            for (int t = 0; t < NTL; t++) {
+                fa[0][t] = S[f_off[t]];
+                fb[0][t] = fa[0][t] * dk;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSW; ks++) {
+            const int cur = ks & 1, nx = cur ^ 1;
+            if (ks + 1 < KSW) {
+                const double dk = D[4 * (ks + 1)];
+#pragma unroll
+                for (int t = 0; t < NTL; t++) {
+                    fa[nx][t] = S[f_off[t] + 4 * (ks + 1)];
+                    fb[nx][t] = fa[nx][t] * dk;
+                }
+            }
+            int idx = 0;
+#pragma unroll
+            for (int ti = 0; ti < NTL; ti++)
+#pragma unroll
+                for (int tj = ti; tj < NTL; tj++, idx++)
+                    acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][ti], fb[cur][tj], acc[idx], 0, 0, 0);
+        }
+    };
+    issue(0, 0);
+    weights(0, 0);
+    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) precedes the barrier)
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) {
+            issue(ch + 1, buf ^ 1);
+            weights(ch + 1, buf ^ 1);
+        }
+        chunk_mma(buf);
+        __syncthreads();
+    }
+    // (wave 0 + wave 2) + (wave 1 + wave 3): two exchanges through the chunk buffers
+    double* const red = Ss + (wave & 1) * NTILES * 256;
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < NTILES; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) red[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < NTILES; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) acc[t][reg] += red[(t * 4 + reg) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < NTILES; t++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) red[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double* __restrict__ out = Gext + (long)b * KT * KT;
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < NTL; ti++) {
+#pragma unroll
+        for (int tj = ti; tj < NTL; tj++, idx++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const double v = acc[idx][reg] + (Ss + NTILES * 256)[(idx * 4 + reg) * 64 + lane];
+                const int row = 16 * ti + lq + 4 * reg, col = 16 * tj + l15;
+                if (row < KT && col < KT) {
+                    out[(long)row * KT + col] = v;
+                    if (ti != tj) out[(long)col * KT + row] = v;
+                }
+            }
+        }
+    }
+}
+
 constexpr int PMAX = CRM_MAX_COV_WIDE + 1;
 
 __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const double* __restrict__ Gext,
@@ -322,6 +499,27 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
         return CRM_ERR_UNSUPPORTED;
     }
     const int ts = (KT + 15) / 16;
+    // LDS-DMA form: 16-byte loads, so every row must start on a 16-byte boundary and hold an even number of doubles
+    bool dma = ts <= 4 && a.ldA % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && !getenv("CRM_GRAM_STAGED");
+    for (int i = 0; dma && i < CRM_MAX_RHO; i++) {
+        const AssembleRho& R = a.rho[i];
+        if (R.r <= 0 && !R.ty) continue;
+        dma = R.ldW % 2 == 0 && R.ldT % 2 == 0 && ((reinterpret_cast<uintptr_t>(R.ty) | reinterpret_cast<uintptr_t>(R.tW) |
+                                                    reinterpret_cast<uintptr_t>(R.T)) & 15) == 0;
+    }
+#define CRM_GRAM_DMA(NTL)                                                                                     \
+    do {                                                                                                      \
+        const size_t lds = sizeof(double) * (2 * (16 * NTL / 2) * 130 + 2 * CH);                              \
+        if (lds > 60 * 1024)                                                                                  \
+            CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_ext_dma_kernel<NTL>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(gram_ext_dma_kernel<NTL>, dim3(variants), dim3(256), lds, st, a, Gext, KT);        \
+    } while (0)
+    if (dma) {
+        if (ts <= 2) CRM_GRAM_DMA(2);
+        else CRM_GRAM_DMA(4);   // (k0 + c + 2 > 64: 21 tiles per wavefront would leave one wavefront per SIMD -- staged kernel)
+    }
+#undef CRM_GRAM_DMA
 #define CRM_GRAM(NTL)                                                                                         \
     do {                                                                                                      \
         const size_t lds = sizeof(double) * 16 * NTL * SLD;                                                   \
@@ -330,7 +528,8 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         hipLaunchKernelGGL(gram_ext_kernel<NTL>, dim3(variants), dim3(256), lds, st, a, Gext, KT);            \
     } while (0)
-    if (ts <= 2) CRM_GRAM(2);
+    if (dma) {
+    } else if (ts <= 2) CRM_GRAM(2);
     else if (ts <= 4) CRM_GRAM(4);
     else if (ts <= 6) CRM_GRAM(6);
     else CRM_GRAM(9);

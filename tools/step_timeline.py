@@ -1,6 +1,6 @@
 """Kernel timeline of the last scan steps in a rocprofv3 rocpd database: per kernel name the time inside the
 window, and the idle time of the device between consecutive kernels.
-    python tools/step_timeline.py db [window_ms 100]"""
+    python tools/step_timeline.py db [window_ms 100] [list kernels >= min_us] [skip the last ms]"""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -8,8 +8,9 @@ from collections import defaultdict
 con = sqlite3.connect(sys.argv[1])
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-t_end = max(r[2] for r in rows)
-rows = [r for r in rows if r[1] >= t_end - win * 1e6]
+skip = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+t_end = max(r[2] for r in rows) - skip * 1e6
+rows = [r for r in rows if t_end - win * 1e6 <= r[1] <= t_end]
 busy = defaultdict(float)
 calls = defaultdict(int)
 gap_after = defaultdict(float)
