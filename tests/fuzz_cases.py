@@ -52,6 +52,21 @@ def fuzz_cases(count, seed=7, max_cells=600, max_contexts=128, max_variants=70, 
         # the oracle can land in different basins); not a parity case.
         if mode == "A" and k0 >= n:
             continue
+        # The same in modes B and C: once the background's columns and the fixed effects [W, g] together span
+        # all n cells (cols + c + 1 >= n) the model is saturated -- the residual outside span(Q0) has no degrees
+        # of freedom left, the profiled likelihood grows without bound as delta -> 0 and where a finite-precision
+        # search stops is decided by rounding (seed 2026 of tools/fuzz_scan.py: n = 43 with 42-rank Q0 and 9
+        # fixed effects -- device delta 4e-14 / lml 237, oracle delta 0.92 / lml -60).  Not a parity case either.
+        cols = k0 if mode == "A" else (k0 + donors if mode == "B" else k0 + k0 * donors)
+        if cols + c + 1 >= n:
+            continue
+        # Mode B with two donors: the genotype is constant within a donor, so span(1, g) IS the span of the two donor
+        # indicators -- at rho = 0 the whole random effect hK hK' is absorbed by the fixed effects and the restricted
+        # likelihood does not depend on delta at all (flat to 1e-12 over delta in [1e-9, 0.99]).  Brent then walks
+        # to delta ~ 1e-13, where the complement terms' rounding noise divided by delta is O(1) in the likelihood
+        # and decides which "optimum" is reported (seed 2026: device -61.2, oracle -66.4 at the same delta).
+        if mode == "B" and donors <= 2:
+            continue
         out.append((i - 1, n, k0, c, p, donors, mode, perm))
     return out
 

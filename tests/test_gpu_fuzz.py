@@ -28,9 +28,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P_ATOL = 1e-13
 
 
-def _run(polish):
+def _run(polish, count=150, seed=None):
+    """``count`` / ``seed``: tools/fuzz_scan.py runs larger samples from other streams through the same code."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
     from oracle.crm import OracleCellRegMap
+
+    if seed is None:
+        seed = 7 if not polish else 8
 
     lib = _lib.load()
     ctx = _engine._context(0)
@@ -38,7 +42,7 @@ def _run(polish):
     rows = []   # per (variant, path): rel dQ, rel dp, abs dp, rel dlml, same rho
     skipped = 0
     try:
-        for case in fuzz_cases(150, seed=7 if not polish else 8, wide_covariates=not polish):
+        for case in fuzz_cases(count, seed=seed, wide_covariates=not polish):
             y, E, W, G, kw, hooks = build_case(case)
             try:
                 opv, oinfo, ost = OracleCellRegMap(y, E, W=W, polish=polish, **kw).scan_interaction(
@@ -61,7 +65,7 @@ def _run(polish):
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
     a = np.array(rows, float)   # columns: rel dQ, rel dp, |dp|, rel dlml, same rho*, oracle p
     same = a[:, 4] > 0
-    s = {"procedure": "polished" if polish else "verbatim", "problems": 150 - skipped, "oracle_raised": skipped,
+    s = {"procedure": "polished" if polish else "verbatim", "problems": count - skipped, "seed": seed, "oracle_raised": skipped,
          "variant_scans": int(a.shape[0]), "rho_star_differs": int((~same).sum()),
          "worst_rel_lml_where_rho_differs": float(a[~same, 3].max()) if (~same).any() else 0.0,
          "worst_rel_Q": float(a[same, 0].max()), "median_rel_Q": float(np.median(a[same, 0])),
