@@ -249,3 +249,26 @@ def test_cached_eigen_workspace_is_reused_and_can_be_released():
         assert np.array_equal(a, b)
     for a, b in zip(spectra(big), first):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(8, 30, 5, 40), (6, 40, 37, 24), (10, 20, 60, 12)])
+def test_gram_kernel_forms_agree(shape, monkeypatch):
+    """The score-statistic Gram through direct-to-LDS loads (default for k0 + c + 2 <= 64) against the register-staged
+    kernel (CRM_GRAM_STAGED=1; also what wider problems and unaligned rows use): same Q and F to rounding.  The shapes
+    cover 2 and 4 row blocks, spectra that are not multiples of the 64-column chunk, and one (k0 = 60) that only the
+    staged kernel serves."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+
+    donors, cells, k, p = shape
+    c = make_cohort(donors, cells, k, p, seed=17)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    panel = crm.GenotypePanel(c.G, groups=None)
+    pv, _, st = obj.scan_interaction(panel, return_stats=True)
+    monkeypatch.setenv("CRM_GRAM_STAGED", "1")
+    pv2, _, st2 = obj.scan_interaction(panel, return_stats=True)
+    scale = np.maximum(np.abs(st2["Q"]), np.trace(st2["F"], axis1=1, axis2=2))
+    assert np.all(np.abs(st["Q"] - st2["Q"]) <= 1e-11 * scale)
+    fs = np.abs(st2["F"]).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(st["F"] - st2["F"]) <= 1e-11 * fs)
+    assert np.all(np.abs(pv - pv2) <= 1e-6 * pv2 + 1e-13)
