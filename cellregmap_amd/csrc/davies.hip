@@ -386,6 +386,9 @@ __device__ double liu_mod_sf(const double* lb, int r, double t, int lane) {
 
 // ---- the kernel ------------------------------------------------------------------------------
 // LDS: A [k][ks] (ks = k | 1), ev [k], kept [k], tridiagonal + Householder scratch
+#ifdef CRM_DAVIES_WAVES
+__attribute__((amdgpu_waves_per_eu(CRM_DAVIES_WAVES, CRM_DAVIES_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict__ Fall,
                                                          const double* __restrict__ Qall, int k,
                                                          double* __restrict__ lambda_out,

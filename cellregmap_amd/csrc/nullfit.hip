@@ -118,6 +118,9 @@ __device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
 }
 
 template <int C>
+#ifdef CRM_NULLFIT_WAVES
+__attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
     constexpr int P = C + 1;  // columns of X = [W, g]
     constexpr int U = C + 2;  // ... plus y
