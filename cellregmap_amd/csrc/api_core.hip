@@ -82,6 +82,18 @@ static size_t trim_context(crm_ctx* c) {
     return freed;
 }
 
+EighWork* acquire_eigh_workspace(crm_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (!c->eigh_ws) c->eigh_ws = new EighWork();
+    c->eigh_ws_busy = true;
+    return c->eigh_ws;
+}
+
+void release_eigh_workspace(crm_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    c->eigh_ws_busy = false;
+}
+
 size_t trim_idle_workspaces() {
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     size_t freed = 0;

@@ -315,10 +315,8 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
     const int nmine = (int)bb->mine.size();
     if (nmine > 0) {
         // the context's cached work buffers (grown on demand; see crm_ctx::eigh_ws)
-        if (!ctx->eigh_ws) ctx->eigh_ws = new EighWork();
-        EighWork& ew = *ctx->eigh_ws;
-        ctx->eigh_ws_busy = true;
-        struct EGuard { crm_ctx* c; ~EGuard() { c->eigh_ws_busy = false; } } eguard{ctx};
+        EighWork& ew = *acquire_eigh_workspace(ctx);
+        struct EGuard { crm_ctx* c; ~EGuard() { release_eigh_workspace(c); } } eguard{ctx};
         CRM_BG(eigh_alloc(ew, nmine, dim));
         trace.lap("  eigen workspace");
         CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nmine * ew.slab, st));

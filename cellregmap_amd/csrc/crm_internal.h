@@ -39,6 +39,13 @@ struct EighWork;
 // Release the idle cached workspaces of every context (the eigen-solver's); returns the bytes handed back.
 // DevBuf::ensure calls it once before giving up on an allocation.
 size_t trim_idle_workspaces();
+}  // namespace crm
+struct crm_ctx;
+namespace crm {
+// The context's cached eigen-solver workspace, marked busy / idle under the same lock the trimming takes (a context that
+// runs out of memory on one thread must not free the buffers another thread's constructor has just picked up).
+EighWork* acquire_eigh_workspace(crm_ctx* ctx);
+void release_eigh_workspace(crm_ctx* ctx);
 
 }  // namespace crm
 
