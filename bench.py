@@ -311,7 +311,9 @@ def main():
     achieved = kr_fl.value / kr_s * 1e-12 if kr_s > 0 else 0.0
     roofline = {
         "bound": "mfma", "kernel": "gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
-                                   "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel)",
+                                   "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
+                                   "+ gemm_tn_glds_kernel<true, KRQ, ECQ, false, 160> over the last 128 + r mod 128 columns when r mod 128 <= 32 "
+                                   "(cfg3: 38 x 128 + 136 of r = 5000); achieved / avg_launch_ms cover both launches of a block",
         "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
         "launches": int(kr_n.value), "avg_launch_ms": round(kr_ms.value / max(kr_n.value, 1), 3),

@@ -139,7 +139,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     crm_ctx* c = new crm_ctx();
     c->device = device;
     // tuning knob: large Khatri-Rao launches run as persistent workgroups that re-align per XCD every k generations
-    // (default k = 1: 7.5x less L2-fabric traffic for 0.65 % of the kernel's time);
+    // (default k = 1: 7.3x less L2-fabric traffic for 0.6 % of the kernel's time);
     // CRM_CONTRACTION_SYNC=0 restores one workgroup per tile
     if (const char* e = getenv("CRM_CONTRACTION_SYNC")) c->tune.sync = atoi(e) > 0 ? atoi(e) : 0;
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

@@ -83,7 +83,7 @@ struct GemmTune {
     int bn = 0;         // output-tile width: 0 = chosen per launch, else 64 or 128
     int glds = 1;       // 128-wide tiles / Khatri-Rao launches through the LDS-DMA kernel (gemm_tn_glds.hip)
     int sync = 1;       // > 0: large Khatri-Rao launches as 8 x 64 persistent workgroups re-aligned every `sync` generations
-                        // (default: 7.5x less L2-fabric traffic, L2 hit rate 66 % -> 96 %, for 0.65 % of the kernel's time)
+                        // (default: 7.3x less L2-fabric traffic, L2 hit rate 67 % -> 96 %, for 0.6 % of the kernel's time)
     int shared_h = -1;  // multi-gene scan: -1 cost model, 0 never, 1 always contract once per variant against H
 };
 int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n,
@@ -99,5 +99,7 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
 int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0);
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
+int launch_reduce_splits_band(hipStream_t st, double* C, long rows, long ld, int col0, int ncols, int ksplit,
+                              long split_stride);
 
 }  // namespace crm

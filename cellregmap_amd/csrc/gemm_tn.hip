@@ -261,6 +261,19 @@ __global__ void reduce_splits_kernel(double* __restrict__ C, long count, int ksp
     C[i] = s;
 }
 
+// the same for a band of columns [col0, col0 + ncols) of a row-major matrix with leading dimension ld
+__global__ void reduce_splits_band_kernel(double* __restrict__ C, long rows, long ld, int col0, int ncols, int ksplit,
+                                          long stride) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ncols) return;
+    const long row = i / ncols;
+    const int col = (int)(i - row * ncols);
+    double* p = C + row * ld + col0 + col;
+    double s = *p;
+    for (int k = 1; k < ksplit; k++) s += p[k * stride];
+    *p = s;
+}
+
 int split_for(long cells_pad, long blocks_without_split) {
     // enough workgroups to cover the 256 CUs twice, at least eight stages per slice, every slice non-empty
     const long stages = cells_pad / GEMM_BK;
@@ -385,6 +398,15 @@ int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long
     if (ksplit <= 1 || count <= 0) return CRM_OK;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                        C, count, ksplit, split_stride);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_reduce_splits_band(hipStream_t st, double* C, long rows, long ld, int col0, int ncols, int ksplit,
+                              long split_stride) {
+    if (ksplit <= 1 || rows <= 0 || ncols <= 0) return CRM_OK;
+    hipLaunchKernelGGL(reduce_splits_band_kernel, dim3((unsigned)((rows * ncols + 255) / 256)), dim3(256), 0, st, C, rows,
+                       ld, col0, ncols, ksplit, split_stride);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

@@ -842,7 +842,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     int* d_if = (int*)(sm + o_if);
     double* d_liu = (double*)(sm + o_liu);
     double* d_part = (double*)(sm + o_part);
-    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
+    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
     const long slab = (long)(1 + c) * ldq;  // rotations of [y, W] per grid point
@@ -1056,6 +1056,39 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             (void)nzz;
             if (kr_split > 1) CRM_TRY(ctx->ws_A.ensure(sizeof(double) * a_slab * kr_split));
         }
+        // A spectrum a little longer than a multiple of the 128-column tile (config 3: r = 5000 = 39 tiles + 8 columns)
+        // would pay a whole last column of tiles -- 1 / 40 of the launch -- for those few columns: the last 128 + rem
+        // columns (rem <= 32) go into a second launch of 160-column tiles instead, cut along the cell axis to fill its
+        // rounds (38 x 128 + 160 = 5024 columns computed instead of 5120).
+        std::vector<GemmProblem> tails;
+        int tail_split = 1, tail_maxn = 0;
+        bool tail_of[CRM_MAX_RHO] = {false};
+        if (!collapsed && !via_H && kr_split == 1 && ctx->tune.glds && ctx->tune.bn != 64 && ctx->tune.bn != 160 &&
+            !getenv("CRM_KR_NO_TAIL")) {
+            long tail_row_tiles = 0, main_tiles = 0;
+            for (int i = 0; i < nrho; i++) {
+                if (cnt[i] == 0) continue;
+                const int N = bg->r[i], rem = N % 128;
+                const long rt = ((long)cnt[i] * k0 + GEMM_BM - 1) / GEMM_BM;
+                main_tiles += rt * ((N + 127) / 128);
+                if (N >= 1024 && rem > 0 && rem <= 32) {
+                    tail_of[i] = true;
+                    tail_row_tiles += rt;
+                    tail_maxn = std::max(tail_maxn, 128 + rem);
+                }
+            }
+            if (tail_row_tiles == 0 || main_tiles <= 1024) {
+                std::fill(tail_of, tail_of + CRM_MAX_RHO, false);
+            } else {
+                const int saved_bn = ctx->tune.bn;
+                ctx->tune.bn = 160;
+                const int cap = (int)std::min<size_t>(8, ((size_t)16 << 30) / std::max<size_t>(sizeof(double) * a_slab, 1));
+                tail_split = kr_split_for(ctx, tail_row_tiles, tail_maxn, 1, np, std::max(cap, 1));
+                ctx->tune.bn = saved_bn;
+                // (before the problem records take addresses inside ws_A: growing the buffer does not keep its contents)
+                if (tail_split > 1) CRM_TRY(ctx->ws_A.ensure(sizeof(double) * a_slab * tail_split));
+            }
+        }
         for (int i = 0; i < nrho; i++) {
             if (cnt[i] == 0) continue;
             GemmProblem p{};
@@ -1078,6 +1111,13 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.ldc = ldA;
                 p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
                 kr_flops += 2.0 * (double)n * (double)bg->r[i] * (double)k0 * (double)cnt[i];
+                if (tail_of[i]) {
+                    GemmProblem t = p;
+                    const int rem = 128 + p.N % 128;
+                    p.N -= rem;
+                    t.Y = p.Y + p.N; t.C = p.C + p.N; t.N = rem;
+                    tails.push_back(t);
+                }
             }
             max_m = std::max(max_m, p.M);
             max_n = std::max(max_n, p.N);
@@ -1114,6 +1154,15 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         else {
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, kr_split, (long)a_slab));
             CRM_TRY(launch_reduce_splits(st, ctx->ws_A.as<double>(), (long)npairs * k0 * ldA, kr_split, (long)a_slab));
+            if (!tails.empty()) {
+                const int saved_bn = ctx->tune.bn;
+                ctx->tune.bn = 160;
+                struct Restore { crm_ctx* c; int bn; ~Restore() { c->tune.bn = bn; } } restore{ctx, saved_bn};
+                CRM_HIP(hipMemcpyAsync(d_probs + nz, tails.data(), sizeof(GemmProblem) * tails.size(), hipMemcpyHostToDevice, st));
+                CRM_TRY(launch_gemm_tn(ctx, d_probs + nz, (int)tails.size(), max_m, tail_maxn, np, true, k0, tail_split, (long)a_slab));
+                for (const GemmProblem& t : tails)
+                    CRM_TRY(launch_reduce_splits_band(st, t.C, (long)t.M, t.ldc, 0, t.N, tail_split, (long)a_slab));
+            }
         }
         if (timing) {
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
