@@ -68,6 +68,7 @@ SIGNATURES = {
     "crm_kernel_timer_stop": (ctypes.c_int, [vp]),
     "crm_test_set_contraction": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
     "crm_test_set_shared_h": (ctypes.c_int, [vp, ctypes.c_int]),
+    "crm_test_tail_launches": (ctypes.c_long, [vp]),
     "crm_test_set_contraction_sync": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,
                                          ctypes.c_int]),

@@ -65,6 +65,7 @@ struct crm_ctx {
     // of 11 x 10 050^2) back to the driver costs 1.3 s per call and mapping them again up to as much; per-SNP
     // backgrounds of the effect-size path call the constructor once per variant.  Released by crm_ctx_trim,
     // crm_ctx_destroy, or when another allocation would otherwise fail.
+    long tail_launches = 0;   // blocks whose last columns took the 160-column-tile launch (crm_test_tail_launches)
     crm::EighWork* eigh_ws = nullptr;
     bool eigh_ws_busy = false;
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)

@@ -1160,6 +1160,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 struct Restore { crm_ctx* c; int bn; ~Restore() { c->tune.bn = bn; } } restore{ctx, saved_bn};
                 CRM_HIP(hipMemcpyAsync(d_probs + nz, tails.data(), sizeof(GemmProblem) * tails.size(), hipMemcpyHostToDevice, st));
                 CRM_TRY(launch_gemm_tn(ctx, d_probs + nz, (int)tails.size(), max_m, tail_maxn, np, true, k0, tail_split, (long)a_slab));
+                ctx->tail_launches++;
                 for (const GemmProblem& t : tails)
                     CRM_TRY(launch_reduce_splits_band(st, t.C, (long)t.M, t.ldc, 0, t.N, tail_split, (long)a_slab));
             }
@@ -1274,6 +1275,8 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
     std::vector<ScanOut> outs{o};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
 }
+
+long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
     if (!ctx) return CRM_ERR_ARG;

@@ -27,6 +27,9 @@ int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const d
  * pair against Q0(rho), 1 once per variant against H followed by Mix(rho) per pair (when the
  * background keeps H). */
 int crm_test_set_shared_h(crm_ctx* ctx, int mode);
+/* Number of Khatri-Rao blocks of this context's scans whose last columns went through the 160-column-tile launch
+ * (scan.hip: spectra with r mod 128 <= 32); tests use it to know which form they exercised. */
+long crm_test_tail_launches(const crm_ctx* ctx);
 /* The same product stored transposed: CT (N x (B*k0)). */
 int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                            const double* E, const double* Y, double* CT);

@@ -272,3 +272,39 @@ def test_gram_kernel_forms_agree(shape, monkeypatch):
     fs = np.abs(st2["F"]).max(axis=(1, 2), keepdims=True)
     assert np.all(np.abs(st["F"] - st2["F"]) <= 1e-11 * fs)
     assert np.all(np.abs(pv - pv2) <= 1e-6 * pv2 + 1e-13)
+
+
+def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(monkeypatch):
+    """r = 2064 = 16 x 128 + 16: the last 144 columns of the Khatri-Rao contraction go through a launch of 160-column tiles
+    (scan.hip; CRM_KR_NO_TAIL=1 keeps the single launch over seventeen columns of 128-column tiles).  Both forms must give the
+    same statistics to rounding, and the oracle's on a few variants."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    from cellregmap_amd import _engine, _lib
+
+    c = make_cohort(129, 17, 16, 2048, seed=23)         # rank 16 * 129 = 2064 = 16 x 128 + 16 (cols 2080) < n = 2193
+    rng = np.random.default_rng(1)
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes: the dense path
+    Ls = crm.get_L_values(c.hK, c.E)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+    assert max(obj._bg.rank(i) for i in range(11)) == 2064
+    lib, ctx = _lib.load(), _engine._context(0)
+    panel = crm.GenotypePanel(G, groups=None)
+    before = lib.crm_test_tail_launches(ctx)
+    pv, info, st = obj.scan_interaction(panel, return_stats=True)
+    used = lib.crm_test_tail_launches(ctx)
+    assert used > before                                  # the form under test ran ...
+    monkeypatch.setenv("CRM_KR_NO_TAIL", "1")
+    pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
+    monkeypatch.delenv("CRM_KR_NO_TAIL")
+    assert lib.crm_test_tail_launches(ctx) == used        # ... and the knob really switches it off
+    assert np.array_equal(info["rho1"], info1["rho1"])
+    scale = np.maximum(np.abs(st1["Q"]), np.trace(st1["F"], axis1=1, axis2=2))
+    assert np.all(np.abs(st["Q"] - st1["Q"]) <= 1e-11 * scale)
+    assert np.all(np.abs(st["F"] - st1["F"]) <= 1e-11 * np.abs(st1["F"]).max(axis=(1, 2), keepdims=True))
+    assert np.all(np.abs(pv - pv1) <= 1e-6 * pv1 + 1e-13)
+    pick = np.array([0, 5, 777, 1500, 2047])
+    opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, pick])
+    assert np.all(np.abs(pv[pick] - opv) <= 1e-5 * opv + 1e-13), np.c_[pv[pick], opv]
