@@ -44,7 +44,8 @@ struct NullFitArgs {
 
 // c <= CRM_MAX_COV: register kernel (nullfit.hip); larger c (or force_wide): LDS kernel
 // (nullfit_wide.hip).  Both end with the rho* selection into a.out.
-int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide = false);
+// queue: CRM_MAX_RHO unsigned counters in device memory (optional; enables the LDS-shared form for c == 1)
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide = false, unsigned* queue = nullptr);
 int launch_nullfit_wide(hipStream_t st, const NullFitArgs& a, int variants);
 
 // ---- association paths (assoc.hip) ---------------------------------------------------------------

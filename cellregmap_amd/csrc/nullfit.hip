@@ -117,17 +117,14 @@ __device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
     }
 }
 
-template <int C>
-#ifdef CRM_NULLFIT_WAVES
-__attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
-#endif
-__global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
+// One fit: variant b at grid point w, by one wavefront.  SH: the vectors every variant of a grid point shares --
+// Q0'W, Q0'y, S0 -- are read from LDS (sW [C][sld], sy, sS) instead of global memory.
+template <int C, bool SH>
+__device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, const int w, const int lane,
+                                            const double* sW, const double* sy, const double* sS, const int sld) {
     constexpr int P = C + 1;  // columns of X = [W, g]
     constexpr int U = C + 2;  // ... plus y
     constexpr int NP = U * (U + 1) / 2;
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int w = blockIdx.y;  // rho index
     const NullFitRho R = a.rho[w];
     const double* __restrict__ tg = R.T + (long)b * R.ldT;
     const int r = R.r;
@@ -212,10 +209,10 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
                 ok[q] = j < r;
                 const int jj = ok[q] ? j : r - 1;
 #pragma unroll
-                for (int i = 0; i < C; i++) t[q][i] = R.tW[(long)i * R.ldW + jj];
+                for (int i = 0; i < C; i++) t[q][i] = SH ? sW[i * sld + jj] : R.tW[(long)i * R.ldW + jj];
                 t[q][C] = tg[jj];
-                t[q][C + 1] = R.ty[jj];
-                s0[q] = weighted ? R.S0[jj] : 0.0;
+                t[q][C + 1] = SH ? sy[jj] : R.ty[jj];
+                s0[q] = weighted ? (SH ? sS[jj] : R.S0[jj]) : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < UNR; q++) {
@@ -496,6 +493,61 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
     }
 }
 
+template <int C>
+#ifdef CRM_NULLFIT_WAVES
+__attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
+#endif
+__global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
+    nullfit_fit<C, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
+}
+
+// The same fits with the shared vectors of a grid point resident in LDS.  The one-wavefront-per-fit kernel above
+// re-reads Q0'W, Q0'y and S0 from L2 on every likelihood evaluation: 4096 variants x 11 grid points x ~30 evaluations
+// x 160 KB at config 3 = 36 TB/s at the speed it runs -- the L2's aggregate bandwidth, not the vector ALU, is what
+// bounds it.  Here one workgroup of twelve wavefronts per CU copies the three vectors of a grid point into LDS once
+// (120 KB at r = 5000) and its wavefronts then draw variants of that grid point from a queue (an atomic counter per
+// grid point: likelihood-evaluation counts differ from variant to variant); when the queue is empty the workgroup moves
+// on to the next grid point with work left.  Only Q0'g still comes from L2.
+constexpr int NF_SHARED_WAVES = 12;
+template <int C>
+__global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(NullFitArgs a, int variants, int sld,
+                                                                             unsigned* __restrict__ queue) {
+    extern __shared__ double nf_sm[];   // Q0'W [C][sld], Q0'y [sld], S0 [sld]
+    __shared__ int any_left;
+    double* const sW = nf_sm;
+    double* const sy = nf_sm + C * sld;
+    double* const sS = sy + sld;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w0 = (int)(blockIdx.x % (unsigned)a.nrho);
+    for (int pass = 0; pass < a.nrho; pass++) {
+        const int w = (w0 + pass) % a.nrho;
+        if (tid == 0)   // (the counter only grows: a stale "work left" costs one LDS fill, never a missed variant)
+            any_left = (__hip_atomic_load(&queue[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6) < (unsigned)variants;
+        __syncthreads();
+        const bool any = any_left != 0;
+        __syncthreads();
+        if (!any) continue;
+        const NullFitRho R = a.rho[w];
+        for (int j = tid; j < R.r; j += 64 * NF_SHARED_WAVES) {
+#pragma unroll
+            for (int i = 0; i < C; i++) sW[i * sld + j] = R.tW[(long)i * R.ldW + j];
+            sy[j] = R.ty[j];
+            sS[j] = R.S0[j];
+        }
+        __syncthreads();
+        for (;;) {
+            // every lane takes a ticket (the compiler turns this into one add of 64 per wavefront); a branch on the lane
+            // around the atomic was restructured by the compiler into a loop that drew a ticket once and then re-fitted
+            // variant 0 for ever
+            const unsigned ticket = __hip_atomic_fetch_add(&queue[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket) >> 6;
+            if (b >= (unsigned)variants) break;
+            nullfit_fit<C, true>(a, (int)b, w, lane, sW, sy, sS, sld);
+        }
+        __syncthreads();
+    }
+}
+
 // rho* = first strictly larger lml over the grid (_cellregmap.py:354-357)
 __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nrho, int variants,
                                   NullFitOut* __restrict__ out) {
@@ -534,13 +586,29 @@ static void launch_c(hipStream_t st, const NullFitArgs& a, int variants) {
     hipLaunchKernelGGL(nullfit_kernel<C>, dim3(variants, a.nrho), dim3(64), 0, st, a);
 }
 
-int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide) {
+int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide, unsigned* queue) {
     if (variants <= 0) return CRM_OK;
     if (a.nrho < 1 || a.nrho > CRM_MAX_RHO) {
         set_error("null fit: %d grid points (supported 1..%d)", a.nrho, CRM_MAX_RHO);
         return CRM_ERR_UNSUPPORTED;
     }
-    if (force_wide || a.c > CRM_MAX_COV) {
+    int rmax = 1;
+    for (int i = 0; i < a.nrho; i++) rmax = std::max(rmax, a.rho[i].r);
+    const int sld = (rmax + 63) / 64 * 64;
+    const size_t shared_lds = sizeof(double) * 3 * (size_t)sld;
+    // (one covariate column -- the reference's default W = ones -- enough variants to keep 256 x 12 wavefronts busy, and
+    // the three vectors of the longest spectrum within LDS)
+    if (queue && !force_wide && a.c == 1 && variants >= 1024 && shared_lds <= 144 * 1024 && !getenv("CRM_NULLFIT_PER_WAVE")) {
+        int cus = 256, dev = 0;
+        CRM_HIP(hipGetDevice(&dev));
+        CRM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        CRM_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned) * CRM_MAX_RHO, st));
+        if (shared_lds > 60 * 1024)
+            CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nullfit_shared_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));
+        hipLaunchKernelGGL(nullfit_shared_kernel<1>, dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a, variants, sld,
+                           queue);
+    } else if (force_wide || a.c > CRM_MAX_COV) {
         CRM_TRY(launch_nullfit_wide(st, a, variants));
     } else
     switch (a.c) {

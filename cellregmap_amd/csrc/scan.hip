@@ -826,7 +826,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                  o_ord = carve(sizeof(int) * max_pairs), o_Q = carve(sizeof(double) * BLK),
                  o_pv = carve(sizeof(double) * BLK), o_lam = carve(sizeof(double) * BLK * k0),
                  o_if = carve(sizeof(int) * BLK), o_liu = carve(sizeof(double) * BLK),
-                 o_part = carve(stats_ws);
+                 o_part = carve(stats_ws), o_queue = carve(sizeof(unsigned) * CRM_MAX_RHO);
     CRM_TRY(ctx->ws_small.ensure(off));
     char* sm = ctx->ws_small.as<char>();
     double* d_gg = (double*)(sm + o_gg);
@@ -842,6 +842,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     int* d_if = (int*)(sm + o_if);
     double* d_liu = (double*)(sm + o_liu);
     double* d_part = (double*)(sm + o_part);
+    unsigned* d_queue = (unsigned*)(sm + o_queue);   // work queue of the null fits (one counter per grid point)
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
@@ -996,7 +997,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
             fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = ld_gW;
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
-            CRM_TRY(launch_nullfit(st, fa, nb));
+            CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));
         }
         trace_pop();
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
