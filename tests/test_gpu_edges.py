@@ -308,3 +308,26 @@ def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(monkeypatch):
     pick = np.array([0, 5, 777, 1500, 2047])
     opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, pick])
     assert np.all(np.abs(pv[pick] - opv) <= 1e-5 * opv + 1e-13), np.c_[pv[pick], opv]
+
+
+def test_null_fit_forms_are_bit_identical(monkeypatch):
+    """Null fits by LDS-sharing workgroups that draw variants from a queue (default from 1024 variants on, one covariate
+    column) against one independent wavefront per (variant, grid point) (CRM_NULLFIT_PER_WAVE=1): the arithmetic and its
+    order are the same, so every output must agree bit for bit -- including which variants land where in the queue."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 30, 4, 1536, seed=3)
+    for kw in ({"hK": c.hK}, {"Ls": crm.get_L_values(c.hK, c.E)}):
+        obj = crm.CellRegMap(c.y, c.E, W=c.W, **kw)
+        rng = np.random.default_rng(2)
+        panel = crm.GenotypePanel(c.G + 0.05 * rng.normal(size=c.G.shape), groups=None)
+        pv, info, st = obj.scan_interaction(panel, return_stats=True)
+        monkeypatch.setenv("CRM_NULLFIT_PER_WAVE", "1")
+        pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
+        monkeypatch.delenv("CRM_NULLFIT_PER_WAVE")
+        assert np.array_equal(pv, pv1, equal_nan=True)
+        for k in info:
+            assert np.array_equal(info[k], info1[k], equal_nan=True), k
+        for k in ("delta", "lml", "scale", "Q"):
+            assert np.array_equal(st[k], st1[k], equal_nan=True), k
