@@ -1,7 +1,6 @@
 // Stand-alone probe: (1) bare v_mfma_f64_16x16x4_f64 issue rate, (2) throughput of the
 // contraction kernel (plain and Khatri-Rao) at config-3 shapes.  Not part of the product.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip cellregmap_amd/csrc/gemm_tn.hip \
-//         cellregmap_amd/csrc/api_core.hip -o tools/gemm_bench
+//   sh tools/build_probes.sh   (links against the built libcrm_hip.so)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
