@@ -331,3 +331,23 @@ def test_null_fit_forms_are_bit_identical(monkeypatch):
             assert np.array_equal(info[k], info1[k], equal_nan=True), k
         for k in ("delta", "lml", "scale", "Q"):
             assert np.array_equal(st[k], st1[k], equal_nan=True), k
+
+
+def test_wide_panel_on_a_small_cohort_against_the_oracle():
+    """1 200 variants on 120 cells: enough variants for the LDS-sharing null-fit workgroups and their queue (from 1 024
+    on), few enough cells for the oracle to scan all of them -- every p-value at the north-star tolerance."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    c = make_cohort(6, 20, 3, 1200, seed=41)
+    rng = np.random.default_rng(4)
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    pv, info = obj.scan_interaction(crm.GenotypePanel(G, groups=None))
+    opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(G)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-13), np.c_[pv, opv][np.abs(pv - opv) > 1e-5 * opv + 1e-13][:5]
+    same = info["rho1"] == oinfo["rho1"]
+    total = oinfo["e2"] + oinfo["g2"] + oinfo["eps2"]
+    flat = (oinfo["e2"] + oinfo["g2"] <= 1e-6 * total) & (info["e2"] + info["g2"] <= 1e-6 * total)
+    assert np.all(same | flat)
