@@ -28,8 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P_ATOL = 1e-13
 
 
-def _run(polish, count=150, seed=None):
-    """``count`` / ``seed``: tools/fuzz_scan.py runs larger samples from other streams through the same code."""
+def _run(polish, count=150, seed=None, **case_limits):
+    """``count`` / ``seed`` / ``case_limits`` (``max_cells``, ``max_variants``, ... of ``fuzz_cases``): tools/fuzz_scan.py
+    runs larger samples from other streams through the same code."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
     from oracle.crm import OracleCellRegMap
 
@@ -42,7 +43,7 @@ def _run(polish, count=150, seed=None):
     rows = []   # per (variant, path): rel dQ, rel dp, abs dp, rel dlml, same rho
     skipped = 0
     try:
-        for case in fuzz_cases(count, seed=seed, wide_covariates=not polish):
+        for case in fuzz_cases(count, seed=seed, wide_covariates=not polish, **case_limits):
             y, E, W, G, kw, hooks = build_case(case)
             try:
                 opv, oinfo, ost = OracleCellRegMap(y, E, W=W, polish=polish, **kw).scan_interaction(

@@ -1,5 +1,5 @@
 """Random problems, device (dense + collapsed) vs oracle, both null-fit procedures: prints the summaries that
-tests/test_gpu_fuzz.py asserts on.  GPU only.   python tools/fuzz_scan.py [polished|verbatim|both] [count 150] [seed]"""
+tests/test_gpu_fuzz.py asserts on.  GPU only.   python tools/fuzz_scan.py [polished|verbatim|both] [count 150] [seed] [max_variants] [max_cells]"""
 import json
 import os
 import sys
@@ -12,5 +12,10 @@ from test_gpu_fuzz import _run  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else None
+limits = {}
+if len(sys.argv) > 4:
+    limits["max_variants"] = int(sys.argv[4])      # e.g. 1400: panels wide enough for the queue-based null fits
+if len(sys.argv) > 5:
+    limits["max_cells"] = int(sys.argv[5])
 for polish in ([True, False] if which == "both" else [which == "polished"]):
-    print(json.dumps(_run(polish, count=count, seed=seed)[0], indent=1), flush=True)
+    print(json.dumps({**_run(polish, count=count, seed=seed, **limits)[0], **limits}, indent=1), flush=True)
