@@ -68,6 +68,11 @@ int DevBuf::ensure(size_t need) {
     if (e != hipSuccess) ptr = nullptr;
     CRM_HIP(e);
     bytes = need;
+    // CRM_POISON=1 (GPU AddressSanitizer is not available for this target): every fresh allocation is filled with
+    // 0xFF bytes -- NaN as a double, -1 as an int -- so that a read of memory nobody wrote shows up as a NaN result or
+    // as a range-checked index, whatever the previous tenant of the HBM left behind.
+    static const bool poison = getenv("CRM_POISON") && atoi(getenv("CRM_POISON")) != 0;
+    if (poison) CRM_HIP(hipMemset(ptr, 0xFF, need));
     return CRM_OK;
 }
 
@@ -127,6 +132,7 @@ const char* crm_last_error(void) { return last_error_text(); }
 const char* crm_version(void) { return "0.1.0"; }
 
 int crm_ctx_create(int device, crm_ctx** out) {
+    return crm::guarded("crm_ctx_create", [&]() -> int {
     if (!out) return CRM_ERR_ARG;
     *out = nullptr;
     int count = 0;
@@ -151,18 +157,22 @@ int crm_ctx_create(int device, crm_ctx** out) {
     }
     *out = c;
     return CRM_OK;
+    });
 }
 
 int crm_ctx_trim(crm_ctx* c) {
+    return crm::guarded("crm_ctx_trim", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     (void)trim_context(c);
     return CRM_OK;
+    });
 }
 
 void crm_ctx_destroy(crm_ctx* c) {
+    try {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -184,41 +194,54 @@ void crm_ctx_destroy(crm_ctx* c) {
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;
+    } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
+    }
 }
 
 int crm_ctx_synchronize(crm_ctx* c) {
+    return crm::guarded("crm_ctx_synchronize", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 int crm_set_block_variants(crm_ctx* c, int variants) {
+    return crm::guarded("crm_set_block_variants", [&]() -> int {
     if (!c || variants < 0) return CRM_ERR_ARG;
     c->block_variants = variants == 0 ? 0 : (int)round_up(variants, 128);
     return CRM_OK;
+    });
 }
 
 int crm_set_null_fit_polish(crm_ctx* c, int on) {
+    return crm::guarded("crm_set_null_fit_polish", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->polish = on != 0;
     return CRM_OK;
+    });
 }
 
 int crm_set_progress_callback(crm_ctx* c, void (*callback)(long, long, void*), void* user) {
+    return crm::guarded("crm_set_progress_callback", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->progress = callback;
     c->progress_user = user;
     return CRM_OK;
+    });
 }
 
 int crm_set_fast_rotation(crm_ctx* c, int on) {
+    return crm::guarded("crm_set_fast_rotation", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->fast_T = on != 0;
     return CRM_OK;
+    });
 }
 
 int crm_kernel_timer_reset(crm_ctx* c) {
+    return crm::guarded("crm_kernel_timer_reset", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -226,16 +249,20 @@ int crm_kernel_timer_reset(crm_ctx* c) {
     c->kr_flops = 0.0;
     c->timing = true;
     return CRM_OK;
+    });
 }
 
 int crm_kernel_timer_stop(crm_ctx* c) {
+    return crm::guarded("crm_kernel_timer_stop", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->timing = false;  // later scans record nothing; the pairs recorded so far stay readable
     return CRM_OK;
+    });
 }
 
 int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* kr_flops,
                           double* total_ms) {
+    return crm::guarded("crm_kernel_timer_read", [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -250,24 +277,30 @@ int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* 
     if (kr_flops) *kr_flops = c->kr_flops;
     if (total_ms) *total_ms = 0.0;
     return CRM_OK;
+    });
 }
 
 // ---- single-kernel hooks -------------------------------------------------------------
 int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
+    return crm::guarded("crm_test_set_contraction", [&]() -> int {
     if (!c || (tile_width != 0 && tile_width != 64 && tile_width != 128 && tile_width != 160)) return CRM_ERR_ARG;
     c->tune.bn = tile_width;
     c->tune.glds = lds_dma ? 1 : 0;
     return CRM_OK;
+    });
 }
 
 int crm_test_set_contraction_sync(crm_ctx* c, int every) {
+    return crm::guarded("crm_test_set_contraction_sync", [&]() -> int {
     if (!c || every < 0) return CRM_ERR_ARG;
     c->tune.sync = every;
     return CRM_OK;
+    });
 }
 
 int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit) {
+    return crm::guarded("crm_test_contract", [&]() -> int {
     if (!c || cells <= 0 || M <= 0 || N <= 0 || !X || !Y || !C || ksplit < 1) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK * (long)ksplit);
@@ -290,10 +323,12 @@ int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, con
                              M, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const double* G,
                          const double* E, const double* Y, double* C) {
+    return crm::guarded("crm_test_contract_kr", [&]() -> int {
     if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !C) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK);
@@ -317,11 +352,13 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
                              M, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 // transposed store: CT is N x (B*k0) row-major
 int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const double* G, const double* E,
                            const double* Y, double* CT) {
+    return crm::guarded("crm_test_contract_kr_t", [&]() -> int {
     if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !CT) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK);
@@ -346,6 +383,7 @@ int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const d
                              hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 }  // extern "C"
@@ -356,6 +394,7 @@ int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const d
 extern "C" {
 
 int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lambda) {
+    return crm::guarded("crm_test_eigvalsh", [&]() -> int {
     if (!c || count <= 0 || k <= 0 || !F || !lambda) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     ScopedBuf bF, bQ, bL, bP;
@@ -370,10 +409,12 @@ int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lam
     CRM_HIP(hipMemcpyAsync(lambda, bL.ptr, sizeof(double) * (size_t)count * k, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double* lambda, double* pvalue,
                     int* ifault, double* liu) {
+    return crm::guarded("crm_test_davies", [&]() -> int {
     if (!c || count <= 0 || k <= 0 || !Q || !lambda || !pvalue) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     ScopedBuf bQ, bL, bP, bI, bU;
@@ -391,6 +432,7 @@ int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double*
     if (liu) CRM_HIP(hipMemcpyAsync(liu, bU.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;
+    });
 }
 
 }  // extern "C"

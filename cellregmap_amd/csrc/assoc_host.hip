@@ -9,6 +9,7 @@ using namespace crm;
 
 extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long count, int fast,
                                     double* out_pvalue, double* out_alt_lml, double* out_null) {
+    return crm::guarded("crm_scan_association", [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;
@@ -82,6 +83,10 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     CRM_HIP(hipMemcpyAsync(&null, d_fit, sizeof null, hipMemcpyDeviceToHost, st));
     CRM_HIP(hipStreamSynchronize(st));
     const int ri = null.rho_index;
+    if (ri < 0 || ri >= nrho) {
+        set_error("association: the null model's fit did not run (grid index %d)", ri);
+        return CRM_ERR_NUMERIC;
+    }
     const double rho = bg->rho[ri];
     if (out_null) {
         out_null[0] = rho;
@@ -138,4 +143,5 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
         CRM_HIP(hipStreamSynchronize(st));
     }
     return CRM_OK;
+    });
 }

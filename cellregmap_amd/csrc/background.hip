@@ -623,42 +623,54 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
 extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B,
                                      long kb, int nrho, const double* rho, double rel_tol,
                                      crm_background** out) {
+    return crm::guarded("crm_background_create", [&]() -> int {
     if (kb > 0 && !B) return CRM_ERR_ARG;
     return background_create_core(ctx, n, E1, k1, B, kb, nullptr, 0, nullptr, 0, nrho, rho, rel_tol, out);
+    });
 }
 
 extern "C" int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k1, const double* U,
                                               int k2, const double* hK, int m, int nrho, const double* rho,
                                               double rel_tol, crm_background** out) {
+    return crm::guarded("crm_background_create_hadamard", [&]() -> int {
     if (!U || !hK || k2 < 1 || m < 1) return CRM_ERR_ARG;
     return background_create_core(ctx, n, E1, k1, nullptr, (long)k2 * m, U, k2, hK, m, nrho, rho, rel_tol, out);
+    });
 }
 
 // ---- the same constructor split over several processes (one per GPU) ------------------------------------------
 extern "C" int crm_background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
                                     const double* U, int k2, const double* hK, int m, int nrho, const double* rho,
                                     const int* mine, double rel_tol, crm_background** out) {
+    return crm::guarded("crm_background_begin", [&]() -> int {
     if (kb > 0 && !B && !(U && hK && k2 >= 1 && m >= 1 && (long)k2 * m == kb)) return CRM_ERR_ARG;
     return background_begin(ctx, n, E1, k1, B, kb, U, k2, hK, m, nrho, rho, mine, rel_tol, out);
+    });
 }
 
 extern "C" int crm_background_complete(crm_background* bg, const int* ranks) {
+    return crm::guarded("crm_background_complete", [&]() -> int {
     if (!bg || !ranks) return CRM_ERR_ARG;
     return background_complete(bg, ranks);
+    });
 }
 
 extern "C" int crm_background_seal(crm_background* bg) {
+    return crm::guarded("crm_background_seal", [&]() -> int {
     if (!bg) return CRM_ERR_ARG;
     return background_seal(bg);
+    });
 }
 
 extern "C" int crm_background_layout(const crm_background* bg, long* n_pad, long* ldq, long* ldh, int* has_mix) {
+    return crm::guarded("crm_background_layout", [&]() -> int {
     if (!bg || !bg->builder || !bg->builder->completed) return CRM_ERR_ARG;
     if (n_pad) *n_pad = bg->n_pad;
     if (ldq) *ldq = bg->ldq;
     if (ldh) *ldh = bg->builder->thin ? bg->builder->cp : 0;   // > 0: exchange S0 and Mix only, Q0 = H Mix is formed locally
     if (has_mix) *has_mix = bg->builder->thin ? 1 : 0;
     return CRM_OK;
+    });
 }
 
 // what: 0 = Q0 (n_pad x ldq), 1 = S0 (ldq), 2 = Mix (ldh x ldq); device-to-device copies on the context's stream
@@ -673,6 +685,7 @@ static int background_slot(const crm_background* bg, int i, int what, void** ptr
 }
 
 extern "C" int crm_background_export(const crm_background* bg, int i, int what, void* dst_device) {
+    return crm::guarded("crm_background_export", [&]() -> int {
     void* p = nullptr;
     size_t bytes = 0;
     if (bg && what == 0 && i >= 0 && i < bg->nrho && !bg->q0_ready[i] && bg->builder && bg->builder->thin) {
@@ -684,9 +697,11 @@ extern "C" int crm_background_export(const crm_background* bg, int i, int what, 
     CRM_HIP(hipMemcpyAsync(dst_device, p, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
     CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
     return CRM_OK;
+    });
 }
 
 extern "C" int crm_background_import(crm_background* bg, int i, int what, const void* src_device) {
+    return crm::guarded("crm_background_import", [&]() -> int {
     void* p = nullptr;
     size_t bytes = 0;
     if (!src_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
@@ -695,6 +710,7 @@ extern "C" int crm_background_import(crm_background* bg, int i, int what, const 
     CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
     if (what == 0) bg->q0_ready[i] = true;
     return CRM_OK;
+    });
 }
 
 int crm_background_require_q0(crm_background* bg, int i) {

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,23 @@ const char* last_error_text();
     } while (0)
 
 inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// No C++ exception may cross the C-ABI (ctypes / cgo / JNI callers cannot unwind, the process would end in
+// std::terminate): every extern "C" entry point runs its body through this guard, which turns std::bad_alloc,
+// std::length_error and anything else into a status code with the text in crm_last_error().
+template <class Body>
+inline int guarded(const char* entry, Body&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory (std::bad_alloc)", entry);
+    } catch (const std::exception& e) {
+        set_error("%s: unexpected C++ exception: %s", entry, e.what());
+    } catch (...) {
+        set_error("%s: unexpected C++ exception", entry);
+    }
+    return CRM_ERR_INTERNAL;
+}
 
 // Named ranges for rocprofv3 --marker-trace (rocprofiler-sdk roctx), resolved at run time: without the library
 // in the process they are no-ops.  Around the phases of the constructor and of every block of a scan.

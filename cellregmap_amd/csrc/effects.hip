@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void cov_solve_kernel(const double* __restrict
 }  // namespace
 
 extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, double* out_beta) {
+    return crm::guarded("crm_lmm_fit", [&]() -> int {
     if (!gene || !out_fit) return CRM_ERR_ARG;
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;
@@ -92,7 +93,7 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
     NullFitOut fit{};
     CRM_HIP(hipMemcpyAsync(&fit, fa.out, sizeof fit, hipMemcpyDeviceToHost, st));
     CRM_HIP(hipStreamSynchronize(st));
-    if (!std::isfinite(fit.lml)) {
+    if (!std::isfinite(fit.lml) || fit.rho_index < 0 || fit.rho_index >= bg->nrho) {
         set_error("lmm_fit: the model could not be fitted (non-finite log-likelihood)");
         return CRM_ERR_NUMERIC;
     }
@@ -128,10 +129,12 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
         out_beta[i] = s / L[i * CMAX + i];
     }
     return CRM_OK;
+    });
 }
 
 extern "C" int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const double* rhs,
                              int m, double* out) {
+    return crm::guarded("crm_cov_solve", [&]() -> int {
     if (!bg || !rhs || !out) return CRM_ERR_ARG;
     if (rho_index < 0 || rho_index >= bg->nrho || m < 1 || !(v1 > 0.0)) {
         set_error("cov_solve: rho_index=%d (grid of %d), m=%d, v1=%g", rho_index, bg->nrho, m, v1);
@@ -168,4 +171,5 @@ extern "C" int crm_cov_solve(crm_background* bg, int rho_index, double v0, doubl
     CRM_HIP(hipMemcpyAsync(out, d_out.ptr, sizeof(double) * n * m, hipMemcpyDeviceToHost, st));
     CRM_HIP(hipStreamSynchronize(st));
     return CRM_OK;
+    });
 }

@@ -599,6 +599,7 @@ int eigh_dc(crm_ctx* ctx, EighWork& w, double* lam_host, double** Qt_out) {
 // ---- test hook (host only: no GPU touched): the deflation plan of one merge ------------------------------------------
 extern "C" int crm_test_dc_plan(const double* lam, const double* z, int n1, int n, double beta, int* k, double* rho,
                                 int* rows, double* dl, double* w, int* nrot, double* rots) {
+    return crm::guarded("crm_test_dc_plan", [&]() -> int {
     if (!lam || !z || n1 < 1 || n <= n1 || !k || !rho || !rows || !dl || !w || !nrot || !rots) return CRM_ERR_ARG;
     crm::MergePlan P;
     crm::plan_merge(lam, z, n1, n, beta, P);
@@ -611,4 +612,5 @@ extern "C" int crm_test_dc_plan(const double* lam, const double* z, int n1, int 
         rots[4 * i] = P.rots[i].a; rots[4 * i + 1] = P.rots[i].b; rots[4 * i + 2] = P.rots[i].c; rots[4 * i + 3] = P.rots[i].s;
     }
     return CRM_OK;
+    });
 }

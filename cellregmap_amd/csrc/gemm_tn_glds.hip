@@ -114,7 +114,12 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
         for (int q = 0; q < YQ; q++) {
             const int p = (wave + 4 * q) * 64 + lane;
             const int r = p / 80, g = p - r * 80;
-            y_piece[q] = 8u * (unsigned)(r * (int)P.ldy + ((g ^ ((r & 1) << 3)) << 1));
+            // A 160-column tile on rows shorter than n0 + 160 doubles (a 128-column operand forced through this
+            // kernel) would read past the row -- on the operand's last row past its allocation, an illegal access
+            // whenever the buffer ends on a page boundary (round 2's intermittent abort of the GPU suite).  Pieces
+            // beyond the row fetch its first granule instead: they only feed output columns >= N, never stored.
+            const int col = (g ^ ((r & 1) << 3)) << 1;
+            y_piece[q] = 8u * (unsigned)(r * (int)P.ldy + ((long)n0 + col + 2 <= P.ldy ? col : 0));
         }
     }
     constexpr int ECN = ECQ > 0 ? ECQ : 1;

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
     for (int pass = 0; pass < a.nrho; pass++) {
         const int w = (w0 + pass) % a.nrho;
         if (tid == 0)   // (the counter only grows: a stale "work left" costs one LDS fill, never a missed variant)
-            any_left = (__hip_atomic_load(&queue[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6) < (unsigned)variants;
+            any_left = __hip_atomic_load(&queue[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)variants;
         __syncthreads();
         const bool any = any_left != 0;
         __syncthreads();
@@ -536,11 +536,13 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
         }
         __syncthreads();
         for (;;) {
-            // every lane takes a ticket (the compiler turns this into one add of 64 per wavefront); a branch on the lane
-            // around the atomic was restructured by the compiler into a loop that drew a ticket once and then re-fitted
-            // variant 0 for ever
-            const unsigned ticket = __hip_atomic_fetch_add(&queue[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket) >> 6;
+            // One ticket per wavefront, wave-uniform by construction: every lane issues the atomic, lane 0 adds one and
+            // the others add zero, so lane 0's return value is this wavefront's own ticket whatever form the compiler
+            // gives the 64 lane-atomics (one per lane, or one per wavefront with a prefix sum) -- no branch on the lane
+            // around the atomic, no reliance on a particular optimisation.  Tickets count variants in units of one.
+            const unsigned ticket = __hip_atomic_fetch_add(&queue[w], lane == 0 ? 1u : 0u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
             if (b >= (unsigned)variants) break;
             nullfit_fit<C, true>(a, (int)b, w, lane, sW, sy, sS, sld);
         }
@@ -548,23 +550,30 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
     }
 }
 
-// rho* = first strictly larger lml over the grid (_cellregmap.py:354-357)
+// rho* = first strictly larger lml over the grid (_cellregmap.py:354-357).  launch_nullfit fills the trial records
+// with 0xFF bytes (nfev = -1) before the fit kernels run: a (variant, grid point) no kernel fitted is reported as
+// rho_index = -1, which every host consumer turns into CRM_ERR_NUMERIC instead of using what the memory held.
 __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nrho, int variants,
                                   NullFitOut* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= variants) return;
     double best = -INFINITY;
     int bi = -1;
+    bool fitted = true;
     for (int i = 0; i < nrho; i++) {
-        const double v = trial[(long)b * nrho + i].lml;
-        if (v > best) {
-            best = v;
+        const NullFitTrial t = trial[(long)b * nrho + i];
+        if (t.nfev <= 0) fitted = false;
+        if (t.lml > best) {
+            best = t.lml;
             bi = i;
         }
     }
     NullFitOut o;
     o.use_g = trial[(long)b * nrho].use_g;
-    if (bi < 0) {
+    if (!fitted) {
+        o.rho_index = -1;
+        o.lml = NAN; o.delta = NAN; o.scale = NAN; o.v0 = NAN; o.v1 = NAN;
+    } else if (bi < 0) {
         o.rho_index = 0;
         o.lml = NAN; o.delta = NAN; o.scale = NAN; o.v0 = NAN; o.v1 = NAN;
     } else {
@@ -592,6 +601,8 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         set_error("null fit: %d grid points (supported 1..%d)", a.nrho, CRM_MAX_RHO);
         return CRM_ERR_UNSUPPORTED;
     }
+    // poison the trial records: select_rho_kernel recognises a fit that never ran (nfev = -1)
+    CRM_HIP(hipMemsetAsync(a.trial, 0xFF, sizeof(NullFitTrial) * (size_t)variants * a.nrho, st));
     int rmax = 1;
     for (int i = 0; i < a.nrho; i++) rmax = std::max(rmax, a.rho[i].r);
     const int sld = (rmax + 63) / 64 * 64;

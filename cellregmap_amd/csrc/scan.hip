@@ -65,6 +65,7 @@ extern "C" {
 int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, const int* r,
                              const double* const* Q0, const double* const* S0,
                              crm_background** out) {
+    return crm::guarded("crm_background_create_qs", [&]() -> int {
     if (!ctx || !out || n <= 0 || nrho < 1 || !rho || !r || !Q0 || !S0) return CRM_ERR_ARG;
     if (nrho > CRM_MAX_RHO) {
         set_error("background: %d grid points (supported up to %d)", nrho, CRM_MAX_RHO);
@@ -98,9 +99,11 @@ int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, 
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = bg;
     return CRM_OK;
+    });
 }
 
 void crm_background_destroy(crm_background* bg) {
+    try {
     if (!bg) return;
     (void)hipSetDevice(bg->ctx->device);
     (void)hipStreamSynchronize(bg->ctx->stream);
@@ -117,14 +120,19 @@ void crm_background_destroy(crm_background* bg) {
     }
     if (bg->builder) crm_background_builder_free(bg->builder);
     delete bg;
+    } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
+    }
 }
 
 int crm_background_rank(const crm_background* bg, int i) {
+    return crm::guarded("crm_background_rank", [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return -1;
     return bg->r[i];
+    });
 }
 
 int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0) {
+    return crm::guarded("crm_background_read", [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
     if (Q0) CRM_TRY(crm_background_require_q0(const_cast<crm_background*>(bg), i));
     CRM_HIP(hipSetDevice(bg->ctx->device));
@@ -134,11 +142,13 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
                             r * sizeof(double), bg->n, hipMemcpyDeviceToHost));
     if (S0 && r > 0) CRM_HIP(hipMemcpy(S0, bg->S0[i].ptr, r * sizeof(double), hipMemcpyDeviceToHost));
     return CRM_OK;
+    });
 }
 
 // ---- gene -----------------------------------------------------------------------------------
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out) {
+    return crm::guarded("crm_gene_create", [&]() -> int {
     if (!bg || !y || !W || !E0 || !out) return CRM_ERR_ARG;
     *out = nullptr;
     if (bg->builder) {
@@ -261,9 +271,11 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = g;
     return CRM_OK;
+    });
 }
 
 void crm_gene_destroy(crm_gene* g) {
+    try {
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
@@ -272,10 +284,13 @@ void crm_gene_destroy(crm_gene* g) {
                     &g->dt_Zt})
         b->release();
     delete g;
+    } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
+    }
 }
 
 // ---- panel ----------------------------------------------------------------------------------
 int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out) {
+    return crm::guarded("crm_panel_create", [&]() -> int {
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     *out = nullptr;
     CRM_HIP(hipSetDevice(ctx->device));
@@ -292,9 +307,11 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = P;
     return CRM_OK;
+    });
 }
 
 void crm_panel_destroy(crm_panel* P) {
+    try {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
     (void)hipStreamSynchronize(P->ctx->stream);
@@ -303,11 +320,14 @@ void crm_panel_destroy(crm_panel* P) {
     P->group.release();
     P->Z.release();
     delete P;
+    } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
+    }
 }
 
 // ---- grouped (donor-constant) panel --------------------------------------------------------------
 int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
                              long p, crm_panel** out) {
+    return crm::guarded("crm_panel_create_grouped", [&]() -> int {
     if (!ctx || !group || !Gd || !out || n <= 0 || m <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     *out = nullptr;
     for (long i = 0; i < n; i++) {
@@ -340,6 +360,7 @@ int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, con
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = P;
     return CRM_OK;
+    });
 }
 
 }  // extern "C"
@@ -390,6 +411,7 @@ __global__ __launch_bounds__(256) void standardise_dosages_kernel(const signed c
 
 extern "C" int crm_panel_create_grouped_i8(crm_ctx* ctx, long n, const int* group, long m, const signed char* dosage,
                                            long ldd, long p, int standardise, crm_panel** out) {
+    return crm::guarded("crm_panel_create_grouped_i8", [&]() -> int {
     if (!ctx || !group || !dosage || !out || n <= 0 || m <= 0 || p <= 0 || ldd < p) return CRM_ERR_ARG;
     *out = nullptr;
     std::vector<double> cells_of(m, 0.0);
@@ -444,6 +466,7 @@ extern "C" int crm_panel_create_grouped_i8(crm_ctx* ctx, long n, const int* grou
     }
     *out = P;
     return CRM_OK;
+    });
 }
 
 extern "C" {
@@ -454,6 +477,7 @@ extern "C" {
 // verification of detect_groups (both O(n p) memory passes that dominated short scans).
 int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long p, const int* group_hint,
                           long m_hint, const long* rep_rows, crm_panel** out, int* out_grouped) {
+    return crm::guarded("crm_panel_create_auto", [&]() -> int {
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     if (out_grouped) *out_grouped = 0;
     crm_panel* P = nullptr;
@@ -511,12 +535,15 @@ int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long 
     }
     *out = P;
     return CRM_OK;
+    });
 }
 
 int crm_set_donor_collapse(crm_ctx* ctx, int on) {
+    return crm::guarded("crm_set_donor_collapse", [&]() -> int {
     if (!ctx) return CRM_ERR_ARG;
     ctx->collapse = on != 0;
     return CRM_OK;
+    });
 }
 
 }  // extern "C"
@@ -1003,6 +1030,14 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
         CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));
+        for (int gi = 0; gi < ng; gi++)
+            for (int b = 0; b < nb; b++) {
+                const int ri = h_fit[(size_t)gi * BLK + b].rho_index;
+                if (ri < 0 || ri >= nrho) {   // (indexes host arrays below: never trust it unchecked)
+                    set_error("scan: the null fit of variant %ld (phenotype %d) did not run (grid index %d)", col0 + b, gi, ri);
+                    return CRM_ERR_NUMERIC;
+                }
+            }
         std::fill(pair_of.begin(), pair_of.end(), -1);
         for (int gi = 0; gi < ng; gi++)
             for (int b = 0; b < nb; b++) pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b] = 0;
@@ -1259,15 +1294,18 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                          const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
                          double* out_delta, double* out_scale, double* out_lambda, double* out_F) {
+    return crm::guarded("crm_scan_interaction", [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> genes{gene};
     std::vector<ScanOut> outs{{out_pvalue, out_rho1, out_e2, out_g2, out_eps2, out_Q, out_lml, out_delta,
                                out_scale, out_lambda, out_F}};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+    });
 }
 
 int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
                               const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue) {
+    return crm::guarded("crm_scan_interaction_info", [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> genes{gene};
     ScanOut o{out_pvalue, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1275,19 +1313,23 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
     o.liu = out_liu_pvalue;
     std::vector<ScanOut> outs{o};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+    });
 }
 
 long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
+    return crm::guarded("crm_test_set_shared_h", [&]() -> int {
     if (!ctx) return CRM_ERR_ARG;
     ctx->tune.shared_h = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
     return CRM_OK;
+    });
 }
 
 int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* panel, long first, long count,
                                const int* idx_E, const int* idx_G, double* out_pvalue, double* out_rho1,
                                double* out_e2, double* out_g2, double* out_eps2, double* out_Q) {
+    return crm::guarded("crm_scan_interaction_multi", [&]() -> int {
     if (!genes || ngenes < 1 || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> gs(genes, genes + ngenes);
     for (crm_gene* g : gs)
@@ -1299,6 +1341,7 @@ int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* pa
                           nullptr, nullptr, nullptr, nullptr, nullptr};
     }
     return scan_core(gs, panel, first, count, idx_E, idx_G, outs);
+    });
 }
 
 }  // extern "C"

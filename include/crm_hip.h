@@ -24,6 +24,7 @@ extern "C" {
 #define CRM_ERR_ARG (-2)
 #define CRM_ERR_UNSUPPORTED (-3)
 #define CRM_ERR_NUMERIC (-4)
+#define CRM_ERR_INTERNAL (-5) /* host side: out of memory or an unexpected C++ exception, stopped at the boundary */
 
 typedef struct crm_ctx crm_ctx;
 typedef struct crm_background crm_background;

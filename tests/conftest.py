@@ -9,9 +9,52 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# A test that takes the process down (a GPU memory-access fault makes ROCr call abort(), a C++ exception
+# crossing the C-ABI ends in std::terminate) must leave its name behind: every test writes its nodeid to
+# stderr before it starts and to a trace file that survives the process (CRM_TEST_TRACE, default
+# gpurun_out/pytest_trace.log when that directory exists).
+_trace_fh = None
+_echo = True   # nodeids on stderr: always, except in the CPU-only selection (-m "not gpu"), which cannot take a GPU fault
+
+
+def _trace_path():
+    p = os.environ.get("CRM_TEST_TRACE")
+    if p:
+        return p
+    d = os.path.join(ROOT, "gpurun_out")
+    return os.path.join(d, "pytest_trace.log") if os.path.isdir(d) else None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    global _trace_fh, _echo
+    _echo = "not gpu" not in (config.getoption("markexpr", "") or "") or bool(os.environ.get("CRM_TEST_TRACE"))
+    p = _trace_path()
+    if p:
+        try:
+            _trace_fh = open(p, "a", buffering=1)
+            _trace_fh.write("=== session pid %d argv %s\n" % (os.getpid(), " ".join(sys.argv[1:])))
+        except OSError:
+            _trace_fh = None
+
+
+def pytest_runtest_logstart(nodeid, location):
+    msg = "[crm-test] start %s\n" % nodeid
+    if _echo:
+        try:
+            os.write(2, msg.encode())
+        except OSError:
+            pass
+    if _trace_fh is not None:
+        _trace_fh.write(msg)
+        _trace_fh.flush()
+        os.fsync(_trace_fh.fileno())
+
+
+def pytest_runtest_logfinish(nodeid, location):
+    if _trace_fh is not None:
+        _trace_fh.write("[crm-test] done  %s\n" % nodeid)
+        _trace_fh.flush()
 
 
 @pytest.fixture(scope="session")

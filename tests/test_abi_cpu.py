@@ -101,3 +101,43 @@ def test_detect_groups_finds_exactly_the_donor_structure():
     found = detect_groups(G2)
     assert found is None or np.array_equal(G2[found[1]][found[0]], G2)
     assert detect_groups(rng.normal(size=(40, 20))) is None
+
+
+def test_a_cpp_exception_stops_at_the_boundary():
+    """include/crm_hip.h: "no exceptions across the boundary".  An absurd donor count makes std::vector throw
+    std::length_error inside crm_panel_create_grouped_i8 before any GPU call (so this runs without a GPU); the
+    caller must see a status code and a text, not std::terminate."""
+    import ctypes
+
+    from cellregmap_amd import _lib
+
+    lib = _lib.load()
+    fake_ctx = ctypes.create_string_buffer(4096)          # never dereferenced before the allocation that throws
+    group = np.zeros(1, np.int32)
+    dosage = np.zeros(1, np.int8)
+    out = ctypes.c_void_p()
+    rc = lib.crm_panel_create_grouped_i8(ctypes.cast(fake_ctx, ctypes.c_void_p), 1, _lib.ptr(group), 1 << 61,
+                                         _lib.ptr(dosage), 1, 1, 0, ctypes.byref(out))
+    assert rc == -5 and not out.value                     # CRM_ERR_INTERNAL
+    msg = lib.crm_last_error().decode()
+    assert "crm_panel_create_grouped_i8" in msg and "exception" in msg or "memory" in msg
+    with pytest.raises(_lib.CrmError, match="crm_panel_create_grouped_i8"):
+        _lib.check(rc)
+
+
+def test_every_entry_point_runs_behind_the_exception_guard():
+    """Structural: each `int crm_*` the headers declare is defined with its body inside crm::guarded(...) (one-line
+    getters that cannot throw excepted), each `void crm_*_destroy` inside try / catch (...)."""
+    csrc = os.path.join(ROOT, "cellregmap_amd", "csrc")
+    text = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))
+    exempt = {"crm_last_error", "crm_version", "crm_test_tail_launches"}
+    for name in _declared_symbols():
+        if name in exempt:
+            continue
+        m = re.search(r'^(?:extern "C" )?(int|void) %s\((?:[^{;]|\n)*\{\n(.*)$' % name, text, flags=re.M)
+        assert m, f"definition of {name} not found"
+        first = m.group(2).strip()
+        if m.group(1) == "int":
+            assert first.startswith('return crm::guarded("%s"' % name), f"{name}: {first}"
+        else:
+            assert first.startswith("try {"), f"{name}: {first}"

@@ -551,6 +551,21 @@ def test_decaying_spectrum_background(mode):
     _compare(pv, info, st, ppv, pinfo, pst, tight=True)
 
 
+def _loaded_hip_runtime():
+    """The HIP runtime libcrm_hip.so itself is linked against, opened by the path it is mapped from: a bare
+    dlopen("libamdhip64.so") can resolve to a second copy of the runtime (torch bundles one), and device pointers of one
+    runtime mean nothing to the other."""
+    import ctypes
+
+    from cellregmap_amd import _lib
+
+    _lib.load()
+    with open("/proc/self/maps") as fh:
+        paths = {ln.split()[-1] for ln in fh if "libamdhip64.so" in ln}
+    assert len(paths) == 1, paths          # exactly one HIP runtime in this process
+    return ctypes.CDLL(paths.pop())
+
+
 @pytest.mark.parametrize("mode", ["C-thin", "C-eigh", "B"])
 def test_constructor_in_phases_with_exchanged_grid_points(mode):
     """The multi-GPU constructor on one GPU: two builders own the even / odd grid points, exchange their
@@ -565,7 +580,7 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
     # device buffers from the HIP runtime the library itself runs on (a torch tensor's data_ptr() is the same
     # kind of pointer; torch is kept out of this process because it has to initialise the GPU BEFORE the
     # library does, and other tests of the session have used the library already)
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _loaded_hip_runtime()
 
     class DeviceBuffer:
         def __init__(self, doubles):
