@@ -223,7 +223,7 @@ class BackgroundBuilder:
         return {"Q0": n_pad.value * ldq.value, "S0": ldq.value}
 
     def export_slot(self, i, what, tensor):
-        """Copy slot ``what`` of grid point i into ``tensor`` (float64, on this GPU)."""
+        """Copy slot ``what`` of grid point i into ``tensor`` (float64; on this GPU, or a CPU tensor under gloo)."""
         _lib.check(_lib.load().crm_background_export(self._bg.handle, i, self.SLOTS[what], ctypes.c_void_p(tensor.data_ptr())))
 
     def import_slot(self, i, what, tensor):
@@ -432,18 +432,41 @@ def _release_gene(lib, handle, _background_kept_alive):
 _PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
 
 
-class _progress:
-    """Context manager: installs a per-block progress callback on the device's context for one scan."""
+_progress_stack = {}   # device -> callbacks installed by the scans in flight (innermost last)
 
-    def __init__(self, device, progress, total):
+
+def _progress_default():
+    """The reference shows a tqdm bar over the variants of every scan (_cellregmap.py:270,340); so does this engine
+    unless ``progress=False`` is passed or CELLREGMAP_AMD_PROGRESS=0 is set in the environment."""
+    import os
+
+    return os.environ.get("CELLREGMAP_AMD_PROGRESS", "1").lower() not in ("0", "false", "no", "off")
+
+
+class _progress:
+    """Context manager: installs a per-block progress callback on the device's context for one scan.
+    ``progress``: None = the reference's behaviour (a tqdm bar, see ``_progress_default``), True = a tqdm bar,
+    False = silent, or a callable ``(done, total)``.  A scan started from inside a callback (or a nested call)
+    gets its own callback and the outer one is put back afterwards; an exception raised by a user callback is
+    re-raised once the scan has returned (ctypes cannot carry it through the C frames)."""
+
+    def __init__(self, device, progress, total, offset=0, grand_total=None):
+        if progress is None:
+            progress = _progress_default()
         self.device, self.progress, self.total = device, progress, total
+        self.offset, self.grand_total = offset, grand_total
         self.bar = None
+        self.error = None
 
     def __enter__(self):
         if not self.progress:
             return self
         if self.progress is True:
-            from tqdm import tqdm
+            try:
+                from tqdm import tqdm
+            except ImportError:  # pragma: no cover  (the reference depends on tqdm; without it: no bar)
+                self.progress = False
+                return self
 
             self.bar = tqdm(total=self.total)
             state = {"done": 0}
@@ -455,16 +478,26 @@ class _progress:
             fn = self.progress
 
             def cb(done, total, _user):
-                fn(done, total)
+                if self.error is None:
+                    try:
+                        fn(done + self.offset, total if self.grand_total is None else self.grand_total)
+                    except BaseException as exc:  # noqa: BLE001 -- re-raised in __exit__
+                        self.error = exc
         self._cb = _PROGRESS_CB(cb)   # (kept alive until __exit__)
+        _progress_stack.setdefault(self.device, []).append(self._cb)
         _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), ctypes.cast(self._cb, ctypes.c_void_p), None))
         return self
 
     def __exit__(self, *exc):
         if self.progress:
-            _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), None, None))
+            stack = _progress_stack[self.device]
+            stack.remove(self._cb)
+            outer = ctypes.cast(stack[-1], ctypes.c_void_p) if stack else None
+            _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), outer, None))
             if self.bar is not None:
                 self.bar.close()
+            if self.error is not None and exc[0] is None:
+                raise self.error
         return False
 
 
@@ -611,8 +644,9 @@ class CellRegMap:
     def scan_interaction(self, G, idx_E: Optional[any] = None, idx_G: Optional[any] = None,
                          return_stats: bool = False, progress=None):
         """Per-variant GxC score test.  ``G`` is n x p (array-like) or a ``GenotypePanel``.
-        ``progress``: ``True`` for a tqdm bar over variants (the reference always shows one, :340; here it
-        advances block by block), or a callable ``(done, total)``.
+        ``progress``: the reference always shows a tqdm bar over the variants (:340) and so does this method by
+        default (it advances block by block); ``False`` silences it (or CELLREGMAP_AMD_PROGRESS=0 in the
+        environment), a callable ``(done, total)`` replaces it.
 
         Returns ``(pvalues, info)`` with ``info = {rho1, e2, g2, eps2}`` as the reference
         (:439-440); with ``return_stats=True`` additionally a dict holding Q, the eigenvalues
@@ -669,7 +703,7 @@ class CellRegMap:
         return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault}
 
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
-    def _scan_association(self, G, fast, return_stats=False):
+    def _scan_association(self, G, fast, return_stats=False, progress=None):
         lib = _lib.load()
         p_user = None
         if not isinstance(G, GenotypePanel) and np.asarray(G).ndim == 2 and np.asarray(G).shape[1] == 0:
@@ -684,22 +718,24 @@ class CellRegMap:
         pv = np.empty(p)
         alt = np.empty(p)
         null = np.empty(6)
-        _lib.check(lib.crm_scan_association(gene, panel.handle, 0, p, int(bool(fast)), _lib.ptr(pv),
-                                            _lib.ptr(alt), _lib.ptr(null)))
+        with _progress(self._device, progress, p):
+            _lib.check(lib.crm_scan_association(gene, panel.handle, 0, p, int(bool(fast)), _lib.ptr(pv),
+                                                _lib.ptr(alt), _lib.ptr(null)))
         info = {"rho1": np.asarray([null[0]], float), "e2": np.asarray([null[1]], float),
                 "g2": np.asarray([null[2]], float), "eps2": np.asarray([null[3]], float)}
         if return_stats:
             return pv, info, {"alt_lml": alt, "null_lml": null[4], "null_delta": null[5]}
         return pv, info
 
-    def scan_association(self, G, return_stats: bool = False):
-        """Persistent-effect LRT with a full ML refit per SNP (_cellregmap.py:246-281)."""
-        return self._scan_association(G, False, return_stats)
+    def scan_association(self, G, return_stats: bool = False, progress=None):
+        """Persistent-effect LRT with a full ML refit per SNP (_cellregmap.py:246-281; ``progress`` as in
+        ``scan_interaction`` -- the reference shows a tqdm bar over the SNPs, :270)."""
+        return self._scan_association(G, False, return_stats, progress)
 
-    def scan_association_fast(self, G, return_stats: bool = False):
+    def scan_association_fast(self, G, return_stats: bool = False, progress=False):
         """Persistent-effect LRT with the covariance ratio frozen at the null model
-        (glimix-core FastScanner; _cellregmap.py:284-314)."""
-        return self._scan_association(G, True, return_stats)
+        (glimix-core FastScanner; _cellregmap.py:284-314 -- run with ``verbose=False`` there: no bar by default)."""
+        return self._scan_association(G, True, return_stats, progress)
 
     # -- effect sizes (_cellregmap.py:137-244) -----------------------------------------------------
     def _lmm_fit(self, bg, M):
@@ -847,7 +883,7 @@ def _cis_runs(cis_index, ngenes, p, dense_limit=1 << 26):
     return columns, runs
 
 
-def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None):
+def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None, progress=False):
     """Interaction scans of several phenotypes against one genotype panel in a single pass.
 
     ``crms``: ``CellRegMap`` objects that share the background, ``W`` and ``E`` (e.g. built with
@@ -859,7 +895,10 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None):
     ``cis_index`` (optional): one entry per phenotype naming the variants it is tested against (its cis
     window) -- a ``(start, stop)`` pair, a slice, a boolean mask or an array of column indices.  The panel is
     walked once; each stretch of variants is scanned for exactly the phenotypes whose window covers it.  The
-    results are then lists: entry i holds the arrays of ``crms[i].scan_interaction(G[:, cis_index[i]], ...)``."""
+    results are then lists: entry i holds the arrays of ``crms[i].scan_interaction(G[:, cis_index[i]], ...)``.
+
+    ``progress`` (default off -- this entry point has no counterpart in the reference): ``True`` for a tqdm bar, or a
+    callable ``(done, total)`` counted in variants of the panel that at least one phenotype tests."""
     lib = _lib.load()
     crms = list(crms)
     if not crms:
@@ -885,21 +924,38 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None):
     if cis_index is not None:
         columns, runs = _cis_runs(cis_index, ng, p)
         full = {k: [np.full(p, np.nan) if columns[i].size else None for i in range(ng)] for k in keys}
+        tested = int(sum(count for _, count, _ in runs))
+        bar = None
+        if progress is True:   # one bar over all runs
+            from tqdm import tqdm
+
+            bar = tqdm(total=tested)
+            state = {"done": 0}
+
+            def progress(done, total, _bar=bar, _state=state):
+                _bar.update(done - _state["done"])
+                _state["done"] = done
+        seen = 0
         for a, count, active in runs:
             handles = (ctypes.c_void_p * len(active))(*[genes[i].value for i in active])
             out = {k: np.empty((len(active), count)) for k in keys}
-            _lib.check(lib.crm_scan_interaction_multi(handles, len(active), panel.handle, a, count, _lib.ptr(iE),
-                                                      _lib.ptr(iG), *[_lib.ptr(out[k]) for k in keys], None))
+            with _progress(first._device, progress, count, offset=seen, grand_total=tested):
+                _lib.check(lib.crm_scan_interaction_multi(handles, len(active), panel.handle, a, count, _lib.ptr(iE),
+                                                          _lib.ptr(iG), *[_lib.ptr(out[k]) for k in keys], None))
+            seen += count
             for row, i in enumerate(active):
                 for k in keys:
                     full[k][i][a:a + count] = out[k][row]
+        if bar is not None:
+            bar.close()
         res = {k: [full[k][i][columns[i]] if columns[i].size else np.empty(0) for i in range(ng)] for k in keys}
         return res["pv"], {k: res[k] for k in keys[1:]}
     handles = (ctypes.c_void_p * ng)(*[g.value for g in genes])
     out = {k: np.empty((ng, p)) for k in keys}
-    _lib.check(lib.crm_scan_interaction_multi(handles, ng, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),
-                                              _lib.ptr(out["pv"]), _lib.ptr(out["rho1"]), _lib.ptr(out["e2"]),
-                                              _lib.ptr(out["g2"]), _lib.ptr(out["eps2"]), None))
+    with _progress(first._device, progress, p):
+        _lib.check(lib.crm_scan_interaction_multi(handles, ng, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG),
+                                                  _lib.ptr(out["pv"]), _lib.ptr(out["rho1"]), _lib.ptr(out["e2"]),
+                                                  _lib.ptr(out["g2"]), _lib.ptr(out["eps2"]), None))
     return out["pv"], {k: out[k] for k in ("rho1", "e2", "g2", "eps2")}
 
 
@@ -968,11 +1024,27 @@ def run_association_fast(y, W, E, G, hK=None, *, device=0):
 
 
 def compute_maf(X):
-    """Minor allele frequencies of a 0/1/2 (or dosage) matrix with NaN as missing
-    (_cellregmap.py:589-638, plain-array and DataFrame inputs)."""
-    X = np.asarray(X, float)
-    s0 = np.nansum(X, axis=0) / (2 * np.logical_not(np.isnan(X)).sum(axis=0))
-    return np.minimum(s0, 1 - s0)
+    """Minor allele frequencies of a 0 / 1 / 2 (or dosage) matrix, samples along the first axis, NaN = missing
+    (_cellregmap.py:589-638).  Like the reference it keeps the container it is given: a pandas DataFrame yields
+    a Series named "maf" (indexed by the variant columns), an xarray DataArray a DataArray named "maf" (reduced
+    over its "sample" dimension when it has one, else over axis 0), a dask array is reduced lazily and computed,
+    anything else goes through numpy."""
+    kind = type(X).__module__.split(".")[0]
+    if kind == "dask":
+        total = np.asarray(X.shape[0] - np.isnan(X).sum(axis=0))   # (dispatches to dask, then materialises)
+        freq = np.asarray(np.nansum(X, axis=0)) / (2 * total)
+    elif kind == "pandas" and hasattr(X, "isna") and getattr(X, "ndim", 0) == 2:
+        freq = X.sum(axis=0, skipna=True) / (2 * X.notna().sum(axis=0))
+    elif kind == "xarray":
+        over = {"dim": "sample"} if "sample" in X.dims else {"axis": 0}
+        freq = X.sum(skipna=True, **over) / (2 * X.notnull().sum(**over))
+    else:
+        X = np.asarray(X, float)
+        freq = np.nansum(X, axis=0) / (2 * np.logical_not(np.isnan(X)).sum(axis=0))
+    maf = np.minimum(freq, 1 - freq)
+    if hasattr(maf, "name"):
+        maf.name = "maf"
+    return maf
 
 
 def estimate_betas(y, W, E, G, maf=None, E1=None, E2=None, hK=None, *, device=0):

@@ -68,11 +68,14 @@ int DevBuf::ensure(size_t need) {
     if (e != hipSuccess) ptr = nullptr;
     CRM_HIP(e);
     bytes = need;
-    // CRM_POISON=1 (GPU AddressSanitizer is not available for this target): every fresh allocation is filled with
-    // 0xFF bytes -- NaN as a double, -1 as an int -- so that a read of memory nobody wrote shows up as a NaN result or
-    // as a range-checked index, whatever the previous tenant of the HBM left behind.
+    // Fresh allocations never carry the previous tenant's bytes into a kernel: they are zero-filled -- or, with
+    // CRM_POISON=1 (GPU AddressSanitizer is not available for this target), filled with 0xFF bytes: NaN as a double, -1
+    // as an int, so that a read of memory nobody wrote shows up as a NaN result or as a range-checked index.  The fill
+    // runs on the null stream and is waited for here: the contexts' streams are non-blocking and would not order
+    // themselves behind it.
     static const bool poison = getenv("CRM_POISON") && atoi(getenv("CRM_POISON")) != 0;
-    if (poison) CRM_HIP(hipMemset(ptr, 0xFF, need));
+    CRM_HIP(hipMemsetAsync(ptr, poison ? 0xFF : 0, need, nullptr));
+    CRM_HIP(hipStreamSynchronize(nullptr));
     return CRM_OK;
 }
 
@@ -148,6 +151,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     // (default k = 1: 7.3x less L2-fabric traffic for 0.6 % of the kernel's time);
     // CRM_CONTRACTION_SYNC=0 restores one workgroup per tile
     if (const char* e = getenv("CRM_CONTRACTION_SYNC")) c->tune.sync = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));
@@ -193,6 +197,7 @@ void crm_ctx_destroy(crm_ctx* c) {
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
+    if (c->sync_timeouts_host) (void)hipHostFree(c->sync_timeouts_host);
     delete c;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
     }
@@ -289,6 +294,8 @@ int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
     return CRM_OK;
     });
 }
+
+long crm_test_sync_fallbacks(const crm_ctx* c) { return c ? c->sync_fallbacks : -1; }
 
 int crm_test_set_contraction_sync(crm_ctx* c, int every) {
     return crm::guarded("crm_test_set_contraction_sync", [&]() -> int {

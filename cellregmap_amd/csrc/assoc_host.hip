@@ -21,6 +21,11 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
         set_error("association: variants [%ld, %ld) outside the panel (p = %ld)", first, first + count, panel->p);
         return CRM_ERR_ARG;
     }
+    if (ctx->in_scan) {
+        set_error("association: another scan is running on this context (started from a progress callback?)");
+        return CRM_ERR_UNSUPPORTED;
+    }
+    struct InScan { crm_ctx* c; explicit InScan(crm_ctx* c_) : c(c_) { c->in_scan = true; } ~InScan() { c->in_scan = false; } } in_scan(ctx);
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
@@ -66,7 +71,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     CRM_HIP(hipMemsetAsync(d_gy, 0, sizeof(double), st));
     CRM_HIP(hipMemsetAsync(d_gW, 0, sizeof(double) * ld_gW, st));
     NullFitArgs fa{};
-    fa.nrho = nrho; fa.c = c; fa.restricted = 0; fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.n = n;
+    fa.nrho = nrho; fa.c = c; fa.restricted = 0; fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.exact = ctx->nullfit_exact ? 1 : 0; fa.n = n;
     for (int i = 0; i < nrho; i++) {
         NullFitRho& R = fa.rho[i];
         R.T = d_zero; R.ldT = 0;
@@ -141,6 +146,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
         if (out_pvalue) CRM_HIP(hipMemcpyAsync(out_pvalue + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
         if (out_alt_lml) CRM_HIP(hipMemcpyAsync(out_alt_lml + done, d_lml, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));
+        if (ctx->progress) ctx->progress(done + nb, count, ctx->progress_user);   // (the reference's tqdm, :270)
     }
     return CRM_OK;
     });

@@ -673,7 +673,8 @@ extern "C" int crm_background_layout(const crm_background* bg, long* n_pad, long
     });
 }
 
-// what: 0 = Q0 (n_pad x ldq), 1 = S0 (ldq), 2 = Mix (ldh x ldq); device-to-device copies on the context's stream
+// what: 0 = Q0 (n_pad x ldq), 1 = S0 (ldq), 2 = Mix (ldh x ldq); copies on the context's stream, synchronised before
+// returning; the other side may be device memory of this GPU or host memory (the runtime tells them apart)
 static int background_slot(const crm_background* bg, int i, int what, void** ptr, size_t* bytes) {
     if (!bg || !bg->builder || !bg->builder->completed || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
     const DevBuf* b = what == 0 ? &bg->Q0[i] : what == 1 ? &bg->S0[i] : what == 2 ? &bg->Mix[i] : nullptr;
@@ -694,7 +695,7 @@ extern "C" int crm_background_export(const crm_background* bg, int i, int what, 
     }
     if (!dst_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(bg->ctx->device));
-    CRM_HIP(hipMemcpyAsync(dst_device, p, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
+    CRM_HIP(hipMemcpyAsync(dst_device, p, bytes, hipMemcpyDefault, bg->ctx->stream));   // (device or host destination)
     CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
     return CRM_OK;
     });
@@ -706,7 +707,7 @@ extern "C" int crm_background_import(crm_background* bg, int i, int what, const 
     size_t bytes = 0;
     if (!src_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(bg->ctx->device));
-    CRM_HIP(hipMemcpyAsync(p, src_device, bytes, hipMemcpyDeviceToDevice, bg->ctx->stream));
+    CRM_HIP(hipMemcpyAsync(p, src_device, bytes, hipMemcpyDefault, bg->ctx->stream));   // (device or host source)
     CRM_HIP(hipStreamSynchronize(bg->ctx->stream));
     if (what == 0) bg->q0_ready[i] = true;
     return CRM_OK;

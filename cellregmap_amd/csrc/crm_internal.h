@@ -58,9 +58,13 @@ struct crm_ctx {
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     void (*progress)(long done, long total, void* user) = nullptr;  // called after every block of a scan
     void* progress_user = nullptr;
+    bool in_scan = false;  // a scan is running on this context (its work buffers are in use: no second one from a callback)
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
+    bool nullfit_exact = false;  // null-fit likelihood in the reference's own operations (IEEE division, one log per entry)
     crm::GemmTune tune;   // contraction kernel variant (test hooks only change it)
-    crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form
+    crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form ([8]: waits that ran out)
+    unsigned* sync_timeouts_host = nullptr;  // pinned copy of counters[8] of the last persistent launch
+    long sync_fallbacks = 0;                 // times the context left the persistent form because its waits timed out
     // Work buffers of the constructor's eigen-solver, kept between constructor calls: handing 45 GB (config 5: five slabs
     // of 11 x 10 050^2) back to the driver costs 1.3 s per call and mapping them again up to as much; per-SNP
     // backgrounds of the effect-size path call the constructor once per variant.  Released by crm_ctx_trim,

@@ -368,11 +368,15 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_glds_kernel(c
                                     cells_total, split_stride, k0);
 }
 
-// Persistent form with a soft per-XCD generation sync (experiment, crm_test_set_contraction_sync): 8 x 64
-// workgroups; the workgroups that share an XCD (blockIdx % 8) walk a contiguous run of the flattened
-// (problem, slice, tile) list 64 tiles at a time and wait -- bounded, so no assumption about residency can
-// deadlock -- until the whole group has finished a generation before starting the next: the 64 tiles of a
-// generation then stream the same Q0 column tile and the same context rows at the same time.
+// Persistent form with a soft per-XCD generation sync (the default for Khatri-Rao launches of more than 1024 tiles;
+// crm_test_set_contraction_sync / CRM_CONTRACTION_SYNC=0 switch it off): 8 x 64 workgroups; the workgroups that
+// share an XCD (blockIdx % 8) walk a contiguous run of the flattened (problem, slice, tile) list 64 tiles at a time
+// and wait -- bounded, so no assumption about residency can deadlock -- until the whole group has finished a
+// generation before starting the next: the 64 tiles of a generation then stream the same Q0 column tile and the
+// same context rows at the same time.  The wait assumes the 512 workgroups are co-resident; when the GPU is shared
+// (a second process, another stream's kernels) they may not be and every generation would sit out its bound
+// (~5 ms).  A wait that runs out is counted in counters[8]; the host reads the count back with the next launch
+// and returns to one workgroup per tile for the rest of the context's life (crm_test_sync_fallbacks).
 template <bool KR, int KRQ, int ECQ, bool TR>
 __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmProblem* __restrict__ probs,
                                                                     int mtiles_max, int tiles_per_slice, int slices,
@@ -399,10 +403,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmPro
         if (threadIdx.x == 0 && (gen + 1) % every == 0) {
             __hip_atomic_fetch_add(&counters[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)(slots * ((gen + 1) / every));
-            for (int spin = 0; spin < 20000; spin++) {
-                if (__hip_atomic_load(&counters[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-                __builtin_amdgcn_s_sleep(8);
+            bool met = false;
+            for (int spin = 0; spin < 20000 && !met; spin++) {
+                met = __hip_atomic_load(&counters[group], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+                if (!met) __builtin_amdgcn_s_sleep(8);
             }
+            if (!met) __hip_atomic_fetch_add(&counters[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -420,6 +426,15 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
     }
     hipStream_t st = ctx->stream;
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
+    // waits of the previous persistent launch that ran out (read back asynchronously: a late value only delays the
+    // fallback by a launch): the workgroups are not co-resident on this GPU right now -- one workgroup per tile from here
+    if (ctx->tune.sync > 0 && ctx->sync_timeouts_host && *ctx->sync_timeouts_host >= 8) {
+        ctx->tune.sync = 0;
+        ctx->sync_fallbacks++;
+        if (getenv("CRM_VERBOSE") || getenv("CRM_TRACE_SETUP"))
+            fprintf(stderr, "[crm] persistent contraction: %u generation waits timed out (GPU shared?) -- falling back to one "
+                            "workgroup per tile\n", *ctx->sync_timeouts_host);
+    }
     const int sync_every = ctx->tune.sync;
     const bool sync = sync_every > 0 && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024;
     unsigned* sync_counters = nullptr;
@@ -427,6 +442,10 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
         CRM_TRY(ctx->sync_counters.ensure(64));
         sync_counters = ctx->sync_counters.as<unsigned>();
         CRM_HIP(hipMemsetAsync(sync_counters, 0, 64, st));
+        if (!ctx->sync_timeouts_host) {
+            CRM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->sync_timeouts_host), sizeof(unsigned), hipHostMallocDefault));
+            *ctx->sync_timeouts_host = 0;
+        }
     }
     const long cps = (cells / GEMM_BK + ksplit - 1) / ksplit * GEMM_BK;  // validated by launch_gemm_tn
     size_t lds = (size_t)2 * GEMM_BK * bn * sizeof(double);
@@ -490,6 +509,8 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
                            cps, cells, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());
+    if (sync)
+        CRM_HIP(hipMemcpyAsync(ctx->sync_timeouts_host, sync_counters + 8, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return CRM_OK;
 }
 

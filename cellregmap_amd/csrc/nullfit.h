@@ -30,6 +30,8 @@ struct NullFitArgs {
     NullFitRho rho[CRM_MAX_RHO];
     int nrho, c, restricted;
     int polish;        // secant refinement of the optimum on the analytic derivative
+    int exact;         // spectrum pass with IEEE division and one log per entry (the reference's own operations)
+    int pad2_;
     long n;            // cells (unpadded)
     const double* WW;  // [c x c]
     const double* Wy;  // [c]

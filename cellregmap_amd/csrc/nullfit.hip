@@ -119,7 +119,9 @@ __device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
 
 // One fit: variant b at grid point w, by one wavefront.  SH: the vectors every variant of a grid point shares --
 // Q0'W, Q0'y, S0 -- are read from LDS (sW [C][sld], sy, sS) instead of global memory.
-template <int C, bool SH>
+// EX: the spectrum pass in the reference's own operations -- an IEEE division and one log per entry -- instead of the
+// hardware reciprocal + Newton steps and the mantissa-product log-determinant (NullFitArgs::exact).
+template <int C, bool SH, bool EX>
 __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, const int w, const int lane,
                                             const double* sW, const double* sy, const double* sS, const int sld) {
     constexpr int P = C + 1;  // columns of X = [W, g]
@@ -219,9 +221,10 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
                 double wgt = ok[q] ? 1.0 : 0.0, wgt2 = 0.0;
                 if (weighted) {
                     const double D = ok[q] ? omd * s0[q] + delta : 1.0;
-                    const double inv = fast_rcp(D);
+                    const double inv = EX ? 1.0 / D : fast_rcp(D);
                     wgt = ok[q] ? inv : 0.0;
-                    lp.mul(D);
+                    if (EX) lsum += log(D);   // (D = 1 for the padding entries)
+                    else lp.mul(D);
                     if (grad) {
                         const double oms = 1.0 - s0[q];
                         lsum2 += ok[q] ? oms * inv : 0.0;
@@ -239,11 +242,11 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
                     }
                 }
             }
-            if (weighted && (++trips & 127) == 0) lp.renorm();
+            if (!EX && weighted && (++trips & 127) == 0) lp.renorm();
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) S[i] = wave_sum(S[i]);
-        if (weighted) lsum = wave_sum(lp.log_value());
+        if (weighted) lsum = wave_sum(EX ? lsum : lp.log_value());
         if (grad) {
 #pragma unroll
             for (int i = 0; i < NP; i++) S2[i] = wave_sum(S2[i]);
@@ -493,12 +496,12 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
     }
 }
 
-template <int C>
+template <int C, bool EX>
 #ifdef CRM_NULLFIT_WAVES
 __attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
 #endif
 __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
-    nullfit_fit<C, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
+    nullfit_fit<C, false, EX>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
 }
 
 // The same fits with the shared vectors of a grid point resident in LDS.  The one-wavefront-per-fit kernel above
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
 // grid point: likelihood-evaluation counts differ from variant to variant); when the queue is empty the workgroup moves
 // on to the next grid point with work left.  Only Q0'g still comes from L2.
 constexpr int NF_SHARED_WAVES = 12;
-template <int C>
+template <int C, bool EX>
 __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(NullFitArgs a, int variants, int sld,
                                                                              unsigned* __restrict__ queue) {
     extern __shared__ double nf_sm[];   // Q0'W [C][sld], Q0'y [sld], S0 [sld]
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
                                                            __HIP_MEMORY_SCOPE_AGENT);
             const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
             if (b >= (unsigned)variants) break;
-            nullfit_fit<C, true>(a, (int)b, w, lane, sW, sy, sS, sld);
+            nullfit_fit<C, true, EX>(a, (int)b, w, lane, sW, sy, sS, sld);
         }
         __syncthreads();
     }
@@ -592,7 +595,8 @@ __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nr
 
 template <int C>
 static void launch_c(hipStream_t st, const NullFitArgs& a, int variants) {
-    hipLaunchKernelGGL(nullfit_kernel<C>, dim3(variants, a.nrho), dim3(64), 0, st, a);
+    if (a.exact) hipLaunchKernelGGL((nullfit_kernel<C, true>), dim3(variants, a.nrho), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((nullfit_kernel<C, false>), dim3(variants, a.nrho), dim3(64), 0, st, a);
 }
 
 int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide, unsigned* queue) {
@@ -614,11 +618,16 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         CRM_HIP(hipGetDevice(&dev));
         CRM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         CRM_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned) * CRM_MAX_RHO, st));
+        const void* fn = a.exact ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, true>)
+                                 : reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false>);
         if (shared_lds > 60 * 1024)
-            CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nullfit_shared_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));
-        hipLaunchKernelGGL(nullfit_shared_kernel<1>, dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a, variants, sld,
-                           queue);
+            CRM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));
+        if (a.exact)
+            hipLaunchKernelGGL((nullfit_shared_kernel<1, true>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
+                               variants, sld, queue);
+        else
+            hipLaunchKernelGGL((nullfit_shared_kernel<1, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
+                               variants, sld, queue);
     } else if (force_wide || a.c > CRM_MAX_COV) {
         CRM_TRY(launch_nullfit_wide(st, a, variants));
     } else

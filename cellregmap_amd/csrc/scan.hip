@@ -734,6 +734,11 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
     }
     if (count == 0) return CRM_OK;
+    if (ctx->in_scan) {
+        set_error("scan: another scan is running on this context (started from a progress callback?); its work buffers are in use");
+        return CRM_ERR_UNSUPPORTED;
+    }
+    struct InScan { crm_ctx* c; explicit InScan(crm_ctx* c_) : c(c_) { c->in_scan = true; } ~InScan() { c->in_scan = false; } } in_scan(ctx);
     if (ctx->polish && g0->c > CRM_MAX_COV) {
         set_error("interaction scan: the null-fit polish is only built for up to %d covariate columns", CRM_MAX_COV);
         return CRM_ERR_UNSUPPORTED;
@@ -1012,7 +1017,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             NullFitArgs fa{};
-            fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0;
+            fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0; fa.exact = ctx->nullfit_exact ? 1 : 0;
             for (int i = 0; i < nrho; i++) {
                 NullFitRho& R = fa.rho[i];
                 R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;

@@ -77,8 +77,9 @@ int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k
  *   layout   -- n_pad, ldq, ldh (0 when there are no mixing matrices): slot sizes in doubles are
  *               Q0 n_pad * ldq, S0 ldq, Mix ldh * ldq.  With mixing matrices (cols < n) only S0 and Mix are
  *               exchanged: every rank holds H and forms Q0(rho) = H Mix(rho) itself when a scan first needs it
- *   export / import -- copy slot `what` (0 Q0, 1 S0, 2 Mix) of grid point i to / from DEVICE memory of the
- *               same GPU (e.g. a torch tensor's data_ptr()) -- the owner exports and broadcasts, the others import
+ *   export / import -- copy slot `what` (0 Q0, 1 S0, 2 Mix) of grid point i to / from a buffer of the caller:
+ *               device memory of the same GPU (e.g. a torch tensor's data_ptr(), what RCCL broadcasts) or host
+ *               memory (a CPU tensor under the gloo backend) -- the owner exports and broadcasts, the others import
  *   seal     -- all slots filled: finish (the object is then an ordinary background)
  * crm_background_create* == begin(all) + complete + seal. */
 int crm_background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb, const double* U,

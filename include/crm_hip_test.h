@@ -17,6 +17,9 @@ int crm_test_set_contraction(crm_ctx* ctx, int tile_width, int lds_dma);
  * contiguous tile runs per XCD and re-align (bounded wait) every `every` generations -- 7.5x less L2-fabric
  * traffic, 0.65 % slower; 0: one workgroup per tile. */
 int crm_test_set_contraction_sync(crm_ctx* ctx, int every);
+/* Times this context gave the persistent form up because its bounded waits ran out (the 512 workgroups were not
+ * co-resident: a shared GPU); from then on its launches use one workgroup per tile. */
+long crm_test_sync_fallbacks(const crm_ctx* ctx);
 /* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
 int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit);

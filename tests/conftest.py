@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the scans show the reference's tqdm bar by default; the suite keeps its logs clean (tests of the bar pass progress=True)
+os.environ.setdefault("CELLREGMAP_AMD_PROGRESS", "0")
+
 # A test that takes the process down (a GPU memory-access fault makes ROCr call abort(), a C++ exception
 # crossing the C-ABI ends in std::terminate) must leave its name behind: every test writes its nodeid to
 # stderr before it starts and to a trace file that survives the process (CRM_TEST_TRACE, default

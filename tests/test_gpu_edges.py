@@ -351,3 +351,69 @@ def test_wide_panel_on_a_small_cohort_against_the_oracle():
     total = oinfo["e2"] + oinfo["g2"] + oinfo["eps2"]
     flat = (oinfo["e2"] + oinfo["g2"] <= 1e-6 * total) & (info["e2"] + info["g2"] <= 1e-6 * total)
     assert np.all(same | flat)
+
+
+@pytest.mark.parametrize("variants", [1024, 1025, 4096])
+def test_queue_drawn_null_fits_cover_every_variant(monkeypatch, variants):
+    """The LDS-sharing null-fit workgroups draw (variant, grid point) work from a queue with one ticket per wavefront
+    (_cellregmap.py:345-357 fits all 11 grid points of every variant).  At the first size that uses the queue, one past it
+    and a full 4096-variant block: the scan must complete -- launch_nullfit poisons the trial records and
+    select_rho_kernel turns any slot no wavefront fitted into CRM_ERR_NUMERIC -- and agree bit for bit with one
+    independent wavefront per (variant, grid point), i.e. no variant fitted twice in place of another."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 25, 3, variants, seed=11)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E))
+    rng = np.random.default_rng(variants)
+    panel = crm.GenotypePanel(c.G + 0.05 * rng.normal(size=c.G.shape), groups=None)
+    pv, info, st = obj.scan_interaction(panel, return_stats=True)
+    assert np.all(np.isfinite(st["lml"])) and np.all(np.isfinite(pv))
+    monkeypatch.setenv("CRM_NULLFIT_PER_WAVE", "1")
+    pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
+    monkeypatch.delenv("CRM_NULLFIT_PER_WAVE")
+    assert np.array_equal(pv, pv1)
+    for k in ("delta", "lml", "scale", "Q"):
+        assert np.array_equal(st[k], st1[k]), k
+    assert np.array_equal(info["rho1"], info1["rho1"])
+
+
+def test_progress_is_reported_and_a_failing_callback_is_not_swallowed():
+    """The reference shows a tqdm bar over variants (_cellregmap.py:340); here a callable sees (done, total) block by
+    block, a scan started from inside a callback is refused with a status code, and an exception raised by the user's
+    callback surfaces after the scan (ctypes would drop it otherwise)."""
+    import cellregmap_amd as crm
+    from cellregmap_amd import _engine, _lib
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 20, 3, 300, seed=5)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib, ctx = _lib.load(), _engine._context(0)
+    _lib.check(lib.crm_set_block_variants(ctx, 128))
+    try:
+        seen = []
+        pv, _ = obj.scan_interaction(c.G, progress=lambda d, t: seen.append((d, t)))
+        assert seen == [(128, 300), (256, 300), (300, 300)]
+        pv0, _ = obj.scan_interaction(c.G, progress=False)
+        assert np.array_equal(pv, pv0)
+
+        def nested(done, total):   # a scan from inside a callback would reuse the running scan's work buffers: refused
+            obj.scan_interaction(c.G[:, :130], progress=False)
+
+        with pytest.raises(_lib.CrmError, match="another scan is running"):
+            obj.scan_interaction(c.G, progress=nested)
+        pv1, _ = obj.scan_interaction(c.G, progress=False)     # ... and the context is usable afterwards
+        assert np.array_equal(pv, pv1)
+
+        def bad(done, total):
+            raise KeyError("user callback failed")
+
+        with pytest.raises(KeyError, match="user callback failed"):
+            obj.scan_interaction(c.G, progress=bad)
+        assert not _engine._progress_stack[0]
+        # association scans report too (the reference's tqdm at :270)
+        seen.clear()
+        obj.scan_association(c.G, progress=lambda d, t: seen.append((d, t)))
+        assert seen and seen[-1] == (300, 300)
+    finally:
+        _lib.check(lib.crm_set_block_variants(ctx, 0))

@@ -43,3 +43,22 @@ def test_predict_interaction_is_the_dense_blup():
         # BLUP of the GxC effects: cov(beta_gxe, y) K^-1 (y - M beta), cov = v0 rho E0 (g o E0)'
         blup = v0 * rho * c.E @ (gE.T @ (Ki @ (c.y - M @ beta))) / np.sqrt(2 * maf[i] * (1 - maf[i]))
         assert_allclose(bgxe[0, :, i], blup, rtol=1e-6, atol=1e-9)
+
+
+def test_compute_maf_keeps_the_container_like_the_reference():
+    """_cellregmap.py:620-638: a DataFrame gives a Series named "maf"; missing calls (NaN) leave the denominator."""
+    import pandas as pd
+
+    from cellregmap_amd import compute_maf
+
+    X = np.random.RandomState(0).randint(0, 3, size=(100, 10)).astype(float)
+    X[3, 2] = np.nan
+    X[7, 2] = np.nan
+    df = pd.DataFrame(X, columns=[f"snp{i}" for i in range(10)])
+    maf = compute_maf(df)
+    assert isinstance(maf, pd.Series) and maf.name == "maf" and list(maf.index) == list(df.columns)
+    want = np.nansum(X, axis=0) / (2 * (~np.isnan(X)).sum(axis=0))
+    want = np.minimum(want, 1 - want)
+    np.testing.assert_allclose(maf.values, want, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(compute_maf(X), want, rtol=0, atol=1e-15)
+    assert isinstance(compute_maf(X), np.ndarray)
