@@ -85,23 +85,32 @@ def main():
     ap.add_argument("--collapsed", type=int, default=1, help="also time the donor-collapsed path (N=1)")
     ap.add_argument("--full-panel", type=int, default=1, help="strong-scaling leg on the config's fixed panel")
     ap.add_argument("--genes", type=int, default=64, help="phenotypes of the config-4 leg (0 = skip)")
-    ap.add_argument("--genes-variants", type=int, default=2048, help="variants of the config-4 leg, all ranks together")
+    ap.add_argument("--genes-variants", type=int, default=0,
+                    help="variants of the config-4 leg, all ranks together (0 = the config's whole fixed panel when "
+                         "--full-panel is on, i.e. BASELINE config 4 itself at --genes 64; else the weak-scaling panel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    share_gpu = bool(os.environ.get("CRM_BENCH_SHARE_GPU"))
+    if not share_gpu and local_rank == 0:
+        import torch  # (counting devices does not initialise the GPU on this image)
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); "
+                             f"run with --gpus {max(have, 1)}, or CRM_BENCH_SHARE_GPU=1 for a dry run of the N > 1 code "
+                             f"path on one GPU (not a scaling measurement)")
     if world == 1 and args.gpus > 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as child processes.  Nothing in this
-        # process has touched the GPU yet (torch is not even imported), and it never will: it only
-        # relays the children's output and exit code.
+        # process has touched the GPU yet, and it never will: it only relays the children's output and exit code.
         raise SystemExit(_launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
                          f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` directly)")
     import torch
 
-    share_gpu = bool(os.environ.get("CRM_BENCH_SHARE_GPU"))
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
@@ -197,6 +206,8 @@ def main():
 
     # ---- strong scaling on the fixed panel: upload + scan + gather, end to end with the constructor -----------
     full_panel = None
+    fpanel_kept = None
+    fpv = None
     if G_full is not None:
         t0 = time.perf_counter()
         fpanel = GenotypePanel(G_full, device=local_rank, groups=None)  # dense: general genotypes
@@ -224,6 +235,10 @@ def main():
                               "panel upload (host float64) + scan + gather, max over ranks"}
         if f_count >= weak_blocks * batch:
             panel = fpanel
+            fpanel_kept = fpanel
+        elif args.genes > 1 and args.genes_variants <= 0:
+            fpanel_kept = fpanel     # the config-4 leg scans this rank's whole shard of the fixed panel
+            panel = GenotypePanel(G_weak, device=local_rank, groups=None)
         else:
             del fpanel
             panel = GenotypePanel(G_weak, device=local_rank, groups=None)
@@ -265,6 +280,7 @@ def main():
 
     # ---- config 4's shape: `genes` phenotypes against one panel, the variants sharded over the ranks ---------------
     config4 = None
+    multi_keep = None
     if args.genes > 1:
         from cellregmap_amd import scan_interaction_many
 
@@ -276,29 +292,45 @@ def main():
             ci._bind_gene()
             crms.append(ci)
         handles = (ctypes.c_void_p * len(crms))(*[c._gene.value for c in crms])
-        mfirst, mb = variant_shard(min(args.genes_variants, p_need * world), rank, world)
-        mb = min(mb, p_need)
+        # the panel of this leg: this rank's shard of the config's fixed panel (config 4 = config 3 x 64 genes: every
+        # rank scans all genes on its shard of the 50 000 variants), or a sample of it / the weak-scaling panel
+        whole = args.genes_variants <= 0 and fpanel_kept is not None
+        if whole:
+            mpanel, mb, nv = fpanel_kept, f_count, p_total
+        else:
+            want = args.genes_variants if args.genes_variants > 0 else 2048
+            _, mb = variant_shard(min(want, p_need * world), rank, world)
+            mb = min(mb, p_need)
+            mpanel, nv = panel, mb * world
         mpv = np.empty((len(crms), mb)); mrho = np.empty((len(crms), mb))
 
-        def run_multi():
-            _lib.check(lib.crm_scan_interaction_multi(handles, len(crms), panel.handle, 0, mb, None, None,
-                                                      _lib.ptr(mpv), _lib.ptr(mrho), None, None, None, None))
+        def run_multi(count):
+            _lib.check(lib.crm_scan_interaction_multi(handles, len(crms), mpanel.handle, 0, count, None, None,
+                                                      _lib.ptr(mpv[:, :count].copy() if count < mb else mpv),
+                                                      _lib.ptr(mrho[:, :count].copy() if count < mb else mrho),
+                                                      None, None, None, None))
             _lib.check(lib.crm_ctx_synchronize(ctx))
 
-        run_multi()
+        run_multi(min(mb, 512))    # warm-up: work buffers, Q0 of the selected grid points
         fence()
         t0 = time.perf_counter()
-        run_multi()
+        run_multi(mb)
         fence()
         t_multi = max_over_ranks(time.perf_counter() - t0)
-        nv = mb * world
+        same_panel = mpanel is panel
         config4 = {"value": round(len(crms) * nv / t_multi, 1), "unit": "variant-tests/s", "genes": len(crms),
                    "variants": nv, "variants_per_rank": mb, "seconds": round(t_multi, 3),
-                   "distinct_rho_per_variant": float(np.mean([len(set(mrho[:, j])) for j in range(mb)])),
-                   "max_rel_dp_gene0_vs_single_gene_scan": float(np.max(np.abs(mpv[0] - pv_dense[:mb]) / np.maximum(pv_dense[:mb], 1e-300))),
-                   "note": "BASELINE config 4's shape on a sample of the panel: every rank scans all genes on its shard "
-                           "of the variants; G'Q0(rho) shared by the genes, one Khatri-Rao contraction per variant against "
-                           "H (Q0(rho) = H Mix(rho)), each selected (variant, rho*) pair finished with Mix(rho*)"}
+                   "distinct_rho_per_variant": float(np.mean([len(set(mrho[:, j])) for j in range(min(mb, 4096))])),
+                   "max_rel_dp_gene0_vs_single_gene_scan": float(np.max(np.abs(mpv[0, :min(mb, p_need)] - pv_dense[:min(mb, p_need)]) /
+                                                                   np.maximum(pv_dense[:min(mb, p_need)], 1e-300))) if same_panel else
+                                                             float(np.max(np.abs(mpv[0] - fpv) / np.maximum(fpv, 1e-300))),
+                   "note": ("BASELINE config 4 itself: " if whole and len(crms) == 64 else "BASELINE config 4's shape: ") +
+                           f"{len(crms)} phenotypes x the {'whole fixed ' + str(p_total) + '-variant panel' if whole else 'sample of the panel'}, "
+                           "every rank scans all genes on its shard of the variants; G'Q0(rho) shared by the genes, one Khatri-Rao "
+                           "contraction per variant against H (Q0(rho) = H Mix(rho)), each selected (variant, rho*) pair finished "
+                           "with Mix(rho*); gene 0 checked against the single-gene scan here, (gene, variant) pairs against the "
+                           "oracle in the cpu_baseline leg"}
+        multi_keep = (mpv, mrho, [c._y for c in crms], whole)
         del crms[1:]
 
     if rank != 0:
@@ -320,21 +352,29 @@ def main():
         "flops_per_launch": kr_fl.value / max(kr_n.value, 1),
         "share_of_step_time": round(kr_s / elapsed, 4),
     }
-    # L2-fabric traffic of that kernel: separate rocprofv3 --pmc passes over THIS script (profiles/), valid for
-    # the launch shape they were collected on
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    # L2-fabric traffic of that kernel is NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes,
+    # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
+    # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
+    form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
+            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode()}
+    roofline["kernel_form"] = form
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             shape = pmc["launch_shape"]
-            if (args.config == shape["config"] and roofline["launches"] > 0
+            same_form = pmc.get("kernel_form", {"contraction_sync": True, "tail_launch": True, "library": "0.1.0"}) == form
+            if (args.config == shape["config"] and roofline["launches"] > 0 and same_form
                     and abs(roofline["flops_per_launch"] / shape["flops_per_launch"] - 1.0) < 0.05):
                 roofline["traffic"] = pmc["traffic_bytes_per_launch"]
                 roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, fabric side incl. Infinity Cache)"
-                roofline["traffic_source"] = f"profiles/{name}: {pmc.get('collected_on', 'rocprofv3 --pmc')}"
+                roofline["traffic_source"] = (f"EARLIER PROFILE, not this run: profiles/{name} "
+                                              f"({pmc.get('collected_on', 'rocprofv3 --pmc')})")
                 roofline["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_launch"]
                 break
         except (OSError, KeyError, ValueError):
             pass
+    if roofline["traffic"] is None:
+        roofline["traffic_note"] = "no committed PMC profile matches this launch shape and kernel form"
     rstar = float(np.mean([ranks[int(round(x * 10))] if len(ranks) > 1 else ranks[0] for x in rho1[: min(steps, weak_blocks) * batch]]))
     f_alg = algorithmic_flops(n, ranks, rstar, k0, c_cov)
     f_exe = executed_flops(n, cols, ranks, rstar, k0, c_cov, fast_rotation=True)
@@ -398,6 +438,26 @@ def main():
         blas = threadpoolctl.threadpool_info()
         nthreads = max([b.get("num_threads", 1) for b in blas] or [1])
         dev = np.abs(opv - pv_dense[pick]) / np.maximum(opv, 1e-300)
+        # (gene, variant) pairs of the config-4 leg against the oracle (other phenotypes, same decomposition)
+        c4_check = None
+        if multi_keep is not None:
+            import copy
+
+            mpv_, mrho_, ys, whole_ = multi_keep
+            Gsrc = G_full if whole_ else G_weak
+            prng = np.random.default_rng(4)
+            worst, pairs, same_rho = 0.0, 0, True
+            for gi in sorted({1, len(ys) // 2, len(ys) - 1}):
+                cols_ = np.sort(prng.choice(mpv_.shape[1], size=3, replace=False))
+                og = copy.copy(ocrm)
+                og._y = ys[gi]
+                gp, ginfo = og.scan_interaction(np.ascontiguousarray(Gsrc[:, cols_]))
+                worst = max(worst, float(np.max(np.abs(gp - mpv_[gi, cols_]) / np.maximum(gp, 1e-300))))
+                same_rho = same_rho and bool(np.array_equal(ginfo["rho1"], mrho_[gi, cols_]))
+                pairs += len(cols_)
+            c4_check = {"pairs": pairs, "max_rel_dp_vs_oracle": worst, "rho_star_identical": same_rho}
+            if config4 is not None:
+                config4["oracle_check"] = c4_check
         cpu = {
             "value": round(m / t_cpu, 4), "unit": "variant-tests/s", "cores": int(nthreads), "kind": "port",
             "sample": f"{m} variants drawn at random (seed 2024) from the {min(steps, weak_blocks) * batch} this run scanned, "
@@ -432,6 +492,9 @@ def main():
             8.0 * n + 8.0 * (n * float(sum(ranks)) + n * k0 + n * (c_cov + 1)) / p_total + 40.0),
         "setup_s": {"synthetic_data": round(t_data, 2), "background_constructor": round(t_ctor, 2)},
         "speedup_vs_cpu_baseline": None if not cpu else round(value / cpu["value"], 1),
+        "multi_gpu": {"ranks": world, "collective": "all_gather of the per-variant results (RCCL)" if world > 1 else None,
+                      "note": "per-N values are whatever this run measured on this node; the repository holds no measured N > 1 "
+                              "run of its own (its build sessions only ever had one GPU) and models no scaling figure"},
         "full_panel": full_panel,
         "config4": config4,
         "donor_collapsed": collapsed,

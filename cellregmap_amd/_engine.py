@@ -624,6 +624,14 @@ class CellRegMap:
         _lib.check(lib.crm_gene_create(self._bg.handle, _lib.ptr(y), _lib.ptr(Wb), Wb.shape[1], _lib.ptr(E0),
                                        E0.shape[1], ctypes.byref(h)))
         self._gene = h
+        n, rmax = self.n_samples, max(self._bg.rank(i) for i in range(len(self._rho1)))
+        if rmax + Wb.shape[1] + 1 >= n:
+            import warnings
+
+            warnings.warn(f"saturated model: the background covariance has rank {rmax} and with the {Wb.shape[1]} covariate "
+                          f"column(s) and the variant it spans all {n} cells; the reference's likelihood then divides "
+                          "rounding noise by delta and its results (and these) are not reproducible to the usual "
+                          "tolerances (scan_interaction_info flags such variants)", RuntimeWarning, stacklevel=3)
         # (the background object rides along so that it outlives the gene whatever the collection order)
         self._gene_fin = weakref.finalize(self, _release_gene, lib, h, self._bg)
         return h
@@ -690,17 +698,21 @@ class CellRegMap:
 
     def scan_interaction_info(self, G, idx_E=None, idx_G=None):
         """The p-values together with chiscore's ``info`` of ``davies_pvalue(Q, F, True)`` (which the reference
-        computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault"})``."""
+        computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"})``.
+        ``model_flags`` (bits ``MODEL_SATURATED`` = 1, ``MODEL_DELTA_AT_ZERO`` = 2, ``MODEL_G_IN_SPAN_W`` = 4, see
+        include/crm_hip.h) / ``degenerate`` mark the variants where the reference's own result is decided by rounding
+        noise (saturated model, null fit ending at delta = 0)."""
         lib = _lib.load()
         panel = self._panel(G)
         n, p = panel.shape
         gene = self._bind_gene()
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         pv, liu = np.empty(p), np.empty(p)
-        ifault = np.empty(p, np.int32)
+        ifault, flags = np.empty(p, np.int32), np.empty(p, np.int32)
         _lib.check(lib.crm_scan_interaction_info(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
-                                                 _lib.ptr(ifault), _lib.ptr(liu)))
-        return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault}
+                                                 _lib.ptr(ifault), _lib.ptr(liu), _lib.ptr(flags)))
+        return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault,
+                    "model_flags": flags, "degenerate": (flags & 3) != 0}
 
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False, progress=None):

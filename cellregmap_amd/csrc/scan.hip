@@ -696,6 +696,7 @@ struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: co
     double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
     int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
     double* liu = nullptr;   // the modified-Liu p-value (chiscore's info["liu_pval"])
+    int* flags = nullptr;    // CRM_MODEL_* bits per variant (include/crm_hip.h)
 };
 
 // One pass over variants [first, first + count) for one or several genes that share the background,
@@ -1272,9 +1273,18 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             if (o.F) CRM_HIP(hipMemcpyAsync(o.F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
             if (o.ifault) CRM_HIP(hipMemcpyAsync(o.ifault + done, d_if, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             if (o.liu) CRM_HIP(hipMemcpyAsync(o.liu + done, d_liu, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+            int rmax = 0;
+            for (int i = 0; i < nrho; i++) rmax = std::max(rmax, bg->r[i]);
+            const bool saturated = (long)rmax + c + 1 >= n;
             for (int b = 0; b < nb; b++) {
                 const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
                 const double rho = bg->rho[f.rho_index];
+                if (o.flags) {
+                    int fl = saturated ? CRM_MODEL_SATURATED : 0;
+                    if (!(f.delta > 1e-8)) fl |= CRM_MODEL_DELTA_AT_ZERO;
+                    if (!f.use_g) fl |= CRM_MODEL_G_IN_SPAN_W;
+                    o.flags[done + b] = fl;
+                }
                 if (o.rho1) o.rho1[done + b] = rho;
                 if (o.e2) o.e2[done + b] = f.v0 * rho;
                 if (o.g2) o.g2[done + b] = f.v0 * (1 - rho);
@@ -1309,13 +1319,15 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
 }
 
 int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
-                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue) {
+                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue,
+                              int* out_model_flags) {
     return crm::guarded("crm_scan_interaction_info", [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> genes{gene};
     ScanOut o{out_pvalue, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     o.ifault = out_ifault;
     o.liu = out_liu_pvalue;
+    o.flags = out_model_flags;
     std::vector<ScanOut> outs{o};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
     });

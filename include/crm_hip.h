@@ -143,7 +143,19 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
  * integration gave up and the p-value IS the modified-Liu one, 2: round-off flagged, the integral kept; -2: no
  * eigenvalue above the SKAT threshold, p = NaN where the reference raises), out_liu_pvalue = info["liu_pval"]. */
 int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
-                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue);
+                              const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue,
+                              int* out_model_flags);
+/* out_model_flags (may be NULL): per variant, where the reference's own answer is decided by rounding noise rather than by
+ * the data, so that two faithful implementations (or two BLAS builds under the reference) may report different numbers:
+ *   SATURATED      the background's columns and the fixed effects [W, g] together span all n cells (rank + c + 1 >= n):
+ *                  the complement terms (u'v - (Q0'u)'(Q0'v)) / delta of glimix-core's likelihood are rounding noise
+ *                  divided by delta (mode A with at least as many contexts as cells is the extreme case);
+ *   DELTA_AT_ZERO  the null fit ended at delta <= 1e-8: the likelihood was flat or still rising towards delta = 0 (e.g.
+ *                  mode B with two donors, where span(1, g) absorbs the whole random effect), same noise / delta terms;
+ *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X). */
+#define CRM_MODEL_SATURATED 1
+#define CRM_MODEL_DELTA_AT_ZERO 2
+#define CRM_MODEL_G_IN_SPAN_W 4
 
 /* Several phenotypes against one panel in one pass ("genes" that share the background, W and E0):
  * everything that does not depend on y -- G'Q0(rho), the Khatri-Rao contraction per (variant, rho)

@@ -194,7 +194,8 @@ def test_davies_info_is_surfaced():
     pv, _ = crm.scan_interaction(c.G)
     pv2, info = crm.scan_interaction_info(c.G)
     assert np.array_equal(pv, pv2)
-    assert set(info) == {"liu_pval", "Is_Converged", "ifault"} and info["ifault"].dtype == np.int32
+    assert set(info) == {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"} and info["ifault"].dtype == np.int32
+    assert not info["degenerate"].any() and not info["model_flags"].any()      # a well-posed problem
     _, _, ost = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G, return_stats=True)
     for j in range(20):
         _, oinfo = davies_pvalue(ost["Q"][j], ost["F"][j], True)
@@ -417,3 +418,37 @@ def test_progress_is_reported_and_a_failing_callback_is_not_swallowed():
         assert seen and seen[-1] == (300, 300)
     finally:
         _lib.check(lib.crm_set_block_variants(ctx, 0))
+
+
+def test_degenerate_models_are_flagged():
+    """The problem families the fuzz generator leaves out (tests/fuzz_cases.py) because the reference's own answer is
+    decided by rounding noise there are reported, not silently scanned: a saturated model (background columns + fixed
+    effects span all cells; mode A with as many contexts as cells is the extreme case) warns at bind time and sets
+    MODEL_SATURATED on every variant; mode B with two donors ends its null fits at delta = 0 and sets
+    MODEL_DELTA_AT_ZERO; a variant inside span(W) sets MODEL_G_IN_SPAN_W."""
+    import warnings
+
+    from cellregmap_amd import CellRegMap
+    from fuzz_cases import random_problem
+
+    # saturated: 40 cells, 45 contexts (mode A)
+    y, E, W, G, kw = random_problem(40, 45, 1, 6, 5, seed=1, mode="A")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        crm = CellRegMap(y, E, W=W, **kw)
+        pv, info = crm.scan_interaction_info(G)
+    assert any("saturated model" in str(w.message) for w in caught)
+    assert np.all(info["model_flags"] & 1) and info["degenerate"].all()
+    # mode B with two donors: the restricted likelihood is flat in delta at rho = 0
+    y, E, W, G, kw = random_problem(120, 3, 1, 8, 2, seed=2, mode="B")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # not saturated: no warning
+        pv, info = CellRegMap(y, E, W=W, **kw).scan_interaction_info(G)
+    assert np.all((info["model_flags"] & 1) == 0)
+    assert np.any(info["model_flags"] & 2), info["model_flags"]
+    # a variant inside span(W)
+    y, E, W, G, kw = random_problem(150, 3, 3, 5, 6, seed=3, mode="B")
+    G = G.copy()
+    G[:, 2] = W @ np.array([0.5, -1.0, 2.0])
+    pv, info = CellRegMap(y, E, W=W, **kw).scan_interaction_info(G)
+    assert info["model_flags"][2] & 4 and not np.any(np.delete(info["model_flags"], 2) & 4)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # L2-fabric traffic of the dominant kernel for the launch shape bench.py itself issues: separate rocprofv3 --pmc
 # passes (the TCC block cannot hold FETCH_SIZE and WRITE_SIZE together), restricted to the Khatri-Rao kernel.
-#   gpurun -- 'bash tools/pmc_bench.sh [sync]'      -> gpurun_out/pmc_r02[_sync]/
+#   gpurun -- 'bash tools/pmc_bench.sh [sync]'      -> gpurun_out/pmc_r03[_sync]/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-tag=pmc_r02
-if [ -n "$1" ]; then export CRM_CONTRACTION_SYNC=$1; tag=pmc_r02_sync$1; fi
+tag=pmc_r03
+if [ -n "$1" ]; then export CRM_CONTRACTION_SYNC=$1; tag=pmc_r03_sync$1; fi
 out=gpurun_out/$tag
 mkdir -p $out
 BENCH="bench.py --steps 2 --warmup 1 --cpu-variants 0 --full-panel 0 --genes 0 --collapsed 0"

@@ -1,11 +1,11 @@
-"""Turn the CSVs of tools/pmc_bench.sh into profiles/r02_pmc_summary.json.
+"""Turn the CSVs of tools/pmc_bench.sh into profiles/r03_pmc_summary.json.
 
 A block of 4096 variants is one large Khatri-Rao launch (gemm_tn_glds_sync_kernel) plus, when the spectrum is a little
 longer than a multiple of the 128-column tile, a second launch of 160-column tiles for the last columns; the counters of
 both are added per block.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 bytes; FETCH_SIZE is doubled for
 16-byte-per-lane streams (the gfx950 correction of MI355X_MICROARCH.md's HBM section).
 
-    python tools/pmc_summary.py gpurun_out/pmc_r02 [gpurun_out/pmc_r02_sync0] > profiles/r02_pmc_summary.json"""
+    python tools/pmc_summary.py gpurun_out/pmc_r03 [gpurun_out/pmc_r03_sync0] > profiles/r03_pmc_summary.json"""
 import csv
 import json
 import os
@@ -60,6 +60,8 @@ def main():
                         "gemm_tn_glds_kernel<true,...,160> launch over the last 136, summed), one pass per counter group, "
                         "kernel filter gemm_tn_glds_(sync_)?kernel<true; summary by tools/pmc_summary.py",
         "launch_shape": {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13},
+        # bench.py quotes this profile only for the same kernel form (bench.py: roofline["kernel_form"])
+        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.1.0"},
         "algorithmic_bytes_per_launch": alg,
         "algorithmic_bytes_note": "Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
                                   "(SURVEY 8d per-unit figure x 4096)",
