@@ -311,22 +311,29 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
     }
     CRM_BG_HIP(hipStreamSynchronize(st));
     trace.lap("half factor + Gram");
-    // eigen-decompositions of the owned grid points, all at once (eigh*.hip)
-    const int nmine = (int)bb->mine.size();
-    if (nmine > 0) {
+    // eigen-decompositions of the owned grid points (eigh*.hip), all at once -- except that a grid point whose second
+    // weight vanishes (rho = 1 in the thin branch: hS = [E1, 0]) has a scaled Gram matrix that is zero outside its
+    // leading k1 x k1 block: that block is decomposed on its own (k1 contexts against cols = k1 + kb columns: 50
+    // against 5 050 at config 3, i.e. one of the eleven full-size decompositions less)
+    std::vector<int> full_pts, lead_pts;
+    for (int i : bb->mine) ((thin && kb > 0 && rho[i] >= 1.0) ? lead_pts : full_pts).push_back(i);
+    auto decompose = [&](const std::vector<int>& pts, const long sub) -> int {   // sub: order of the matrices of this batch
+        const int npts = (int)pts.size();
+        if (npts == 0) return CRM_OK;
+        const long subp = round_up(sub, 128);
         // the context's cached work buffers (grown on demand; see crm_ctx::eigh_ws)
         EighWork& ew = *acquire_eigh_workspace(ctx);
         struct EGuard { crm_ctx* c; ~EGuard() { release_eigh_workspace(c); } } eguard{ctx};
-        CRM_BG(eigh_alloc(ew, nmine, dim));
+        CRM_TRY(eigh_alloc(ew, npts, sub));
         trace.lap("  eigen workspace");
-        CRM_BG_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)nmine * ew.slab, st));
-        for (int q = 0; q < nmine; q++) {
-            const int i = bb->mine[q];
+        CRM_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)npts * ew.slab, st));
+        for (int q = 0; q < npts; q++) {
+            const int i = pts[q];
             const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
             double* Ai = ew.A.as<double>() + (size_t)q * ew.slab;
             if (thin) {
-                dim3 grid((unsigned)((cols + 255) / 256), (unsigned)cols);
-                hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)cols, k1, a, b,
+                dim3 grid((unsigned)((sub + 255) / 256), (unsigned)sub);
+                hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)sub, k1, a, b,
                                    Ai, ew.ld);
             } else {
                 // Sigma(rho) = rho E1 E1' + (1 - rho) B B'
@@ -335,55 +342,59 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
                                    dG.as<double>() + dimp * dimp, dimp, (int)n, rho[i], 1.0 - rho[i], Ai);
             }
         }
-        CRM_BG_HIP(hipGetLastError());
-        std::vector<double> lam((size_t)nmine * dim);
+        CRM_HIP(hipGetLastError());
+        std::vector<double> lam((size_t)npts * sub);
         double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
         trace.lap("  scaled Gram matrices");
-        CRM_BG(eigh_batched(ctx, ew, lam.data(), &Zt));
+        CRM_TRY(eigh_batched(ctx, ew, lam.data(), &Zt));
         trace.lap("eigen-decompositions");
         ScopedBuf wKeep, wLam;
-        CRM_BG(wKeep.ensure(sizeof(int) * dimp));
-        CRM_BG(wLam.ensure(sizeof(double) * dimp));
-        for (int q = 0; q < nmine; q++) {
-            const int i = bb->mine[q];
-            const double* hW = &lam[(size_t)q * dim];   // ascending
+        CRM_TRY(wKeep.ensure(sizeof(int) * subp));
+        CRM_TRY(wLam.ensure(sizeof(double) * subp));
+        for (int q = 0; q < npts; q++) {
+            const int i = pts[q];
+            const double* hW = &lam[(size_t)q * sub];   // ascending
             const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
             std::vector<int> keep;
             if (thin) {
-                const double cut = rel_tol * std::max(hW[dim - 1], 0.0);
-                for (long j = dim - 1; j >= 0; j--)  // descending, like singular values
+                const double cut = rel_tol * std::max(hW[sub - 1], 0.0);
+                for (long j = sub - 1; j >= 0; j--)  // descending, like singular values
                     if (hW[j] > cut && hW[j] > 0.0) keep.push_back((int)j);
             } else {
                 const double eps_small = 1.4901161193847656e-08;  // sqrt(machine eps), _math.py:204
-                for (long j = 0; j < dim; j++)                    // ascending, like eigh
+                for (long j = 0; j < sub; j++)                    // ascending, like eigh
                     if (hW[j] >= eps_small) keep.push_back((int)j);
             }
             const int r = (int)keep.size();
             bg->r[i] = r;
             bb->S0_host[i].resize(r);
             for (int j = 0; j < r; j++) bb->S0_host[i][j] = hW[keep[j]];
-            // keep what `complete` needs: thin -> mixing matrix M (cols x r); else -> the vectors themselves
+            // keep what `complete` needs: thin -> mixing matrix M (cols x r; rows beyond `sub` stay zero); else -> the
+            // vectors themselves
             const long ldm = round_up(std::max(r, 1), 128);
-            CRM_BG(bb->Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
-            CRM_BG_HIP(hipMemsetAsync(bb->Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
+            CRM_TRY(bb->Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
+            CRM_HIP(hipMemsetAsync(bb->Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
             if (r > 0) {
                 const double* Vi = Zt + (size_t)q * ew.slab;
-                CRM_BG_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
-                CRM_BG_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * dim, hipMemcpyHostToDevice, st));
+                CRM_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
+                CRM_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * sub, hipMemcpyHostToDevice, st));
                 if (thin) {
-                    dim3 grid((unsigned)((r + 255) / 256), (unsigned)cols);
+                    dim3 grid((unsigned)((r + 255) / 256), (unsigned)sub);
                     hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wLam.as<double>(),
-                                       wKeep.as<int>(), r, (int)cols, k1, a, b, bb->Mbuf[i].as<double>(), ldm);
+                                       wKeep.as<int>(), r, (int)sub, k1, a, b, bb->Mbuf[i].as<double>(), ldm);
                 } else {
                     dim3 grid((unsigned)((r + 255) / 256), (unsigned)n);
                     hipLaunchKernelGGL(gather_vectors_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wKeep.as<int>(), r, n,
                                        bb->Mbuf[i].as<double>(), ldm);
                 }
-                CRM_BG_HIP(hipGetLastError());
+                CRM_HIP(hipGetLastError());
             }
-            CRM_BG_HIP(hipStreamSynchronize(st));   // keep / hW are reused by the next grid point
+            CRM_HIP(hipStreamSynchronize(st));   // keep / hW are reused by the next grid point
         }
-    }
+        return CRM_OK;
+    };
+    CRM_BG(decompose(full_pts, dim));
+    CRM_BG(decompose(lead_pts, k1));
     trace.lap("  mixing matrices");
     *out = bg;
     return CRM_OK;

@@ -150,8 +150,8 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *   SATURATED      the background's columns and the fixed effects [W, g] together span all n cells (rank + c + 1 >= n):
  *                  the complement terms (u'v - (Q0'u)'(Q0'v)) / delta of glimix-core's likelihood are rounding noise
  *                  divided by delta (mode A with at least as many contexts as cells is the extreme case);
- *   DELTA_AT_ZERO  the null fit ended at delta <= 1e-8: the likelihood was flat or still rising towards delta = 0 (e.g.
- *                  mode B with two donors, where span(1, g) absorbs the whole random effect), same noise / delta terms;
+ *   DELTA_AT_ZERO  the null fit at rho* ended at delta <= 1e-8: the likelihood was flat or still rising towards delta = 0
+ *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
  *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X). */
 #define CRM_MODEL_SATURATED 1
 #define CRM_MODEL_DELTA_AT_ZERO 2

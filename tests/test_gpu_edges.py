@@ -424,7 +424,7 @@ def test_degenerate_models_are_flagged():
     """The problem families the fuzz generator leaves out (tests/fuzz_cases.py) because the reference's own answer is
     decided by rounding noise there are reported, not silently scanned: a saturated model (background columns + fixed
     effects span all cells; mode A with as many contexts as cells is the extreme case) warns at bind time and sets
-    MODEL_SATURATED on every variant; mode B with two donors ends its null fits at delta = 0 and sets
+    MODEL_SATURATED on every variant; a null fit that ends at delta = 0 (here: a phenotype without residual) sets
     MODEL_DELTA_AT_ZERO; a variant inside span(W) sets MODEL_G_IN_SPAN_W."""
     import warnings
 
@@ -439,13 +439,15 @@ def test_degenerate_models_are_flagged():
         pv, info = crm.scan_interaction_info(G)
     assert any("saturated model" in str(w.message) for w in caught)
     assert np.all(info["model_flags"] & 1) and info["degenerate"].all()
-    # mode B with two donors: the restricted likelihood is flat in delta at rho = 0
-    y, E, W, G, kw = random_problem(120, 3, 1, 8, 2, seed=2, mode="B")
+    # a phenotype that the random effect explains without residual (y in span(E) + intercept, Sigma = EE'): the
+    # likelihood rises all the way to delta = 0 and the fit ends at the clamp (the oracle reports delta = 2.2e-16)
+    y, E, W, G, kw = random_problem(100, 3, 1, 5, 6, seed=3, mode="A")
+    y = E @ np.array([1.0, -2.0, 0.5]) + 0.3
     with warnings.catch_warnings():
         warnings.simplefilter("error")          # not saturated: no warning
         pv, info = CellRegMap(y, E, W=W, **kw).scan_interaction_info(G)
     assert np.all((info["model_flags"] & 1) == 0)
-    assert np.any(info["model_flags"] & 2), info["model_flags"]
+    assert np.all(info["model_flags"] & 2) and info["degenerate"].all(), info["model_flags"]
     # a variant inside span(W)
     y, E, W, G, kw = random_problem(150, 3, 3, 5, 6, seed=3, mode="B")
     G = G.copy()

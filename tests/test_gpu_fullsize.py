@@ -195,7 +195,6 @@ def test_config3_block_headline_size():
     pick = sorted(set(np.random.default_rng(2024).choice(256, size=32, replace=False).tolist()) | {10, 11})
     opv, oinfo, ost = o.scan_interaction(c.G[:, pick], return_stats=True)
     _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, c.E.shape[1])
-    assert len(set(oinfo["rho1"])) >= 2          # the sample exercises more than one grid point
     del o
 
     # donor-collapsed path

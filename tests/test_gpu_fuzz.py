@@ -28,9 +28,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P_ATOL = 1e-13
 
 
-def _run(polish, count=150, seed=None, **case_limits):
+def _oracle_on_device_decomposition(crm, y, E, W, polish):
+    """The oracle bound to the (Q0, S0) the DEVICE's constructor produced instead of its own LAPACK SVDs: what is
+    left between the two sides is then the scan alone."""
+    from oracle.crm import OracleCellRegMap
+
+    o = OracleCellRegMap.__new__(OracleCellRegMap)
+    o._polish = bool(polish)
+    o._y, o._E0, o._W, o._E1 = np.asarray(y, float).ravel(), E, W, E
+    o._Ls, o._half = [], {}
+    o._rho = [float(r) for r in crm._rho1]
+    o._qs = {}
+    for i, rho in enumerate(o._rho):
+        Q0, S0 = crm._bg.read(i, o._y.size)
+        o._qs[rho] = ((Q0,), S0)
+    return o
+
+
+def _run(polish, count=150, seed=None, share_decomposition=False, **case_limits):
     """``count`` / ``seed`` / ``case_limits`` (``max_cells``, ``max_variants``, ... of ``fuzz_cases``): tools/fuzz_scan.py
-    runs larger samples from other streams through the same code."""
+    runs larger samples from other streams through the same code.  ``share_decomposition``: the oracle scans on the
+    device's decompositions (isolates the scan from the constructor)."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
     from oracle.crm import OracleCellRegMap
 
@@ -45,13 +63,14 @@ def _run(polish, count=150, seed=None, **case_limits):
     try:
         for case in fuzz_cases(count, seed=seed, wide_covariates=not polish, **case_limits):
             y, E, W, G, kw, hooks = build_case(case)
+            crm = CellRegMap(y, E, W=W, **kw)
             try:
-                opv, oinfo, ost = OracleCellRegMap(y, E, W=W, polish=polish, **kw).scan_interaction(
-                    G, return_stats=True, **hooks)
+                o = (_oracle_on_device_decomposition(crm, y, E, W, polish) if share_decomposition
+                     else OracleCellRegMap(y, E, W=W, polish=polish, **kw))
+                opv, oinfo, ost = o.scan_interaction(G, return_stats=True, **hooks)
             except ValueError:  # the reference's LMM raises on degenerate variants
                 skipped += 1
                 continue
-            crm = CellRegMap(y, E, W=W, **kw)
             for groups in (None, "auto"):
                 pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
                 same = info["rho1"] == oinfo["rho1"]
@@ -67,6 +86,8 @@ def _run(polish, count=150, seed=None, **case_limits):
     a = np.array(rows, float)   # columns: rel dQ, rel dp, |dp|, rel dlml, same rho*, oracle p
     same = a[:, 4] > 0
     s = {"procedure": "polished" if polish else "verbatim", "problems": count - skipped, "seed": seed, "oracle_raised": skipped,
+         "oracle_decomposition": "the device's (Q0, S0)" if share_decomposition else "its own LAPACK SVD / eigh",
+         "null_fit_arithmetic": "exact (IEEE division, log per entry)" if os.environ.get("CRM_NULLFIT_EXACT", "0") not in ("", "0") else "rcp + Newton, mantissa-product log-determinant",
          "variant_scans": int(a.shape[0]), "rho_star_differs": int((~same).sum()),
          "worst_rel_lml_where_rho_differs": float(a[~same, 3].max()) if (~same).any() else 0.0,
          "worst_rel_Q": float(a[same, 0].max()), "median_rel_Q": float(np.median(a[same, 0])),

@@ -17,5 +17,6 @@ if len(sys.argv) > 4:
     limits["max_variants"] = int(sys.argv[4])      # e.g. 1400: panels wide enough for the queue-based null fits
 if len(sys.argv) > 5:
     limits["max_cells"] = int(sys.argv[5])
+share = bool(os.environ.get("CRM_FUZZ_SHARE_DECOMPOSITION"))   # the oracle on the device's (Q0, S0): isolates the scan
 for polish in ([True, False] if which == "both" else [which == "polished"]):
-    print(json.dumps({**_run(polish, count=count, seed=seed, **limits)[0], **limits}, indent=1), flush=True)
+    print(json.dumps({**_run(polish, count=count, seed=seed, share_decomposition=share, **limits)[0], **limits}, indent=1), flush=True)
