@@ -132,7 +132,7 @@ using namespace crm;
 extern "C" {
 
 const char* crm_last_error(void) { return last_error_text(); }
-const char* crm_version(void) { return "0.1.0"; }
+const char* crm_version(void) { return "0.3.0"; }
 
 int crm_ctx_create(int device, crm_ctx** out) {
     return crm::guarded("crm_ctx_create", [&]() -> int {
@@ -152,6 +152,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     // CRM_CONTRACTION_SYNC=0 restores one workgroup per tile
     if (const char* e = getenv("CRM_CONTRACTION_SYNC")) c->tune.sync = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
+    if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));

@@ -65,3 +65,10 @@ def math_golden():
     import numpy as np
 
     return np.load(os.path.join(GOLDEN, "math_golden.npz"))
+
+
+def pytest_unconfigure(config):
+    global _trace_fh
+    if _trace_fh is not None:
+        _trace_fh.close()
+        _trace_fh = None

@@ -80,13 +80,14 @@ def _run(polish, count=150, seed=None, share_decomposition=False, **case_limits)
                     qscale = max(abs(ost["Q"][j]), float(np.trace(ost["F"][j])))
                     rows.append((abs(st["Q"][j] - ost["Q"][j]) / qscale, abs(pv[j] - opv[j]) / opv[j],
                                  abs(pv[j] - opv[j]), abs(st["lml"][j] - ost["lml"][j]) / abs(ost["lml"][j]),
-                                 bool(same[j]), opv[j]))
+                                 bool(same[j]), opv[j], 0.0 if groups is None else 1.0, "ABC".index(case[6])))
     finally:
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
     a = np.array(rows, float)   # columns: rel dQ, rel dp, |dp|, rel dlml, same rho*, oracle p
     same = a[:, 4] > 0
     s = {"procedure": "polished" if polish else "verbatim", "problems": count - skipped, "seed": seed, "oracle_raised": skipped,
          "oracle_decomposition": "the device's (Q0, S0)" if share_decomposition else "its own LAPACK SVD / eigh",
+         "rotation": "direct Q0'G" if os.environ.get("CRM_FAST_ROTATION", "1") == "0" else "through the mixing matrices where the background offers them",
          "null_fit_arithmetic": "exact (IEEE division, log per entry)" if os.environ.get("CRM_NULLFIT_EXACT", "0") not in ("", "0") else "rcp + Newton, mantissa-product log-determinant",
          "variant_scans": int(a.shape[0]), "rho_star_differs": int((~same).sum()),
          "worst_rel_lml_where_rho_differs": float(a[~same, 3].max()) if (~same).any() else 0.0,
@@ -94,7 +95,11 @@ def _run(polish, count=150, seed=None, share_decomposition=False, **case_limits)
          "worst_rel_p": float(a[same, 1].max()), "worst_abs_p": float(a[same, 2].max()),
          "worst_rel_lml": float(a[same, 3].max()), "median_rel_lml": float(np.median(a[same, 3])),
          "share_Q_beyond_1e-6": float((a[same, 0] > 1e-6).mean()),
-         "share_p_beyond_1e-5": float((a[same, 1] > 1e-5).mean())}
+         "share_p_beyond_1e-5": float((a[same, 1] > 1e-5).mean()),
+         "share_Q_beyond_1e-6_by_path": {name: float((a[same & (a[:, 6] == v), 0] > 1e-6).mean())
+                                         for name, v in (("dense", 0.0), ("collapsed", 1.0))},
+         "share_Q_beyond_1e-6_by_mode": {m: float((a[same & (a[:, 7] == k), 0] > 1e-6).mean()) for k, m in enumerate("ABC")},
+         "worst_rel_lml_by_mode": {m: float(a[same & (a[:, 7] == k), 3].max()) for k, m in enumerate("ABC")}}
     return s, a, same
 
 

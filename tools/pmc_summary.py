@@ -61,7 +61,7 @@ def main():
                         "kernel filter gemm_tn_glds_(sync_)?kernel<true; summary by tools/pmc_summary.py",
         "launch_shape": {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13},
         # bench.py quotes this profile only for the same kernel form (bench.py: roofline["kernel_form"])
-        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.1.0"},
+        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.3.0"},
         "algorithmic_bytes_per_launch": alg,
         "algorithmic_bytes_note": "Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
                                   "(SURVEY 8d per-unit figure x 4096)",
