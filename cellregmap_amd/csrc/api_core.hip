@@ -153,6 +153,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     if (const char* e = getenv("CRM_CONTRACTION_SYNC")) c->tune.sync = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
     if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
+    if (const char* e = getenv("CRM_FAST_GENE_ROTATION")) c->fast_gene_rot = atoi(e) != 0;
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));
@@ -297,6 +298,23 @@ int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
 }
 
 long crm_test_sync_fallbacks(const crm_ctx* c) { return c ? c->sync_fallbacks : -1; }
+
+int crm_test_null_fit_probe(crm_ctx* c, int on, double x) {
+    return crm::guarded("crm_test_null_fit_probe", [&]() -> int {
+    if (!c) return CRM_ERR_ARG;
+    c->probe_on = on != 0;
+    c->probe_x = x;
+    return CRM_OK;
+    });
+}
+
+int crm_test_null_fit_probe_read(crm_ctx* c, double* out, long capacity) {
+    return crm::guarded("crm_test_null_fit_probe_read", [&]() -> int {
+    if (!c || !out || capacity < (long)c->probe_out.size()) return CRM_ERR_ARG;
+    std::copy(c->probe_out.begin(), c->probe_out.end(), out);
+    return (int)c->probe_out.size();
+    });
+}
 
 int crm_test_set_contraction_sync(crm_ctx* c, int every) {
     return crm::guarded("crm_test_set_contraction_sync", [&]() -> int {

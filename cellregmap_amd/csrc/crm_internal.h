@@ -55,11 +55,15 @@ struct crm_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
+    bool fast_gene_rot = true;  // Q0(rho)'[y, W] of a gene through the mixing matrices as well (else against Q0 itself)
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     void (*progress)(long done, long total, void* user) = nullptr;  // called after every block of a scan
     void* progress_user = nullptr;
     bool in_scan = false;  // a scan is running on this context (its work buffers are in use: no second one from a callback)
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
+    bool probe_on = false;       // crm_test_null_fit_probe: scans stop after the null-fit kernels and keep the trial records
+    double probe_x = 0.0;
+    std::vector<double> probe_out;   // [variants x nrho x 2]: lml, scale at probe_x (last scanned block)
     bool nullfit_exact = false;  // null-fit likelihood in the reference's own operations (IEEE division, one log per entry)
     crm::GemmTune tune;   // contraction kernel variant (test hooks only change it)
     crm::DevBuf sync_counters;  // per-XCD generation counters of the persistent contraction form ([8]: waits that ran out)

@@ -31,7 +31,8 @@ struct NullFitArgs {
     int nrho, c, restricted;
     int polish;        // secant refinement of the optimum on the analytic derivative
     int exact;         // spectrum pass with IEEE division and one log per entry (the reference's own operations)
-    int pad2_;
+    int probe;         // test hook: evaluate the objective at probe_x only (register kernels)
+    double probe_x;
     long n;            // cells (unpadded)
     const double* WW;  // [c x c]
     const double* Wy;  // [c]

@@ -376,6 +376,17 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         return 0.5 * d * delta * (1.0 - delta);
     };
 
+    if (a.probe) {
+        // test hook (crm_test_null_fit_probe): the objective at one given x instead of the search, so that the
+        // likelihood itself can be compared with the oracle's at the same point
+        (void)f(a.probe_x);
+        if (lane == 0) {
+            NullFitTrial t;
+            t.lml = cur_lml; t.delta = cur_delta; t.scale = cur_scale; t.use_g = use_g ? 1 : 0; t.nfev = nfev;
+            a.trial[(long)b * a.nrho + w] = t;
+        }
+        return;
+    }
     {
         // ---- bracket (oracle/brent.py: bracket) ------------------------------------------
         double lo = -LOGMAX, hi = LOGMAX;

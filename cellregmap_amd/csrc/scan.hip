@@ -222,7 +222,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     const int nrho = bg->nrho;
     const long ldq = bg->ldq;
     const long slab = (long)(1 + c) * ldq;
-    if (bg->fast_T) {
+    if (bg->fast_T && ctx->fast_gene_rot) {
         // Q0(rho) = H Mix(rho):  t = Mix(rho)' (H'[y, W]) -- no Q0 needed
         ScopedBuf thw;
         const long ldh = bg->ldh;
@@ -1030,9 +1030,21 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
             fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = ld_gW;
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
+            fa.probe = ctx->probe_on ? 1 : 0; fa.probe_x = ctx->probe_x;
             CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));
         }
         trace_pop();
+        if (ctx->probe_on) {   // test hook: keep the (variant, grid point) records of this block and stop here
+            std::vector<NullFitTrial> h_trial((size_t)nb * nrho);
+            CRM_HIP(hipMemcpyAsync(h_trial.data(), d_trial, sizeof(NullFitTrial) * h_trial.size(), hipMemcpyDeviceToHost, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            ctx->probe_out.assign(2 * h_trial.size(), 0.0);
+            for (size_t q = 0; q < h_trial.size(); q++) {
+                ctx->probe_out[2 * q] = h_trial[q].lml;
+                ctx->probe_out[2 * q + 1] = h_trial[q].scale;
+            }
+            return CRM_OK;
+        }
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
         CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));

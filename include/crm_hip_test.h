@@ -36,6 +36,13 @@ long crm_test_tail_launches(const crm_ctx* ctx);
 /* The same product stored transposed: CT (N x (B*k0)). */
 int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                            const double* E, const double* Y, double* CT);
+/* Null-fit objective at a given point instead of the search (c <= 8 covariate columns): while on, crm_scan_interaction
+ * stops after the null-fit kernels of its first block (outputs untouched) and keeps, per (variant, grid point), the
+ * log-likelihood and the scale at x = logit(delta); crm_test_null_fit_probe_read copies them out as
+ * [variants][grid points][2] doubles and returns their number (> capacity: CRM_ERR_ARG).  Lets a test compare the
+ * likelihood itself with the oracle's at the same point, apart from where the two searches stop. */
+int crm_test_null_fit_probe(crm_ctx* ctx, int on, double x);
+int crm_test_null_fit_probe_read(crm_ctx* ctx, double* out, long capacity);
 /* Eigenvalues (ascending) of `count` symmetric k x k matrices (lower triangle read). */
 int crm_test_eigvalsh(crm_ctx* ctx, int count, int k, const double* F, double* lambda);
 /* Davies/Liu p-values for `count` (Q, lambda[k]) pairs after the eigenvalue filter. */
