@@ -7,8 +7,8 @@ accepted point by an amount of the order of the stopping tolerance, and Q and th
 This CPU test measures that spread on the oracle alone -- the same code, the same inputs, only the
 objective rounded differently -- and so backs the two-tier criterion of tests/test_gpu_fuzz.py:
 
-  * spectrum columns permuted (every sum over the spectrum in another order, ~1 ulp): same Brent path,
-    spread ~1e-9;
+  * spectrum columns permuted (every sum over the spectrum in another order, ~1 ulp) or the cells permuted (every
+    n-length inner product in another order): same Brent path on this sample, spread < 1e-7;
   * objective perturbed by 1e-15 / 1e-14 / 1e-13 relative (4 / 45 / 450 ulp; another BLAS, FMA
     contraction, a hardware reciprocal or another summation tree sit in that range -- the HIP engine's
     lml agrees with the oracle's to ~1e-14, tests/test_gpu_fuzz.py records it): paths part in a growing
@@ -121,17 +121,19 @@ def test_reordered_sums_keep_the_brent_path(spreads):
     assert s["worst_rel_Q"] < 1e-7 and s["worst_rel_p"] < 1e-6, s
 
 
-def test_another_order_of_the_cells_already_moves_Q_beyond_the_north_star(spreads):
-    """The same oracle on the same problem with the cells listed in another order (all inputs and the rows of Q0
-    permuted consistently: identical mathematics, every n-length inner product summed in another order).  The complement
-    terms (u'v - (Q0'u)'(Q0'v)) / delta of glimix-core's likelihood turn that last-bit difference into objective noise,
-    and Brent's 1e-6 search on logit(delta) into a spread of Q that passes the north-star 1e-6 on a share of the variants
-    of the same size as the one tests/test_gpu_fuzz.py records for device vs oracle (~0.4 %).  The device's own
-    arithmetic is not what separates it from the oracle: profiles/r03_fuzz_exact_arithmetic.json (IEEE division and
-    log: no change) and r03_fuzz_shared_decomposition.json (the oracle on the device's Q0, S0: no change)."""
+def test_another_order_of_the_cells_keeps_the_brent_path_on_this_sample(spreads):
+    """The same oracle on the same problem with the cells listed in another order (all inputs and the rows of Q0 permuted
+    consistently: identical mathematics, every n-length inner product summed in another order) moves the objective by
+    ~2e-16 relative (median) and, on this sample, no score statistic by more than 1e-7.  On the 14 832 variant scans of
+    the GPU fuzz stream (tools/oracle_reorder_spread.py, profiles/r03_oracle_vs_oracle_cells_reordered.json) one scan in
+    15 000 passes 1e-6; with 1e-15 / 4e-15 relative noise on the objective -- the size of the device-vs-oracle difference
+    of the likelihood AT FIXED POINTS, profiles/r03_null_fit_objective_probe.json -- 0.12 % / 0.43 % of them do
+    (tools/oracle_noise_spread.py, profiles/r03_oracle_vs_oracle_noise_on_the_fuzz_stream.json), mode C leading as in
+    the device-vs-oracle comparison (0.35-0.40 %): the events are flips of Brent's last comparison f(x0 +- tol) <= f(x0),
+    over which the objective changes by only a few hundred ulp, and each moves the stopping point by one tolerance."""
     s = spreads["cells_permuted"]
     assert s["rho_flips"] == 0, s
-    assert s["worst_rel_Q"] < 2e-5 and s["worst_rel_p"] < 5e-5, s     # inside the envelope of the GPU fuzz test
+    assert s["worst_rel_Q"] < 1e-6 and s["worst_rel_p"] < 1e-5, s
     assert s["frac_Q_beyond_1e-6"] == 0.0, s
 
 
