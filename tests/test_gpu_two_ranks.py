@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["C-thin", "C-eigh", "B"])
+@pytest.mark.parametrize("mode", ["C-thin", "C-eigh", "B", "C-thin-host"])
 def test_two_ranks_share_one_gpu(mode, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -25,6 +25,7 @@ def test_two_ranks_share_one_gpu(mode, tmp_path):
     run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     got = np.load(out)
+    mode = mode.replace("-host", "")      # (exchange through CPU tensors: same results expected)
 
     import cellregmap_amd as crm
     from cellregmap_amd.synth import make_cohort

@@ -16,6 +16,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     mode, out = sys.argv[1], sys.argv[2]
+    # exchange buffers: CUDA tensors (what RCCL broadcasts), or -- mode "...-host" -- the CPU tensors that
+    # sharded_background allocates by default under gloo: crm_background_export / _import then copy to and from HOST memory
+    host = mode.endswith("-host")
+    mode = mode[:-5] if host else mode
     import torch
     import torch.distributed as dist
 
@@ -38,7 +42,7 @@ def main():
     else:
         B = crm.get_L_values(c.hK, c.E)
         kw = dict(Ls=B)
-    bg = sharded_background(c.E, B, rho, device=0, tensor_device=torch.device("cuda", 0))
+    bg = sharded_background(c.E, B, rho, device=0, tensor_device=None if host else torch.device("cuda", 0))
     obj = crm.CellRegMap(c.y, c.E, W=c.W, background=bg, **kw)
     first, count = variant_shard(p, rank, world)
     shard = np.ascontiguousarray(c.G[:, first:first + count])
