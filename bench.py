@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("CELLREGMAP_AMD_PROGRESS", "0")   # no tqdm bars around the benchmark's scans
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X FP64 matrix peak (vendor sheet)
 
