@@ -167,7 +167,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
 }
 
 int crm_ctx_trim(crm_ctx* c) {
-    return crm::guarded("crm_ctx_trim", [&]() -> int {
+    return crm::guarded_on("crm_ctx_trim", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -206,7 +206,7 @@ void crm_ctx_destroy(crm_ctx* c) {
 }
 
 int crm_ctx_synchronize(crm_ctx* c) {
-    return crm::guarded("crm_ctx_synchronize", [&]() -> int {
+    return crm::guarded_on("crm_ctx_synchronize", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -215,7 +215,7 @@ int crm_ctx_synchronize(crm_ctx* c) {
 }
 
 int crm_set_block_variants(crm_ctx* c, int variants) {
-    return crm::guarded("crm_set_block_variants", [&]() -> int {
+    return crm::guarded_on("crm_set_block_variants", c, [&]() -> int {
     if (!c || variants < 0) return CRM_ERR_ARG;
     c->block_variants = variants == 0 ? 0 : (int)round_up(variants, 128);
     return CRM_OK;
@@ -223,7 +223,7 @@ int crm_set_block_variants(crm_ctx* c, int variants) {
 }
 
 int crm_set_null_fit_polish(crm_ctx* c, int on) {
-    return crm::guarded("crm_set_null_fit_polish", [&]() -> int {
+    return crm::guarded_on("crm_set_null_fit_polish", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->polish = on != 0;
     return CRM_OK;
@@ -231,7 +231,7 @@ int crm_set_null_fit_polish(crm_ctx* c, int on) {
 }
 
 int crm_set_progress_callback(crm_ctx* c, void (*callback)(long, long, void*), void* user) {
-    return crm::guarded("crm_set_progress_callback", [&]() -> int {
+    return crm::guarded_on("crm_set_progress_callback", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->progress = callback;
     c->progress_user = user;
@@ -240,7 +240,7 @@ int crm_set_progress_callback(crm_ctx* c, void (*callback)(long, long, void*), v
 }
 
 int crm_set_fast_rotation(crm_ctx* c, int on) {
-    return crm::guarded("crm_set_fast_rotation", [&]() -> int {
+    return crm::guarded_on("crm_set_fast_rotation", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->fast_T = on != 0;
     return CRM_OK;
@@ -248,7 +248,7 @@ int crm_set_fast_rotation(crm_ctx* c, int on) {
 }
 
 int crm_kernel_timer_reset(crm_ctx* c) {
-    return crm::guarded("crm_kernel_timer_reset", [&]() -> int {
+    return crm::guarded_on("crm_kernel_timer_reset", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -260,7 +260,7 @@ int crm_kernel_timer_reset(crm_ctx* c) {
 }
 
 int crm_kernel_timer_stop(crm_ctx* c) {
-    return crm::guarded("crm_kernel_timer_stop", [&]() -> int {
+    return crm::guarded_on("crm_kernel_timer_stop", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->timing = false;  // later scans record nothing; the pairs recorded so far stay readable
     return CRM_OK;
@@ -269,7 +269,7 @@ int crm_kernel_timer_stop(crm_ctx* c) {
 
 int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* kr_flops,
                           double* total_ms) {
-    return crm::guarded("crm_kernel_timer_read", [&]() -> int {
+    return crm::guarded_on("crm_kernel_timer_read", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     CRM_HIP(hipStreamSynchronize(c->stream));
@@ -289,7 +289,7 @@ int crm_kernel_timer_read(crm_ctx* c, double* kr_ms, long* kr_launches, double* 
 
 // ---- single-kernel hooks -------------------------------------------------------------
 int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
-    return crm::guarded("crm_test_set_contraction", [&]() -> int {
+    return crm::guarded_on("crm_test_set_contraction", c, [&]() -> int {
     if (!c || (tile_width != 0 && tile_width != 64 && tile_width != 128 && tile_width != 160)) return CRM_ERR_ARG;
     c->tune.bn = tile_width;
     c->tune.glds = lds_dma ? 1 : 0;
@@ -300,7 +300,7 @@ int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
 long crm_test_sync_fallbacks(const crm_ctx* c) { return c ? c->sync_fallbacks : -1; }
 
 int crm_test_null_fit_probe(crm_ctx* c, int on, double x) {
-    return crm::guarded("crm_test_null_fit_probe", [&]() -> int {
+    return crm::guarded_on("crm_test_null_fit_probe", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
     c->probe_on = on != 0;
     c->probe_x = x;
@@ -309,7 +309,7 @@ int crm_test_null_fit_probe(crm_ctx* c, int on, double x) {
 }
 
 int crm_test_null_fit_probe_read(crm_ctx* c, double* out, long capacity) {
-    return crm::guarded("crm_test_null_fit_probe_read", [&]() -> int {
+    return crm::guarded_on("crm_test_null_fit_probe_read", c, [&]() -> int {
     if (!c || !out || capacity < (long)c->probe_out.size()) return CRM_ERR_ARG;
     std::copy(c->probe_out.begin(), c->probe_out.end(), out);
     return (int)c->probe_out.size();
@@ -317,7 +317,7 @@ int crm_test_null_fit_probe_read(crm_ctx* c, double* out, long capacity) {
 }
 
 int crm_test_set_contraction_sync(crm_ctx* c, int every) {
-    return crm::guarded("crm_test_set_contraction_sync", [&]() -> int {
+    return crm::guarded_on("crm_test_set_contraction_sync", c, [&]() -> int {
     if (!c || every < 0) return CRM_ERR_ARG;
     c->tune.sync = every;
     return CRM_OK;
@@ -326,7 +326,7 @@ int crm_test_set_contraction_sync(crm_ctx* c, int every) {
 
 int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit) {
-    return crm::guarded("crm_test_contract", [&]() -> int {
+    return crm::guarded_on("crm_test_contract", c, [&]() -> int {
     if (!c || cells <= 0 || M <= 0 || N <= 0 || !X || !Y || !C || ksplit < 1) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK * (long)ksplit);
@@ -354,7 +354,7 @@ int crm_test_contract(crm_ctx* c, long cells, int M, int N, const double* X, con
 
 int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const double* G,
                          const double* E, const double* Y, double* C) {
-    return crm::guarded("crm_test_contract_kr", [&]() -> int {
+    return crm::guarded_on("crm_test_contract_kr", c, [&]() -> int {
     if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !C) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK);
@@ -384,7 +384,7 @@ int crm_test_contract_kr(crm_ctx* c, long cells, int B, int k0, int N, const dou
 // transposed store: CT is N x (B*k0) row-major
 int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const double* G, const double* E,
                            const double* Y, double* CT) {
-    return crm::guarded("crm_test_contract_kr_t", [&]() -> int {
+    return crm::guarded_on("crm_test_contract_kr_t", c, [&]() -> int {
     if (!c || cells <= 0 || B <= 0 || k0 <= 0 || N <= 0 || !G || !E || !Y || !CT) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     const long cp = round_up(cells, GEMM_BK);
@@ -420,7 +420,7 @@ int crm_test_contract_kr_t(crm_ctx* c, long cells, int B, int k0, int N, const d
 extern "C" {
 
 int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lambda) {
-    return crm::guarded("crm_test_eigvalsh", [&]() -> int {
+    return crm::guarded_on("crm_test_eigvalsh", c, [&]() -> int {
     if (!c || count <= 0 || k <= 0 || !F || !lambda) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     ScopedBuf bF, bQ, bL, bP;
@@ -440,7 +440,7 @@ int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lam
 
 int crm_test_davies(crm_ctx* c, int count, int k, const double* Q, const double* lambda, double* pvalue,
                     int* ifault, double* liu) {
-    return crm::guarded("crm_test_davies", [&]() -> int {
+    return crm::guarded_on("crm_test_davies", c, [&]() -> int {
     if (!c || count <= 0 || k <= 0 || !Q || !lambda || !pvalue) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(c->device));
     ScopedBuf bQ, bL, bP, bI, bU;

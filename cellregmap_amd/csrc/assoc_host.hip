@@ -9,7 +9,7 @@ using namespace crm;
 
 extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long count, int fast,
                                     double* out_pvalue, double* out_alt_lml, double* out_null) {
-    return crm::guarded("crm_scan_association", [&]() -> int {
+    return crm::guarded_on("crm_scan_association", gene ? gene->ctx : nullptr, [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;

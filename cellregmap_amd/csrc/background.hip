@@ -634,7 +634,7 @@ static int background_create_core(crm_ctx* ctx, long n, const double* E1, int k1
 extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int k1, const double* B,
                                      long kb, int nrho, const double* rho, double rel_tol,
                                      crm_background** out) {
-    return crm::guarded("crm_background_create", [&]() -> int {
+    return crm::guarded_on("crm_background_create", ctx, [&]() -> int {
     if (kb > 0 && !B) return CRM_ERR_ARG;
     return background_create_core(ctx, n, E1, k1, B, kb, nullptr, 0, nullptr, 0, nrho, rho, rel_tol, out);
     });
@@ -643,7 +643,7 @@ extern "C" int crm_background_create(crm_ctx* ctx, long n, const double* E1, int
 extern "C" int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k1, const double* U,
                                               int k2, const double* hK, int m, int nrho, const double* rho,
                                               double rel_tol, crm_background** out) {
-    return crm::guarded("crm_background_create_hadamard", [&]() -> int {
+    return crm::guarded_on("crm_background_create_hadamard", ctx, [&]() -> int {
     if (!U || !hK || k2 < 1 || m < 1) return CRM_ERR_ARG;
     return background_create_core(ctx, n, E1, k1, nullptr, (long)k2 * m, U, k2, hK, m, nrho, rho, rel_tol, out);
     });
@@ -653,28 +653,28 @@ extern "C" int crm_background_create_hadamard(crm_ctx* ctx, long n, const double
 extern "C" int crm_background_begin(crm_ctx* ctx, long n, const double* E1, int k1, const double* B, long kb,
                                     const double* U, int k2, const double* hK, int m, int nrho, const double* rho,
                                     const int* mine, double rel_tol, crm_background** out) {
-    return crm::guarded("crm_background_begin", [&]() -> int {
+    return crm::guarded_on("crm_background_begin", ctx, [&]() -> int {
     if (kb > 0 && !B && !(U && hK && k2 >= 1 && m >= 1 && (long)k2 * m == kb)) return CRM_ERR_ARG;
     return background_begin(ctx, n, E1, k1, B, kb, U, k2, hK, m, nrho, rho, mine, rel_tol, out);
     });
 }
 
 extern "C" int crm_background_complete(crm_background* bg, const int* ranks) {
-    return crm::guarded("crm_background_complete", [&]() -> int {
+    return crm::guarded_on("crm_background_complete", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || !ranks) return CRM_ERR_ARG;
     return background_complete(bg, ranks);
     });
 }
 
 extern "C" int crm_background_seal(crm_background* bg) {
-    return crm::guarded("crm_background_seal", [&]() -> int {
+    return crm::guarded_on("crm_background_seal", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg) return CRM_ERR_ARG;
     return background_seal(bg);
     });
 }
 
 extern "C" int crm_background_layout(const crm_background* bg, long* n_pad, long* ldq, long* ldh, int* has_mix) {
-    return crm::guarded("crm_background_layout", [&]() -> int {
+    return crm::guarded_on("crm_background_layout", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || !bg->builder || !bg->builder->completed) return CRM_ERR_ARG;
     if (n_pad) *n_pad = bg->n_pad;
     if (ldq) *ldq = bg->ldq;
@@ -697,7 +697,7 @@ static int background_slot(const crm_background* bg, int i, int what, void** ptr
 }
 
 extern "C" int crm_background_export(const crm_background* bg, int i, int what, void* dst_device) {
-    return crm::guarded("crm_background_export", [&]() -> int {
+    return crm::guarded_on("crm_background_export", bg ? bg->ctx : nullptr, [&]() -> int {
     void* p = nullptr;
     size_t bytes = 0;
     if (bg && what == 0 && i >= 0 && i < bg->nrho && !bg->q0_ready[i] && bg->builder && bg->builder->thin) {
@@ -713,7 +713,7 @@ extern "C" int crm_background_export(const crm_background* bg, int i, int what, 
 }
 
 extern "C" int crm_background_import(crm_background* bg, int i, int what, const void* src_device) {
-    return crm::guarded("crm_background_import", [&]() -> int {
+    return crm::guarded_on("crm_background_import", bg ? bg->ctx : nullptr, [&]() -> int {
     void* p = nullptr;
     size_t bytes = 0;
     if (!src_device || background_slot(bg, i, what, &p, &bytes) != CRM_OK) return CRM_ERR_ARG;

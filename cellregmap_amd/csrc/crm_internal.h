@@ -1,5 +1,6 @@
 // Internal object layouts behind the opaque C-ABI handles.
 #pragma once
+#include <mutex>
 #include <utility>
 
 #include "crm_common.h"
@@ -50,6 +51,10 @@ void release_eigh_workspace(crm_ctx* ctx);
 }  // namespace crm
 
 struct crm_ctx {
+    // Every entry point that works on a context (directly or through a background / gene / panel of it) holds this lock
+    // for the duration of the call: calls on one context are serialised by the library, whatever threads they come from
+    // (recursive: an entry may call another one; a scan started from a progress callback is refused separately, in_scan).
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -87,3 +92,19 @@ struct crm_ctx {
         return {&sync_counters, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };
+
+namespace crm {
+// crm::guarded (no C++ exception across the C-ABI) with the context's lock held around the body; ctx may be null (the
+// body then reports the bad argument itself).
+template <class Body>
+inline int guarded_on(const char* entry, crm_ctx* ctx, Body&& body) noexcept {
+    try {
+        if (!ctx) return guarded(entry, body);
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        return guarded(entry, body);
+    } catch (...) {   // (std::system_error from the lock)
+        set_error("%s: could not take the context's lock", entry);
+        return CRM_ERR_INTERNAL;
+    }
+}
+}  // namespace crm

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void cov_solve_kernel(const double* __restrict
 }  // namespace
 
 extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, double* out_beta) {
-    return crm::guarded("crm_lmm_fit", [&]() -> int {
+    return crm::guarded_on("crm_lmm_fit", gene ? gene->ctx : nullptr, [&]() -> int {
     if (!gene || !out_fit) return CRM_ERR_ARG;
     crm_background* bg = gene->bg;
     crm_ctx* ctx = bg->ctx;
@@ -134,7 +134,7 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
 
 extern "C" int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const double* rhs,
                              int m, double* out) {
-    return crm::guarded("crm_cov_solve", [&]() -> int {
+    return crm::guarded_on("crm_cov_solve", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || !rhs || !out) return CRM_ERR_ARG;
     if (rho_index < 0 || rho_index >= bg->nrho || m < 1 || !(v1 > 0.0)) {
         set_error("cov_solve: rho_index=%d (grid of %d), m=%d, v1=%g", rho_index, bg->nrho, m, v1);

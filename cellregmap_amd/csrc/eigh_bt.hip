@@ -223,7 +223,7 @@ int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt) {
 // ---- test hook: the solver on host matrices ---------------------------------------------------------------------
 extern "C" int crm_test_eigh(crm_ctx* ctx, int batch, int dim, const double* A, double* lam, double* Z, int stage,
                              double* d_out, double* e_out) {
-    return crm::guarded("crm_test_eigh", [&]() -> int {
+    return crm::guarded_on("crm_test_eigh", ctx, [&]() -> int {
     using namespace crm;
     if (!ctx || batch < 1 || dim < 1 || !A || !lam) return CRM_ERR_ARG;
     CRM_HIP(hipSetDevice(ctx->device));

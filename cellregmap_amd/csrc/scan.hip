@@ -65,7 +65,7 @@ extern "C" {
 int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, const int* r,
                              const double* const* Q0, const double* const* S0,
                              crm_background** out) {
-    return crm::guarded("crm_background_create_qs", [&]() -> int {
+    return crm::guarded_on("crm_background_create_qs", ctx, [&]() -> int {
     if (!ctx || !out || n <= 0 || nrho < 1 || !rho || !r || !Q0 || !S0) return CRM_ERR_ARG;
     if (nrho > CRM_MAX_RHO) {
         set_error("background: %d grid points (supported up to %d)", nrho, CRM_MAX_RHO);
@@ -125,14 +125,14 @@ void crm_background_destroy(crm_background* bg) {
 }
 
 int crm_background_rank(const crm_background* bg, int i) {
-    return crm::guarded("crm_background_rank", [&]() -> int {
+    return crm::guarded_on("crm_background_rank", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return -1;
     return bg->r[i];
     });
 }
 
 int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0) {
-    return crm::guarded("crm_background_read", [&]() -> int {
+    return crm::guarded_on("crm_background_read", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return CRM_ERR_ARG;
     if (Q0) CRM_TRY(crm_background_require_q0(const_cast<crm_background*>(bg), i));
     CRM_HIP(hipSetDevice(bg->ctx->device));
@@ -148,7 +148,7 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
 // ---- gene -----------------------------------------------------------------------------------
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out) {
-    return crm::guarded("crm_gene_create", [&]() -> int {
+    return crm::guarded_on("crm_gene_create", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || !y || !W || !E0 || !out) return CRM_ERR_ARG;
     *out = nullptr;
     if (bg->builder) {
@@ -290,7 +290,7 @@ void crm_gene_destroy(crm_gene* g) {
 
 // ---- panel ----------------------------------------------------------------------------------
 int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out) {
-    return crm::guarded("crm_panel_create", [&]() -> int {
+    return crm::guarded_on("crm_panel_create", ctx, [&]() -> int {
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     *out = nullptr;
     CRM_HIP(hipSetDevice(ctx->device));
@@ -327,7 +327,7 @@ void crm_panel_destroy(crm_panel* P) {
 // ---- grouped (donor-constant) panel --------------------------------------------------------------
 int crm_panel_create_grouped(crm_ctx* ctx, long n, const int* group, long m, const double* Gd, long ldg,
                              long p, crm_panel** out) {
-    return crm::guarded("crm_panel_create_grouped", [&]() -> int {
+    return crm::guarded_on("crm_panel_create_grouped", ctx, [&]() -> int {
     if (!ctx || !group || !Gd || !out || n <= 0 || m <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     *out = nullptr;
     for (long i = 0; i < n; i++) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void standardise_dosages_kernel(const signed c
 
 extern "C" int crm_panel_create_grouped_i8(crm_ctx* ctx, long n, const int* group, long m, const signed char* dosage,
                                            long ldd, long p, int standardise, crm_panel** out) {
-    return crm::guarded("crm_panel_create_grouped_i8", [&]() -> int {
+    return crm::guarded_on("crm_panel_create_grouped_i8", ctx, [&]() -> int {
     if (!ctx || !group || !dosage || !out || n <= 0 || m <= 0 || p <= 0 || ldd < p) return CRM_ERR_ARG;
     *out = nullptr;
     std::vector<double> cells_of(m, 0.0);
@@ -477,7 +477,7 @@ extern "C" {
 // verification of detect_groups (both O(n p) memory passes that dominated short scans).
 int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long p, const int* group_hint,
                           long m_hint, const long* rep_rows, crm_panel** out, int* out_grouped) {
-    return crm::guarded("crm_panel_create_auto", [&]() -> int {
+    return crm::guarded_on("crm_panel_create_auto", ctx, [&]() -> int {
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     if (out_grouped) *out_grouped = 0;
     crm_panel* P = nullptr;
@@ -539,7 +539,7 @@ int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long 
 }
 
 int crm_set_donor_collapse(crm_ctx* ctx, int on) {
-    return crm::guarded("crm_set_donor_collapse", [&]() -> int {
+    return crm::guarded_on("crm_set_donor_collapse", ctx, [&]() -> int {
     if (!ctx) return CRM_ERR_ARG;
     ctx->collapse = on != 0;
     return CRM_OK;
@@ -1321,7 +1321,7 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
                          const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
                          double* out_delta, double* out_scale, double* out_lambda, double* out_F) {
-    return crm::guarded("crm_scan_interaction", [&]() -> int {
+    return crm::guarded_on("crm_scan_interaction", gene ? gene->ctx : nullptr, [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> genes{gene};
     std::vector<ScanOut> outs{{out_pvalue, out_rho1, out_e2, out_g2, out_eps2, out_Q, out_lml, out_delta,
@@ -1333,7 +1333,7 @@ int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long coun
 int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
                               const int* idx_G, double* out_pvalue, int* out_ifault, double* out_liu_pvalue,
                               int* out_model_flags) {
-    return crm::guarded("crm_scan_interaction_info", [&]() -> int {
+    return crm::guarded_on("crm_scan_interaction_info", gene ? gene->ctx : nullptr, [&]() -> int {
     if (!gene || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> genes{gene};
     ScanOut o{out_pvalue, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1348,7 +1348,7 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
 long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
-    return crm::guarded("crm_test_set_shared_h", [&]() -> int {
+    return crm::guarded_on("crm_test_set_shared_h", ctx, [&]() -> int {
     if (!ctx) return CRM_ERR_ARG;
     ctx->tune.shared_h = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
     return CRM_OK;
@@ -1358,7 +1358,7 @@ int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
 int crm_scan_interaction_multi(crm_gene* const* genes, int ngenes, crm_panel* panel, long first, long count,
                                const int* idx_E, const int* idx_G, double* out_pvalue, double* out_rho1,
                                double* out_e2, double* out_g2, double* out_eps2, double* out_Q) {
-    return crm::guarded("crm_scan_interaction_multi", [&]() -> int {
+    return crm::guarded_on("crm_scan_interaction_multi", (genes && ngenes > 0 && genes[0]) ? genes[0]->ctx : nullptr, [&]() -> int {
     if (!genes || ngenes < 1 || !panel) return CRM_ERR_ARG;
     std::vector<crm_gene*> gs(genes, genes + ngenes);
     for (crm_gene* g : gs)

@@ -9,8 +9,13 @@
  * The entry points below are what a ctypes binding inside those methods binds
  * (see INTEGRATION.md for the stub).  Conventions: plain pointers and sizes,
  * float64 host buffers owned by the caller, int status (0 = OK, < 0 = error,
- * text via crm_last_error()), no exceptions across the boundary, one context =
- * one device + one HIP stream, calls on one context serialised by the caller.
+ * text via crm_last_error()), no exceptions across the boundary (every entry
+ * point catches them: CRM_ERR_INTERNAL), one context = one device + one HIP
+ * stream + one set of work buffers.  Calls that touch one context -- directly or
+ * through a background, gene or panel created on it -- are serialised by the
+ * library (a lock per context), so handles may be used from several threads;
+ * distinct contexts run concurrently.  Settings (crm_set_*) belong to the
+ * context, not to the calling thread.
  */
 #ifndef CRM_HIP_H
 #define CRM_HIP_H

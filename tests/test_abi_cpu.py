@@ -126,8 +126,9 @@ def test_a_cpp_exception_stops_at_the_boundary():
 
 
 def test_every_entry_point_runs_behind_the_exception_guard():
-    """Structural: each `int crm_*` the headers declare is defined with its body inside crm::guarded(...) (one-line
-    getters that cannot throw excepted), each `void crm_*_destroy` inside try / catch (...)."""
+    """Structural: each `int crm_*` the headers declare is defined with its body inside crm::guarded(...) or
+    crm::guarded_on(..., context, ...) -- the latter also holds the context's lock -- (one-line getters that cannot throw
+    excepted), each `void crm_*_destroy` inside try / catch (...)."""
     csrc = os.path.join(ROOT, "cellregmap_amd", "csrc")
     text = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))
     exempt = {"crm_last_error", "crm_version", "crm_test_tail_launches", "crm_test_sync_fallbacks"}
@@ -138,6 +139,7 @@ def test_every_entry_point_runs_behind_the_exception_guard():
         assert m, f"definition of {name} not found"
         first = m.group(2).strip()
         if m.group(1) == "int":
-            assert first.startswith('return crm::guarded("%s"' % name), f"{name}: {first}"
+            assert (first.startswith('return crm::guarded("%s"' % name) or
+                    first.startswith('return crm::guarded_on("%s"' % name)), f"{name}: {first}"
         else:
             assert first.startswith("try {"), f"{name}: {first}"

@@ -454,3 +454,39 @@ def test_degenerate_models_are_flagged():
     G[:, 2] = W @ np.array([0.5, -1.0, 2.0])
     pv, info = CellRegMap(y, E, W=W, **kw).scan_interaction_info(G)
     assert info["model_flags"][2] & 4 and not np.any(np.delete(info["model_flags"], 2) & 4)
+
+
+def test_scans_from_several_threads_on_one_device_are_serialised_by_the_library():
+    """ctypes releases the GIL during a call, so two Python threads can enter the library at the same time on the one
+    context of a device, whose work buffers a scan owns while it runs.  Every entry point takes the context's lock
+    (crm::guarded_on): the calls queue up instead of corrupting each other, and every thread gets the result of a
+    serial run, bit for bit."""
+    import threading
+
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 40, 4, 700, seed=17)
+    rng = np.random.default_rng(5)
+    ys = [c.y, c.y[rng.permutation(c.y.size)], rng.normal(size=c.y.size), c.y + rng.normal(size=c.y.size)]
+    first = crm.CellRegMap(ys[0], c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E))
+    objs = [first] + [crm.CellRegMap(y, c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E), background=first._bg) for y in ys[1:]]
+    panel = crm.GenotypePanel(c.G, groups=None)
+    serial = [o.scan_interaction(panel, progress=False) for o in objs]
+    got, errors = [None] * len(objs), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = objs[i].scan_interaction(panel, progress=False)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, exc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(objs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (pv, info), (spv, sinfo) in zip(got, serial):
+        assert np.array_equal(pv, spv) and np.array_equal(info["rho1"], sinfo["rho1"])
