@@ -173,8 +173,13 @@ def test_config3_block_headline_size():
     Ls = get_L_values(c.hK, c.E)
     crm = CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
     dense = GenotypePanel(c.G, groups=None)
+    from cellregmap_amd import _engine, _lib
+    fallbacks = _lib.load().crm_test_sync_fallbacks(_engine._context(0))
     pv, info, st = crm.scan_interaction(dense, return_stats=True)
     assert np.all(np.isfinite(pv)) and np.all((pv > 0) & (pv <= 1))
+    # the contraction of this block ran in its persistent per-XCD form (3 900 tiles); on a GPU this process has to itself
+    # none of its bounded waits runs out (a context that saw them time out would leave that form: crm_test_sync_fallbacks)
+    assert _lib.load().crm_test_sync_fallbacks(_engine._context(0)) == fallbacks
 
     # factorisation: Q0 S0 Q0' v == hS hS' v for one interior grid point, Q0 orthonormal
     i = 6
