@@ -65,8 +65,12 @@ int DevBuf::ensure(size_t need) {
         (void)hipGetLastError();
         e = hipMalloc(&ptr, need);
     }
-    if (e != hipSuccess) ptr = nullptr;
-    CRM_HIP(e);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        (void)hipGetLastError();
+        set_error("device allocation of %zu bytes failed: %s", need, hipGetErrorString(e));
+        return CRM_ERR_HIP;
+    }
     bytes = need;
     // Fresh allocations never carry the previous tenant's bytes into a kernel: they are zero-filled -- or, with
     // CRM_POISON=1 (GPU AddressSanitizer is not available for this target), filled with 0xFF bytes: NaN as a double, -1

@@ -158,3 +158,22 @@ def test_the_context_is_still_sound(world):
     c = world["c"]
     ref, _ = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(GenotypePanel(c.G, groups=None), progress=False)
     assert np.array_equal(pv, ref)
+
+
+def test_out_of_device_memory_is_a_status_code(world):
+    """A background that cannot fit (one grid point of 4 000 000 cells x 10 112 padded columns = 324 GB on a 288 GB device):
+    the allocation fails inside the library, which releases its idle caches, tries once more and then reports
+    CRM_ERR_HIP with the size in the text; nothing is read from the host pointers, nothing leaks into the next
+    call."""
+    lib, _lib = world["lib"], world["_lib"]
+    rho = _lib.f64(np.array([1.0]))
+    r = np.array([10000], np.int32)
+    dummy = np.zeros(8)
+    PP = ctypes.c_void_p * 1
+    out = ctypes.c_void_p()
+    rc = lib.crm_background_create_qs(world["ctx"], 4_000_000, 1, _lib.ptr(rho), _lib.ptr(r), PP(dummy.ctypes.data),
+                                      PP(dummy.ctypes.data), ctypes.byref(out))
+    assert rc == -1 and not out.value, rc
+    assert b"device allocation of 323584000000 bytes failed" in lib.crm_last_error(), lib.crm_last_error()
+    rc, pv = _scan(world, 0, 24)
+    assert rc == OK and np.all((pv > 0) & (pv <= 1))
