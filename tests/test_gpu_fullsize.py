@@ -101,6 +101,28 @@ def test_config2_against_the_oracles_own_decompositions(cfg2):
     _compare_with_oracle(ppv, pinfo, pst, pick, opv, oinfo, ost, c.E.shape[1], q_rtol=1e-8, delta_rtol=1e-7, p_rtol=2e-6)
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_association_at_config2_against_the_oracle(cfg2, fast):
+    """Row a13 at a BASELINE size: the persistent-effect LRT (_cellregmap.py:246-314, 443-469) on the config-2 cohort, full
+    ML refit per SNP and FastScanner, 12 seeded random SNPs (+ the planted persistent ones) against the oracle on the
+    device's decompositions: the null model's rho / variance components and every p-value."""
+    c, Ls, crm, dense, *_ = cfg2
+    o = _oracle_on_device_decomposition(crm, c.y, c.E, c.W, Ls)
+    pick = sorted(set(np.random.default_rng(13).choice(384, size=12, replace=False).tolist()) | {5, 6})
+    G = np.ascontiguousarray(c.G[:, pick])
+    if fast:
+        pv, info = crm.scan_association_fast(G)
+        opv, oinfo = o.scan_association_fast(G)
+    else:
+        pv, info = crm.scan_association(G, progress=False)
+        opv, oinfo = o.scan_association(G)
+    for k in ("rho1", "e2", "g2", "eps2"):
+        assert info[k].shape == (1,)
+        assert_allclose(info[k], oinfo[k], rtol=1e-5, atol=1e-10)
+    assert np.all(np.abs(pv - opv) <= P_RTOL * opv + 1e-300), np.c_[pv, opv]
+    assert pv[[pick.index(5), pick.index(6)]].max() < 1e-6          # the planted persistent effects are found
+
+
 def test_decomposition_is_an_orthonormal_factorisation(cfg2):
     c, Ls, crm, dense, *_ = cfg2
     i = 4
