@@ -35,6 +35,21 @@ def test_estimate_betas_matches_the_oracle(with_kinship):
     _close(bgxe, obgxe, 2e-5)
 
 
+def test_estimate_betas_at_two_thousand_cells():
+    """The same at a size where the per-SNP backgrounds take the constructor's thin branch (10 + 10 x 40 = 410 columns
+    against 2 000 cells: Gram matrix -> eigen-solver -> mixing matrices, the rho = 1 grid point on its leading block) and
+    the fits its LDS kernel (1 + 1 + 10 = 12 fixed-effect columns): _cellregmap.py:137-205, :640-682."""
+    import cellregmap_amd as crm
+    from oracle import crm as ocrm
+
+    c, maf = _cohort(seed=29, donors=40, cells=50, k0=10, p=3)
+    bg, bgxe = crm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=c.hK)
+    obg, obgxe = ocrm.estimate_betas(c.y, c.W, c.E, c.G, maf=maf, hK=c.hK)
+    assert bgxe.shape == (1, 2000, 3)
+    _close(bg, obg, 2e-5)
+    _close(bgxe, obgxe, 2e-5)
+
+
 def test_estimate_betas_with_polished_fits_is_tight():
     import cellregmap_amd as crm
     from cellregmap_amd import _engine, _lib
