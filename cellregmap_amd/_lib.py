@@ -71,6 +71,9 @@ SIGNATURES = {
     "crm_test_tail_launches": (ctypes.c_long, [vp]),
     "crm_test_set_contraction_sync": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_sync_fallbacks": (ctypes.c_long, [vp]),
+    "crm_test_overruns": (ctypes.c_long, []),
+    "crm_test_check_context": (ctypes.c_int, [vp]),
+    "crm_test_overrun_selftest": (ctypes.c_int, [vp]),
     "crm_test_null_fit_probe": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_double]),
     "crm_test_null_fit_probe_read": (ctypes.c_int, [vp, vp, ctypes.c_long]),
     "crm_test_contract": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp, vp,

@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <mutex>
 
@@ -53,17 +54,45 @@ void trace_pop() {
     if (ranges_on() && roctx().pop) roctx().pop();
 }
 
+// CRM_POISON=1 (GPU AddressSanitizer is not available for this target): every fresh allocation is filled with 0xFF bytes
+// -- NaN as a double, -1 as an int -- instead of zeros, so that a read of memory nobody wrote shows up as a NaN result or as
+// a range-checked index, and it is followed by a red zone of REDZONE bytes of the same fill that is inspected when the
+// buffer is released: a kernel that wrote past the end of its buffer is counted (crm_test_overruns) and reported on stderr.
+static bool poison_mode() {
+    static const bool on = getenv("CRM_POISON") && atoi(getenv("CRM_POISON")) != 0;
+    return on;
+}
+static constexpr size_t REDZONE = 4096;
+static std::atomic<long> g_overruns{0};
+long overruns_detected() { return g_overruns.load(); }
+
+static void check_redzone(const void* ptr, size_t bytes) {
+    if (!ptr || !poison_mode()) return;
+    std::vector<unsigned char> rz(REDZONE);
+    if (hipMemcpy(rz.data(), static_cast<const char*>(ptr) + bytes, REDZONE, hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (size_t i = 0; i < REDZONE; i++) {
+        if (rz[i] != 0xFF) {
+            g_overruns++;
+            fprintf(stderr, "[crm] CRM_POISON: write past the end of a %zu-byte device buffer (first touched byte at +%zu)\n",
+                    bytes, i);
+            break;
+        }
+    }
+}
+
 int DevBuf::ensure(size_t need) {
     if (need <= bytes) return CRM_OK;
     if (ptr) {
+        check_redzone(ptr, bytes);
         CRM_HIP(hipFree(ptr));
         ptr = nullptr;
         bytes = 0;
     }
-    hipError_t e = hipMalloc(&ptr, need);
+    const size_t total = need + (poison_mode() ? REDZONE : 0);
+    hipError_t e = hipMalloc(&ptr, total);
     if (e == hipErrorOutOfMemory && trim_idle_workspaces() > 0) {
         (void)hipGetLastError();
-        e = hipMalloc(&ptr, need);
+        e = hipMalloc(&ptr, total);
     }
     if (e != hipSuccess) {
         ptr = nullptr;
@@ -72,13 +101,10 @@ int DevBuf::ensure(size_t need) {
         return CRM_ERR_HIP;
     }
     bytes = need;
-    // Fresh allocations never carry the previous tenant's bytes into a kernel: they are zero-filled -- or, with
-    // CRM_POISON=1 (GPU AddressSanitizer is not available for this target), filled with 0xFF bytes: NaN as a double, -1
-    // as an int, so that a read of memory nobody wrote shows up as a NaN result or as a range-checked index.  The fill
-    // runs on the null stream and is waited for here: the contexts' streams are non-blocking and would not order
-    // themselves behind it.
-    static const bool poison = getenv("CRM_POISON") && atoi(getenv("CRM_POISON")) != 0;
-    CRM_HIP(hipMemsetAsync(ptr, poison ? 0xFF : 0, need, nullptr));
+    // Fresh allocations never carry the previous tenant's bytes into a kernel: they are zero-filled (poison mode: 0xFF,
+    // above).  The fill runs on the null stream and is waited for here: the contexts' streams are non-blocking and would
+    // not order themselves behind it.
+    CRM_HIP(hipMemsetAsync(ptr, poison_mode() ? 0xFF : 0, total, nullptr));
     CRM_HIP(hipStreamSynchronize(nullptr));
     return CRM_OK;
 }
@@ -113,6 +139,7 @@ size_t trim_idle_workspaces() {
     return freed;
 }
 void DevBuf::release() {
+    if (ptr) check_redzone(ptr, bytes);
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
     bytes = 0;
@@ -302,6 +329,36 @@ int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
 }
 
 long crm_test_sync_fallbacks(const crm_ctx* c) { return c ? c->sync_fallbacks : -1; }
+long crm_test_overruns(void) { return crm::overruns_detected(); }
+
+int crm_test_overrun_selftest(crm_ctx* c) {
+    return crm::guarded_on("crm_test_overrun_selftest", c, [&]() -> int {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    const long before = overruns_detected();
+    {
+        ScopedBuf b;
+        CRM_TRY(b.ensure(1000));
+        if (poison_mode()) CRM_HIP(hipMemset(static_cast<char*>(b.ptr) + 1000, 0, 8));   // eight bytes past the end, on purpose
+        CRM_HIP(hipDeviceSynchronize());
+    }
+    return (int)(overruns_detected() - before);
+    });
+}
+
+int crm_test_check_context(crm_ctx* c) {
+    return crm::guarded_on("crm_test_check_context", c, [&]() -> int {
+    if (!c) return CRM_ERR_ARG;
+    CRM_HIP(hipSetDevice(c->device));
+    CRM_HIP(hipStreamSynchronize(c->stream));
+    for (const DevBuf* b : c->all_bufs()) check_redzone(b->ptr, b->bytes);
+    if (c->eigh_ws)
+        for (const DevBuf* b : {&c->eigh_ws->A, &c->eigh_ws->Vt, &c->eigh_ws->Vc, &c->eigh_ws->QA, &c->eigh_ws->QB, &c->eigh_ws->d,
+                                &c->eigh_ws->e, &c->eigh_ws->tau, &c->eigh_ws->lam, &c->eigh_ws->small})
+            check_redzone(b->ptr, b->bytes);
+    return CRM_OK;
+    });
+}
 
 int crm_test_null_fit_probe(crm_ctx* c, int on, double x) {
     return crm::guarded_on("crm_test_null_fit_probe", c, [&]() -> int {

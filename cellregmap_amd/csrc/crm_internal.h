@@ -40,6 +40,8 @@ struct EighWork;
 // Release the idle cached workspaces of every context (the eigen-solver's); returns the bytes handed back.
 // DevBuf::ensure calls it once before giving up on an allocation.
 size_t trim_idle_workspaces();
+// CRM_POISON=1: device buffers whose red zone was found overwritten when they were released
+long overruns_detected();
 }  // namespace crm
 struct crm_ctx;
 namespace crm {

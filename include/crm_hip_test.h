@@ -20,6 +20,14 @@ int crm_test_set_contraction_sync(crm_ctx* ctx, int every);
 /* Times this context gave the persistent form up because its bounded waits ran out (the 512 workgroups were not
  * co-resident: a shared GPU); from then on its launches use one workgroup per tile. */
 long crm_test_sync_fallbacks(const crm_ctx* ctx);
+/* CRM_POISON=1 only (else always 0): number of device buffers of this process whose red zone -- 4 KiB of 0xFF behind every
+ * allocation -- was found overwritten when the buffer was released, i.e. kernels that wrote past the end of a buffer. */
+long crm_test_overruns(void);
+/* ... and the same inspection, now, of the context's own work buffers (which live as long as the context). */
+int crm_test_check_context(crm_ctx* ctx);
+/* Self-test of that detector: writes eight bytes past the end of a scratch buffer on purpose (CRM_POISON=1 only) and
+ * returns by how much the overrun count grew (1 with the poison fill, 0 without). */
+int crm_test_overrun_selftest(crm_ctx* ctx);
 /* C (M x N, ld N) = X' Y with X: cells x M, Y: cells x N (row-major, tight). */
 int crm_test_contract(crm_ctx* ctx, long cells, int M, int N, const double* X, const double* Y,
                       double* C, int ksplit);

@@ -177,3 +177,19 @@ def test_out_of_device_memory_is_a_status_code(world):
     assert b"device allocation of 323584000000 bytes failed" in lib.crm_last_error(), lib.crm_last_error()
     rc, pv = _scan(world, 0, 24)
     assert rc == OK and np.all((pv > 0) & (pv <= 1))
+
+
+def test_the_overrun_detector_detects(world):
+    """CRM_POISON=1 puts 4 KiB of 0xFF behind every device buffer and inspects it on release; the self-test writes eight
+    bytes past a scratch buffer on purpose.  In a poison run it must be counted (and is then subtracted again by the
+    session's bookkeeping: tests/conftest.py), in a normal run nothing is instrumented."""
+    import os
+
+    lib = world["lib"]
+    before = lib.crm_test_overruns()
+    grew = lib.crm_test_overrun_selftest(world["ctx"])
+    poison = os.environ.get("CRM_POISON", "0") not in ("", "0")
+    assert grew == (1 if poison else 0)
+    assert lib.crm_test_overruns() == before + grew
+    if poison:
+        os.environ["CRM_TEST_EXPECTED_OVERRUNS"] = str(int(os.environ.get("CRM_TEST_EXPECTED_OVERRUNS", "0")) + 1)
