@@ -131,6 +131,40 @@ def _make_background(E1, B, rho, device, rel_tol=0.0, cache=True):
     return _make_background_dense(E1, B, rho, device, rel_tol, cache)
 
 
+_kin_cache = OrderedDict()   # digest of hK -> (group of cell, donor-level rows) or None
+
+
+def _kinship_groups(hK):
+    """Donor structure of an "expanded" kinship factor (_cellregmap.py:559: hK is n x m with the rows of a donor-level
+    factor repeated for the cells of each donor): ``(group int32 (n,), hKd (groups, m))`` with ``hK == hKd[group]`` exactly,
+    or ``None`` when the rows do not repeat (more than n / 2 or 2048 distinct rows)."""
+    key = _digest(hK)
+    if key in _kin_cache:
+        _kin_cache.move_to_end(key)
+        return _kin_cache[key]
+    found = detect_groups(hK, max_groups=2048, sample_columns=min(64, hK.shape[1]))
+    out = None
+    if found is not None:
+        group, reps = found
+        out = (np.ascontiguousarray(group, dtype=np.int32), np.ascontiguousarray(hK[reps], dtype=float))
+    _kin_cache[key] = out
+    while len(_kin_cache) > 4:
+        _kin_cache.popitem(last=False)
+    return out
+
+
+def _announce_kinship_groups(bg, halves):
+    """Tell the library about the donor structure of the kinship factor (``crm_background_set_kinship_groups``): the
+    dense scan then forms H'(g o E0) donor by donor instead of contracting every variant against Q0(rho*) over all cells."""
+    found = _kinship_groups(halves.hK)
+    if found is None:
+        return
+    group, hKd = found
+    us = _lib.f64(halves.us)
+    _lib.check(_lib.load().crm_background_set_kinship_groups(bg.handle, _lib.ptr(group), hKd.shape[0], _lib.ptr(hKd),
+                                                             hKd.shape[1], _lib.ptr(us), us.shape[1]))
+
+
 def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
     lib = _lib.load()
     key = (device, "hadamard", _digest(E1, halves.us, halves.hK), tuple(np.asarray(rho, float)), rel_tol)
@@ -144,6 +178,7 @@ def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
                                                   us.shape[1], _lib.ptr(hK), hK.shape[1], rho.shape[0],
                                                   _lib.ptr(rho), float(rel_tol), ctypes.byref(h)))
     bg = _Background(h, rho, device)
+    _announce_kinship_groups(bg, halves)
     if cache:
         _bg_cache[key] = bg
         while len(_bg_cache) > BACKGROUND_CACHE_SIZE:
@@ -191,6 +226,7 @@ class BackgroundBuilder:
         flags = np.ones(nrho, np.int32) if mine is None else np.ascontiguousarray(mine, dtype=np.int32)
         E1c = _lib.f64(E1)
         h = ctypes.c_void_p()
+        self._halves = B if isinstance(B, HadamardHalves) else None
         if isinstance(B, HadamardHalves):
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
                                                 B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.us), B.us.shape[1],
@@ -231,6 +267,8 @@ class BackgroundBuilder:
 
     def seal(self):
         _lib.check(_lib.load().crm_background_seal(self._bg.handle))
+        if self._halves is not None:
+            _announce_kinship_groups(self._bg, self._halves)
         return self._bg
 
 

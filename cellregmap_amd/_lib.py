@@ -31,6 +31,7 @@ SIGNATURES = {
     "crm_background_create_hadamard": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_int, vp,
                                                       ctypes.c_int, ctypes.c_int, vp, ctypes.c_double,
                                                       ctypes.POINTER(vp)]),
+    "crm_background_set_kinship_groups": (ctypes.c_int, [vp, vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_int]),
     "crm_background_begin": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long, vp, ctypes.c_int, vp,
                                             ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.POINTER(vp)]),
     "crm_background_complete": (ctypes.c_int, [vp, vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "crm_test_set_contraction_sync": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_sync_fallbacks": (ctypes.c_long, [vp]),
     "crm_test_overruns": (ctypes.c_long, []),
+    "crm_test_set_kinship_route": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_check_context": (ctypes.c_int, [vp]),
     "crm_test_overrun_selftest": (ctypes.c_int, [vp]),
     "crm_test_null_fit_probe": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_double]),

@@ -188,6 +188,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
     if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
     if (const char* e = getenv("CRM_FAST_GENE_ROTATION")) c->fast_gene_rot = atoi(e) != 0;
+    if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = atoi(e) != 0;
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));
@@ -333,6 +334,14 @@ int crm_test_set_contraction(crm_ctx* c, int tile_width, int lds_dma) {
 
 long crm_test_sync_fallbacks(const crm_ctx* c) { return c ? c->sync_fallbacks : -1; }
 long crm_test_overruns(void) { return crm::overruns_detected(); }
+
+int crm_test_set_kinship_route(crm_ctx* c, int on) {
+    return crm::guarded_on("crm_test_set_kinship_route", c, [&]() -> int {
+    if (!c) return CRM_ERR_ARG;
+    c->kin_route = on != 0;
+    return CRM_OK;
+    });
+}
 
 int crm_test_overrun_selftest(crm_ctx* c) {
     return crm::guarded_on("crm_test_overrun_selftest", c, [&]() -> int {

@@ -252,6 +252,69 @@ int launch_gather_slabs(hipStream_t st, const double* src, long ld_src, long row
     return CRM_OK;
 }
 
+// ---- donor order of a background's kinship structure (objects.h: crm_background::kin*) ------------------------------
+// dst[k, j] = src[map[k], j] (map[k] < 0: a padding row of zeros), j < cols
+__global__ void gather_rows_kernel(const double* __restrict__ src, long ld_src, const int* __restrict__ map, int cols,
+                                   double* __restrict__ dst, long ld_dst) {
+    const long k = blockIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    const int c = map[k];
+    dst[k * ld_dst + j] = c >= 0 ? src[(long)c * ld_src + j] : 0.0;
+}
+
+int launch_gather_rows(hipStream_t st, const double* src, long ld_src, const int* map, long rows, int cols, double* dst,
+                       long ld_dst) {
+    if (rows <= 0 || cols <= 0) return CRM_OK;
+    dim3 grid((unsigned)rows, (unsigned)((cols + 255) / 256));
+    hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, st, src, ld_src, map, cols, dst, ld_dst);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+// Y[k, 0 .. k2) = U[map[k], :], Y[k, k2 .. k2 + k1) = H[map[k], 0 .. k1) (the E1 columns of the half factor), zero elsewhere
+__global__ void kin_operand_kernel(const double* __restrict__ U, int k2, const double* __restrict__ H, long ldh, int k1,
+                                   const int* __restrict__ map, double* __restrict__ Y, long ldy) {
+    const long k = blockIdx.x;
+    const int j = threadIdx.x;
+    if (j >= ldy) return;
+    const int c = map[k];
+    double v = 0.0;
+    if (c >= 0) {
+        if (j < k2) v = U[(long)c * k2 + j];
+        else if (j < k2 + k1) v = H[(long)c * ldh + (j - k2)];
+    }
+    Y[k * ldy + j] = v;
+}
+
+int launch_kin_operand(hipStream_t st, const double* U, int k2, const double* H, long ldh, int k1, const int* map, long rows,
+                       double* Y, long ldy) {
+    if (rows <= 0) return CRM_OK;
+    hipLaunchKernelGGL(kin_operand_kernel, dim3((unsigned)rows), dim3((unsigned)ldy), 0, st, U, k2, H, ldh, k1, map, Y, ldy);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+// AH[a, c] = sum over the donors d' of S[(d' KT + k2 + a), c]: the E1 rows of H'(g o E0) from the per-donor sums
+__global__ void kin_sum_e1_kernel(const double* __restrict__ S, long ld_s, int KT, int k2, int groups, long cols,
+                                  double* __restrict__ AH, long ld_ah) {
+    const int a = blockIdx.y;
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    for (int d = 0; d < groups; d++) acc += S[((long)d * KT + k2 + a) * ld_s + c];
+    AH[(long)a * ld_ah + c] = acc;
+}
+
+int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2, int k1, int groups, long cols, double* AH,
+                      long ld_ah) {
+    if (k1 <= 0 || cols <= 0) return CRM_OK;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)k1);
+    hipLaunchKernelGGL(kin_sum_e1_kernel, grid, dim3(256), 0, st, S, ld_s, KT, k2, groups, cols, AH, ld_ah);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols) {

@@ -62,6 +62,7 @@ struct crm_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
+    bool kin_route = true;      // H'(g o E0) donor by donor when the background knows its kinship structure (CRM_KIN_ROUTE=0)
     bool fast_gene_rot = true;  // Q0(rho)'[y, W] of a gene through the mixing matrices as well (else against Q0 itself)
     bool collapse = true;  // use the donor-collapsed path for grouped panels
     void (*progress)(long done, long total, void* user) = nullptr;  // called after every block of a scan
@@ -90,8 +91,9 @@ struct crm_ctx {
     double kr_flops = 0.0;
     // scan workspace (grown on demand, reused across calls)
     crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
+    crm::DevBuf ws_Gk, ws_S;   // kinship-structure route: the block in donor order, the per-donor sums S
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&sync_counters, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&sync_counters, &ws_S, &ws_Gk, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };
 

@@ -84,6 +84,15 @@ int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cel
 // dst[h, p*k0 + j] = src[h, ord[p]*k0 + j] for p < npairs, zero in the remaining dst_cols
 int launch_gather_slabs(hipStream_t st, const double* src, long ld_src, long rows, const int* ord, int npairs,
                         int k0, double* dst, long ld_dst, int dst_cols);
+// rows in the donor order of a background's kinship structure: dst[k, :cols] = src[map[k], :cols], zeros where map[k] < 0
+int launch_gather_rows(hipStream_t st, const double* src, long ld_src, const int* map, long rows, int cols, double* dst,
+                       long ld_dst);
+// the per-donor right-hand operand [us | E1] in donor order (crm_background::kin_Y)
+int launch_kin_operand(hipStream_t st, const double* U, int k2, const double* H, long ldh, int k1, const int* map, long rows,
+                       double* Y, long ldy);
+// E1 rows of H'(g o E0): sums of the per-donor blocks S over the donors
+int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2, int k1, int groups, long cols, double* AH,
+                      long ld_ah);
 // dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]
 int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
                         long cells, const int* row_index, int variants, double* dst, long ld_dst,

@@ -44,6 +44,22 @@ struct crm_background {
     long ldh = 0, cols = 0;
     crm::DevBuf H;                        // [n_pad x ldh]
     crm::DevBuf Mix[crm::CRM_MAX_RHO];   // [ldh x ldq]
+    // Donor structure of the kinship factor (crm_background_set_kinship_groups): H = [E1, L_1 .. L_k2] with
+    // L_j = diag(us[:, j]) hK and hK[c, :] = hKd[group(c), :] -- rows of hK constant within a donor, as in the reference's
+    // "expanded" kinship factor.  Then  H'(g o E0)  needs no n-length contraction against the cols = k1 + k2 m columns of H:
+    //   S[d', (us_j | E1_a), (b, i)] = sum over the cells c of donor d' of  [us(c, j) | E1(c, a)] g_b(c) E0(c, i)
+    //   (H'(g o E0))[(j, d), .] = sum_d' hKd[d', d] S[d', us_j, .],   (H'(g o E0))[a, .] = sum_d' S[d', E1_a, .]
+    // i.e. 2 n (k1 + k2) k0 flops per variant for S instead of 2 n cols k0 (40 times fewer at config 3).
+    bool kin = false;
+    long kin_groups = 0, kin_groups_pad = 0;   // m' donors (padded to the contraction's stage depth)
+    long kin_cols = 0;                          // m: columns of hK
+    int kin_k1 = 0, kin_k2 = 0;
+    long kin_rows = 0;                          // cells in donor order, every donor's run padded to a multiple of 16 rows
+    std::vector<long> kin_row0, kin_len;        // first row / padded length of each donor's run
+    crm::DevBuf kin_map;                        // int[kin_rows]: cell of a sorted row, -1 for padding
+    crm::DevBuf kin_Y;                          // [kin_rows x 128]: columns 0..k2-1 us, k2..k2+k1-1 E1, donor order
+    crm::DevBuf kin_hKd;                        // [kin_groups_pad x kin_ldh]
+    long kin_ldh = 0;
     // shared donor tables, most recently used first (at most DT_CACHE entries)
     static constexpr int DT_CACHE = 2;
     std::vector<crm_donor_tables*> dt_cache;
@@ -68,6 +84,7 @@ struct crm_gene {
     crm::DevBuf rot;  // [nrho][(1+c) x ldq]: rows Q0(rho)'y, Q0(rho)'W_i
     // features of the (possibly row-permuted) contexts, rebuilt per scan call
     crm::DevBuf Ep, YE, EE, idx;
+    crm::DevBuf kinEp;    // the (permuted) contexts in the donor order of the background's kinship structure
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
     unsigned long e0_key = 0;    // content hash of E0 (key of the background's shared donor tables)

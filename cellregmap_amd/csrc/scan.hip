@@ -114,6 +114,9 @@ void crm_background_destroy(crm_background* bg) {
     }
     bg->H.release();
     bg->Ht.release();
+    bg->kin_map.release();
+    bg->kin_Y.release();
+    bg->kin_hKd.release();
     for (crm_donor_tables* t : bg->dt_cache) {
         t->release();
         delete t;
@@ -122,6 +125,66 @@ void crm_background_destroy(crm_background* bg) {
     delete bg;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
     }
+}
+
+int crm_background_set_kinship_groups(crm_background* bg, const int* group, long groups, const double* hKd, long m,
+                                      const double* U, int k2) {
+    return crm::guarded_on("crm_background_set_kinship_groups", bg ? bg->ctx : nullptr, [&]() -> int {
+    if (!bg || !group || !hKd || !U || groups < 1 || m < 1 || k2 < 1) return CRM_ERR_ARG;
+    if (bg->builder) {
+        set_error("kinship groups: the background is still under construction");
+        return CRM_ERR_ARG;
+    }
+    const long n = bg->n;
+    const int k1 = (int)(bg->cols - (long)k2 * m);
+    // only backgrounds that kept their half factor H = [E1, L_1 .. L_k2] (thin branch, well-conditioned spectrum) can use it
+    if (!bg->fast_T || !bg->H.ptr || k1 < 1 || k1 + k2 > 128 || groups > 4096) return CRM_OK;
+    for (long i = 0; i < n; i++)
+        if (group[i] < 0 || group[i] >= groups) {
+            set_error("kinship groups: group index %d at cell %ld outside [0, %ld)", group[i], i, groups);
+            return CRM_ERR_ARG;
+        }
+    crm_ctx* ctx = bg->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // cells in donor order, every donor's run padded to whole stages of the contraction
+    std::vector<long> count(groups, 0);
+    for (long i = 0; i < n; i++) count[group[i]]++;
+    bg->kin_row0.assign(groups, 0);
+    bg->kin_len.assign(groups, 0);
+    long rows = 0;
+    for (long d = 0; d < groups; d++) {
+        bg->kin_row0[d] = rows;
+        bg->kin_len[d] = round_up(std::max<long>(count[d], 1), GEMM_BK);
+        rows += bg->kin_len[d];
+    }
+    std::vector<int> map(rows, -1);
+    std::vector<long> fill(groups, 0);
+    for (long i = 0; i < n; i++) {
+        const long d = group[i];
+        map[bg->kin_row0[d] + fill[d]++] = (int)i;
+    }
+    bg->kin_rows = rows;
+    bg->kin_groups = groups;
+    bg->kin_groups_pad = round_up(groups, GEMM_BK);
+    bg->kin_cols = m;
+    bg->kin_k1 = k1;
+    bg->kin_k2 = k2;
+    bg->kin_ldh = round_up(m, 128);
+    CRM_TRY(bg->kin_map.ensure(sizeof(int) * rows));
+    CRM_TRY(bg->kin_Y.ensure(sizeof(double) * rows * 128));
+    CRM_TRY(bg->kin_hKd.ensure(sizeof(double) * bg->kin_groups_pad * bg->kin_ldh));
+    ScopedBuf dU;
+    CRM_TRY(dU.ensure(sizeof(double) * n * k2));
+    CRM_HIP(hipMemcpyAsync(bg->kin_map.ptr, map.data(), sizeof(int) * rows, hipMemcpyHostToDevice, st));
+    CRM_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
+    CRM_TRY(upload_padded(st, bg->kin_hKd.as<double>(), bg->kin_ldh, bg->kin_groups_pad, hKd, m, groups, m));
+    CRM_TRY(launch_kin_operand(st, dU.as<double>(), k2, bg->H.as<double>(), bg->ldh, k1, bg->kin_map.as<int>(), rows,
+                               bg->kin_Y.as<double>(), 128));
+    CRM_HIP(hipStreamSynchronize(st));
+    bg->kin = true;
+    return CRM_OK;
+    });
 }
 
 int crm_background_rank(const crm_background* bg, int i) {
@@ -281,7 +344,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
-                    &g->dt_Zt})
+                    &g->dt_Zt, &g->kinEp})
         b->release();
     delete g;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
@@ -876,7 +939,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* d_liu = (double*)(sm + o_liu);
     double* d_part = (double*)(sm + o_part);
     unsigned* d_queue = (unsigned*)(sm + o_queue);   // work queue of the null fits (one counter per grid point)
-    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4)));
+    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4 + (bg->kin ? bg->kin_groups + bg->kin_k2 : 0))));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
     const long slab = (long)(1 + c) * ldq;  // rotations of [y, W] per grid point
@@ -889,10 +952,23 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     const bool collapsed = grouped && ctx->collapse && bd_bytes <= ((size_t)48 << 30) && (!idx_G || panel->m <= 128);
     const bool cross = collapsed && idx_G;
     const long ld_ah = round_up((long)BLK * k0, 128) + 128, ld_xg = round_up((long)max_pairs * k0, 128) + 128;
-    if (bg->fast_T && ctx->fast_T && ng > 1 && !collapsed) {  // operands of the shared-H route (step 6)
+    // Kinship-structure route (objects.h, crm_background::kin): H'(g o E0) donor by donor, then Mix(rho*)' -- the dense
+    // scan's default whenever the background knows the donor structure of its kinship factor.  S: per-donor sums.
+    const int KK = bg->kin ? bg->kin_k1 + bg->kin_k2 : 0;   // rows of S per donor: [us | E1]
+    const size_t s_bytes = bg->kin ? sizeof(double) * (size_t)bg->kin_groups_pad * KK * ld_ah : 0;
+    const bool kin_route = bg->kin && bg->fast_T && ctx->fast_T && !collapsed && ctx->kin_route && s_bytes <= ((size_t)48 << 30);
+    if (bg->fast_T && ctx->fast_T && (ng > 1 || kin_route) && !collapsed) {  // operands of the routes through H (step 6)
         CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
         CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)bg->ldh * ld_xg));
         CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
+    }
+    if (kin_route) {
+        CRM_TRY(ctx->ws_S.ensure(s_bytes));
+        CRM_TRY(ctx->ws_Gk.ensure(sizeof(double) * (size_t)bg->kin_rows * ldb));
+        // rows of the padding donors (kin_groups .. kin_groups_pad) are operands of the contraction over the donors
+        if (bg->kin_groups_pad > bg->kin_groups)
+            CRM_HIP(hipMemsetAsync(ctx->ws_S.as<double>() + (size_t)bg->kin_groups * KK * ld_ah, 0,
+                                   sizeof(double) * (size_t)(bg->kin_groups_pad - bg->kin_groups) * KK * ld_ah, st));
     }
     const long mp = grouped ? panel->m_pad : 0;
     crm_donor_tables* tab = nullptr;  // phenotype-free donor tables of this call (collapsed mode)
@@ -948,6 +1024,11 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
     }
     if (!collapsed) CRM_TRY(context_features(true));
+    if (kin_route) {   // the (permuted) contexts in donor order
+        CRM_TRY(g0->kinEp.ensure(sizeof(double) * (size_t)bg->kin_rows * g0->ld_ep));
+        CRM_TRY(launch_gather_rows(st, d_Ep, g0->ld_ep, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ep,
+                                   g0->kinEp.as<double>(), g0->ld_ep));
+    }
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit((size_t)BLK * ng);
     std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
@@ -1083,8 +1164,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         //    Several genes can select several rho* for one variant; with Q0(rho) = H Mix(rho) the
         //    n-length Khatri-Rao contraction is then done once per variant against H (stored transposed)
         //    and every (variant, rho) pair costs a cols-length product with Mix(rho) instead.
-        bool via_H = false;
-        if (fastT && ng > 1) {
+        bool via_H = kin_route;
+        if (fastT && ng > 1 && !kin_route) {
             double direct = 0.0, via = (double)nb * (double)bg->cols * (double)n;
             for (int i = 0; i < nrho; i++) {
                 direct += (double)cnt[i] * bg->r[i] * (double)n;
@@ -1187,7 +1268,47 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
-        if (via_H) {
+        if (via_H && kin_route) {
+            // AH = H'(g o E0) without an n-length contraction against the cols columns of H:
+            // (a) the block in donor order; (b) per donor d' the Khatri-Rao contraction over its own cells against
+            // [us | E1] (transposed store: S[(d' KK + q), (b, i)]); (c) the L rows: for every j a contraction over the
+            // donors with hKd, AH[(k1 + j m + d), .] = sum_d' hKd[d', d] S[(d' KK + j), .]; (d) the E1 rows: sums over d'
+            double* Gk = ctx->ws_Gk.as<double>();
+            double* S = ctx->ws_S.as<double>();
+            const int k1 = bg->kin_k1, k2 = bg->kin_k2;
+            const long groups = bg->kin_groups, mk = bg->kin_cols;
+            CRM_TRY(launch_gather_rows(st, Gt, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
+            std::vector<GemmProblem> kp((size_t)groups + k2);
+            long maxlen = GEMM_BK;
+            for (long d = 0; d < groups; d++) {
+                GemmProblem p{};
+                p.X = Gk + bg->kin_row0[d] * ldb; p.ldx = ldb;
+                p.E = g0->kinEp.as<double>() + bg->kin_row0[d] * g0->ld_ep; p.lde = g0->ld_ep; p.k0 = k0;
+                p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * 128; p.ldy = 128;
+                p.C = S + (size_t)d * KK * ld_ah; p.ldc = ld_ah;
+                p.M = nb * k0; p.N = KK; p.cells = bg->kin_len[d];
+                maxlen = std::max(maxlen, bg->kin_len[d]);
+                kp[d] = p;
+            }
+            for (int j = 0; j < k2; j++) {
+                GemmProblem p{};
+                p.X = bg->kin_hKd.as<double>(); p.ldx = bg->kin_ldh;
+                p.Y = S + (size_t)j * ld_ah; p.ldy = (long)KK * ld_ah;
+                p.C = ctx->ws_AH.as<double>() + (size_t)(k1 + (long)j * mk) * ld_ah; p.ldc = ld_ah;
+                p.M = (int)mk; p.N = nb * k0;
+                kp[groups + j] = p;
+            }
+            GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+            CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * kp.size(), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, nb * k0, KK, maxlen, k0));
+            CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, k2, (int)mk, nb * k0, bg->kin_groups_pad, false, 0, 1, 0));
+            CRM_TRY(launch_kin_sum_e1(st, S, ld_ah, KK, k2, k1, (int)groups, (long)nb * k0, ctx->ws_AH.as<double>(), ld_ah));
+            kr_flops += 2.0 * (double)bg->kin_rows * KK * (double)k0 * nb + 2.0 * (double)bg->kin_groups_pad * mk * k2 * (double)k0 * nb;
+            const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
+            CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
+                                        ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+            CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+        } else if (via_H) {
             GemmProblem p{};
             p.X = Gt; p.ldx = ldb; p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;
             p.Y = bg->H.as<double>(); p.ldy = bg->ldh;

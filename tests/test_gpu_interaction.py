@@ -251,6 +251,9 @@ def test_shared_h_route_of_the_multi_gene_scan():
     panel = GenotypePanel(c.G, groups=None)
     lib = _lib.load()
     out = {}
+    # (the routes under test are the two that contract over all cells; the donor-structured one is switched off here and
+    # has its own test, test_kinship_structure_route_equals_the_direct_route)
+    _lib.check(lib.crm_test_set_kinship_route(_engine._context(0), 0))
     try:
         for mode in (0, 1):
             _lib.check(lib.crm_test_set_shared_h(_engine._context(0), mode))
@@ -261,6 +264,7 @@ def test_shared_h_route_of_the_multi_gene_scan():
                 out[mode, name] = scan_interaction_many(crms, panel, **kw)
     finally:
         _lib.check(lib.crm_test_set_shared_h(_engine._context(0), -1))
+        _lib.check(lib.crm_test_set_kinship_route(_engine._context(0), 1))
     for name in ("plain", "idx_E", "idx_G"):
         (pv0, info0), (pv1, info1) = out[0, name], out[1, name]
         for k in info0:
@@ -643,3 +647,53 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
     half = BackgroundBuilder(c.E, B, _RHO_GRID, mine=even)
     with pytest.raises(Exception, match="under construction"):
         CellRegMap(c.y, c.E, W=c.W, background=half._bg, **kw).scan_interaction(panel)
+
+
+@pytest.mark.parametrize("hook", ["none", "E", "G"])
+def test_kinship_structure_route_equals_the_direct_route(hook):
+    """Mode C through get_L_values with an "expanded" kinship factor (rows of a donor-level factor repeated for the cells
+    of each donor, ragged donors, a DENSE donor-level factor): the dense scan of general genotypes forms
+    Q0(rho*)'(g o E0) = Mix(rho*)' [H'(g o E0)] with H'(g o E0) built donor by donor (crm_background_set_kinship_groups)
+    instead of contracting against Q0(rho*) over all cells.  Same statistics as the direct route (test hook) to rounding,
+    and the oracle's; one phenotype and several."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values, scan_interaction_many
+    from oracle.crm import OracleCellRegMap, khatri_rao_halves
+
+    rng = np.random.default_rng(77)
+    donors, k0, p = 9, 5, 40
+    sizes = rng.integers(7, 40, size=donors)
+    donor = np.repeat(np.arange(donors), sizes)
+    n = donor.size
+    hKd = rng.normal(size=(donors, 6))                     # donor-level factor of rank 6 < donors, dense
+    hK = hKd[donor]
+    E = rng.normal(size=(n, k0))
+    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 1))], axis=1)
+    G = rng.normal(size=(n, p))                            # general genotypes: the dense path
+    y = 0.5 * G[:, 3] * E[:, 0] + E @ rng.normal(size=k0) * 0.3 + hK @ rng.normal(size=6) * 0.2 + rng.normal(size=n)
+    idx = rng.permutation(n)
+    hooks = {} if hook == "none" else ({"idx_E": idx} if hook == "E" else {"idx_G": idx})
+    crm = CellRegMap(y, E, W=W, Ls=get_L_values(hK, E))
+    lib, ctx = _lib.load(), _engine._context(0)
+    panel = GenotypePanel(G, groups=None)
+    pv, info, st = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+    _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+    try:
+        pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+    assert np.array_equal(info["rho1"], info0["rho1"])
+    assert np.array_equal(st["delta"], st0["delta"])       # the null fits do not depend on the route
+    scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
+    assert np.all(np.abs(st["Q"] - st0["Q"]) <= 1e-10 * scale)
+    assert np.all(np.abs(st["F"] - st0["F"]) <= 1e-10 * np.abs(st0["F"]).max(axis=(1, 2), keepdims=True))
+    assert np.all(np.abs(pv - pv0) <= 1e-6 * pv0 + 1e-13)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, Ls=khatri_rao_halves(hK, E)).scan_interaction(G, return_stats=True, **hooks)
+    _compare(pv, info, st, opv, oinfo, ost)
+    # several phenotypes in one pass take the same route for H'(g o E0)
+    ys = [y, y[rng.permutation(n)], rng.normal(size=n)]
+    crms = [crm] + [CellRegMap(v, E, W=W, Ls=get_L_values(hK, E), background=crm._bg) for v in ys[1:]]
+    mpv, minfo = scan_interaction_many(crms, panel, **hooks)
+    for i, obj in enumerate(crms):
+        spv, sinfo = obj.scan_interaction(panel, progress=False, **hooks)
+        assert np.array_equal(minfo["rho1"][i], sinfo["rho1"])
+        assert np.all(np.abs(mpv[i] - spv) <= 1e-7 * spv + 1e-13)
