@@ -142,7 +142,7 @@ def _kinship_groups(hK):
     if key in _kin_cache:
         _kin_cache.move_to_end(key)
         return _kin_cache[key]
-    found = detect_groups(hK, max_groups=2048, sample_columns=min(64, hK.shape[1]))
+    found = detect_groups(hK, max_groups=2048, sample_columns=hK.shape[1])   # (every column: an indicator factor has one 1 per row)
     out = None
     if found is not None:
         group, reps = found

@@ -187,6 +187,8 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     });
 }
 
+int crm_background_kinship_groups(const crm_background* bg) { return (bg && bg->kin) ? (int)bg->kin_groups : 0; }
+
 int crm_background_rank(const crm_background* bg, int i) {
     return crm::guarded_on("crm_background_rank", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return -1;

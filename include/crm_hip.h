@@ -81,6 +81,8 @@ int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k
  * route to rounding.  Optional: without it, or when k1 + k2 > 128, the scan contracts against Q0 itself. */
 int crm_background_set_kinship_groups(crm_background* bg, const int* group, long groups, const double* hKd, long m,
                                       const double* U, int k2);
+/* Number of donors of the kinship structure in use by this background (0: none announced, or not usable). */
+int crm_background_kinship_groups(const crm_background* bg);
 /* The same constructor split over several processes, one per GPU (the grid points are decomposed
  * by different ranks, the results exchanged over RCCL; cellregmap_amd/distributed.py drives it):
  *   begin    -- H = [E1, B] (B explicit, or U / hK as in crm_background_create_hadamard when B == NULL), Gram
