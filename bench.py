@@ -43,12 +43,22 @@ def algorithmic_flops(n, r_list, r_star, k0, c):
     return 2.0 * n * R + 2.0 * n * r_star * k0 + n * k0 * (k0 + 1) + 2.0 * n * k0 * (c + 2) + r_star * k0 * (k0 + 1)
 
 
-def executed_flops(n, cols, r_list, r_star, k0, c, fast_rotation):
-    """What the engine executes per variant-test: the rotations go through the mixing matrices,
-    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones -- when the background offers them."""
+def executed_flops(n, cols, r_list, r_star, k0, c, fast_rotation, kin=None):
+    """What the engine executes per variant-test.  fast_rotation: the rotations go through the mixing matrices,
+    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones.  kin = (k1, k2, donors_padded, m): the
+    background knows the donor structure of its kinship factor, so H'g and H'(g o E0) are formed donor by donor
+    (2 n (k1 + k2) flops per product column plus the contraction over the donors with the donor-level factor) and
+    Q0(rho*)'(g o E0) is taken as Mix(rho*)'[H'(g o E0)]: 2 cols r* k0 instead of 2 n r* k0."""
     R = float(sum(r_list))
-    rot = 2.0 * n * cols + 2.0 * cols * R if fast_rotation else 2.0 * n * R
-    return rot + 2.0 * n * r_star * k0 + n * k0 * (k0 + 1) + 2.0 * n * k0 * (c + 2) + r_star * k0 * (k0 + 1)
+    if kin is not None:
+        k1, k2, dpad, m = kin
+        per_column = 2.0 * n * (k1 + k2) + 2.0 * dpad * m * k2        # donor sums + contraction over the donors
+        rot = per_column + 2.0 * cols * R
+        contraction = per_column * k0 + 2.0 * cols * r_star * k0
+    else:
+        rot = 2.0 * n * cols + 2.0 * cols * R if fast_rotation else 2.0 * n * R
+        contraction = 2.0 * n * r_star * k0
+    return rot + contraction + n * k0 * (k0 + 1) + 2.0 * n * k0 * (c + 2) + r_star * k0 * (k0 + 1)
 
 
 def _free_port():
@@ -342,11 +352,20 @@ def main():
     # ---- roofline of the dominant kernel (Khatri-Rao contraction, FP64 MFMA bound) ----------
     kr_s = kr_ms.value * 1e-3
     achieved = kr_fl.value / kr_s * 1e-12 if kr_s > 0 else 0.0
+    kin_groups = lib.crm_background_kinship_groups(crm._bg.handle) if os.environ.get("CRM_KIN_ROUTE", "1") != "0" else 0
+    if kin_groups:
+        kernel = ("gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>: A~ = Mix(rho*)' [H'(g o E0)] for every variant of a block, one "
+                  "launch per block (a plain cols x (variants k0) x r product over the cols = k1 + k2 m columns of the half "
+                  "factor, LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route, which "
+                  "forms H'(g o E0) donor by donor first (DESIGN.md 6c); achieved = its executed flops 2 cols r* k0 per "
+                  "variant / its duration by HIP events on the library's stream")
+    else:
+        kernel = ("gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
+                  "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
+                  "+ gemm_tn_glds_kernel<true, KRQ, ECQ, false, 160> over the last 128 + r mod 128 columns when r mod 128 <= 32 "
+                  "(cfg3: 38 x 128 + 136 of r = 5000); achieved / avg_launch_ms cover both launches of a block")
     roofline = {
-        "bound": "mfma", "kernel": "gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
-                                   "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
-                                   "+ gemm_tn_glds_kernel<true, KRQ, ECQ, false, 160> over the last 128 + r mod 128 columns when r mod 128 <= 32 "
-                                   "(cfg3: 38 x 128 + 136 of r = 5000); achieved / avg_launch_ms cover both launches of a block",
+        "bound": "mfma", "kernel": kernel,
         "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
         "launches": int(kr_n.value), "avg_launch_ms": round(kr_ms.value / max(kr_n.value, 1), 3),
@@ -357,13 +376,15 @@ def main():
     # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
     # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
     form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
-            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode()}
+            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
+            "kinship_route": bool(kin_groups)}
     roofline["kernel_form"] = form
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             shape = pmc["launch_shape"]
-            same_form = pmc.get("kernel_form", {"contraction_sync": True, "tail_launch": True, "library": "0.1.0"}) == form
+            same_form = {"kinship_route": False, **pmc.get("kernel_form", {"contraction_sync": True, "tail_launch": True,
+                                                                           "library": "0.1.0"})} == form
             if (args.config == shape["config"] and roofline["launches"] > 0 and same_form
                     and abs(roofline["flops_per_launch"] / shape["flops_per_launch"] - 1.0) < 0.05):
                 roofline["traffic"] = pmc["traffic_bytes_per_launch"]
@@ -378,7 +399,11 @@ def main():
         roofline["traffic_note"] = "no committed PMC profile matches this launch shape and kernel form"
     rstar = float(np.mean([ranks[int(round(x * 10))] if len(ranks) > 1 else ranks[0] for x in rho1[: min(steps, weak_blocks) * batch]]))
     f_alg = algorithmic_flops(n, ranks, rstar, k0, c_cov)
-    f_exe = executed_flops(n, cols, ranks, rstar, k0, c_cov, fast_rotation=True)
+    kin = None
+    if kin_groups:
+        k2_, m_ = (Ls.us.shape[1], Ls.hK.shape[1]) if args.mode == "C" else (0, 0)
+        kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_)
+    f_exe = executed_flops(n, cols, ranks, rstar, k0, c_cov, fast_rotation=True, kin=kin)
     per_rank_rate = value / world
 
     # ---- the same steps through the donor-collapsed path (exact for donor-constant genotypes, which
@@ -477,6 +502,8 @@ def main():
                         f"{steps} steps x {batch} variants per GPU of the {p_total}-variant panel, 1 gene",
             "batch_variants": batch, "cells": n, "contexts": k0, "rho_grid": len(ranks),
             "null_fit": "brent-1e-6" + ("+polish" if args.polish else ""),
+            "route": ("kinship structure of the background (%d donors): H'(g o E0) donor by donor, then Mix(rho*)'" % kin_groups)
+                     if kin_groups else "direct contraction against Q0(rho*) over all cells",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
@@ -484,7 +511,8 @@ def main():
                        "frac_of_fp64_mfma_peak": round(f_exe * per_rank_rate * 1e-12 / PEAK_FP64_MFMA_TFLOPS, 4),
                        "algorithmic_flop_per_variant": f_alg,
                        "algorithmic_equivalent_tflops": round(f_alg * per_rank_rate * 1e-12, 3),
-                       "note": "per GPU; 'executed' counts what the kernels do (rotations through the mixing matrices); "
+                       "note": "per GPU; 'executed' counts what the kernels do (rotations through the mixing matrices; with "
+                               "the background's kinship structure: H'g and H'(g o E0) donor by donor, then Mix(rho*)'); "
                                "the SURVEY 8(d) count (rotations as 2 n sum r) is a throughput equivalent, not a roofline fraction"},
         # SURVEY 8(d) asks for both views; the path is bound by the matrix pipe, not by HBM
         "hbm_view": (lambda b_alg: {"algorithmic_bytes_per_variant": round(b_alg), "achieved_GBps": round(b_alg * per_rank_rate * 1e-9, 3),

@@ -357,7 +357,7 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
     }
 }
 
-template <bool KR, int KRQ, int ECQ, bool TR = false, int BN = 128>
+template <bool KR, int KRQ, int ECQ, bool TR = false, int BN = 128, int TAG = 0>   // TAG: see GemmTune::tag
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_glds_kernel(const GemmProblem* __restrict__ probs,
                                                                int mtiles_max, long cells_per_split, long cells_total,
                                                                long split_stride, int k0) {
@@ -505,8 +505,12 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
 #undef CRM_GLDS_T
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);
-        hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,
-                           cps, cells, split_stride, 0);
+        if (ctx->tune.tag)
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>), grid, dim3(256), lds, st, probs_dev, mt,
+                               cps, cells, split_stride, 0);
+        else
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,
+                               cps, cells, split_stride, 0);
     }
     CRM_HIP(hipGetLastError());
     if (sync)

@@ -961,12 +961,16 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     const bool kin_route = bg->kin && bg->fast_T && ctx->fast_T && !collapsed && ctx->kin_route && s_bytes <= ((size_t)48 << 30);
     if (bg->fast_T && ctx->fast_T && (ng > 1 || kin_route) && !collapsed) {  // operands of the routes through H (step 6)
         CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
-        CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)bg->ldh * ld_xg));
+        if (ng > 1) CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)bg->ldh * ld_xg));
         CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
     }
     if (kin_route) {
         CRM_TRY(ctx->ws_S.ensure(s_bytes));
-        CRM_TRY(ctx->ws_Gk.ensure(sizeof(double) * (size_t)bg->kin_rows * ldb));
+        CRM_TRY(ctx->ws_Gk.ensure(sizeof(double) * (size_t)bg->kin_rows * std::max(ldb, ldp)));
+        CRM_TRY(ctx->ws_S2.ensure(sizeof(double) * (size_t)bg->kin_groups_pad * KK * ldb));
+        if (bg->kin_groups_pad > bg->kin_groups)
+            CRM_HIP(hipMemsetAsync(ctx->ws_S2.as<double>() + (size_t)bg->kin_groups * KK * ldb, 0,
+                                   sizeof(double) * (size_t)(bg->kin_groups_pad - bg->kin_groups) * KK * ldb, st));
         // rows of the padding donors (kin_groups .. kin_groups_pad) are operands of the contraction over the donors
         if (bg->kin_groups_pad > bg->kin_groups)
             CRM_HIP(hipMemsetAsync(ctx->ws_S.as<double>() + (size_t)bg->kin_groups * KK * ld_ah, 0,
@@ -1073,7 +1077,40 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         //    flops per variant instead of 2 n sum r.
         const bool fastT = !collapsed && bg->fast_T && ctx->fast_T;
         if (!fastT && !collapsed) CRM_TRY(crm_background_require_q0(bg, -1));
-        if (fastT) {
+        if (fastT && kin_route) {
+            // H'G donor by donor (as H'(g o E0) in step 6): per donor [us | E1]' G over its own cells, then the L rows by a
+            // contraction over the donors with hKd and the E1 rows as sums over the donors
+            double* Gk = ctx->ws_Gk.as<double>();
+            double* S2 = ctx->ws_S2.as<double>();
+            const int k1 = bg->kin_k1, k2 = bg->kin_k2;
+            const long groups = bg->kin_groups, mk = bg->kin_cols;
+            CRM_TRY(launch_gather_rows(st, Gb, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
+            std::vector<GemmProblem> kp((size_t)groups + k2);
+            long maxlen = GEMM_BK;
+            for (long d = 0; d < groups; d++) {
+                GemmProblem p{};
+                p.X = bg->kin_Y.as<double>() + bg->kin_row0[d] * 128; p.ldx = 128;
+                p.Y = Gk + bg->kin_row0[d] * ldb; p.ldy = ldb;
+                p.C = S2 + (size_t)d * KK * ldb; p.ldc = ldb;
+                p.M = KK; p.N = nb; p.cells = bg->kin_len[d];
+                maxlen = std::max(maxlen, bg->kin_len[d]);
+                kp[d] = p;
+            }
+            for (int j = 0; j < k2; j++) {
+                GemmProblem p{};
+                p.X = bg->kin_hKd.as<double>(); p.ldx = bg->kin_ldh;
+                p.Y = S2 + (size_t)j * ldb; p.ldy = (long)KK * ldb;
+                p.C = ctx->ws_TH.as<double>() + (size_t)(k1 + (long)j * mk) * ldb; p.ldc = ldb;
+                p.M = (int)mk; p.N = nb;
+                kp[groups + j] = p;
+            }
+            GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+            CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * kp.size(), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, KK, nb, maxlen, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, k2, (int)mk, nb, bg->kin_groups_pad, false, 0, 1, 0));
+            CRM_TRY(launch_kin_sum_e1(st, S2, ldb, KK, k2, k1, (int)groups, nb, ctx->ws_TH.as<double>(), ldb));
+            CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+        } else if (fastT) {
             GemmProblem p{};
             p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
             p.C = ctx->ws_TH.as<double>(); p.ldc = ldb; p.M = (int)bg->cols; p.N = nb;
@@ -1236,6 +1273,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.Y = tab->Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
                 p.ldc = (long)k0 * ldA;
                 p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
+            } else if (via_H && kin_route && ng == 1) {   // (AH is in pair order already, see below)
+                p.X = ctx->ws_AH.as<double>() + (size_t)start[i] * k0; p.ldx = ld_ah;
+                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+                p.ldc = ldA;
+                p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+                kr_flops += 2.0 * (double)bg->cols * (double)bg->r[i] * (double)k0 * (double)cnt[i];
             } else if (via_H) {
                 p.X = ctx->ws_XG.as<double>() + (size_t)start[i] * k0; p.ldx = ld_xg;
                 p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
@@ -1268,8 +1311,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 CRM_HIP(hipEventCreate(&b));
                 ctx->timed.emplace_back(a, b);
             }
-            CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
+            // (kinship-structure route: the pair brackets the dominant launch alone, the Mix(rho*)' product further down)
+            if (!kin_route) CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
+        double kin_prep_flops = 0.0;
         if (via_H && kin_route) {
             // AH = H'(g o E0) without an n-length contraction against the cols columns of H:
             // (a) the block in donor order; (b) per donor d' the Khatri-Rao contraction over its own cells against
@@ -1279,16 +1324,23 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             double* S = ctx->ws_S.as<double>();
             const int k1 = bg->kin_k1, k2 = bg->kin_k2;
             const long groups = bg->kin_groups, mk = bg->kin_cols;
-            CRM_TRY(launch_gather_rows(st, Gt, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
+            // one phenotype: the columns are taken in the rho*-sorted pair order (Gs) straight away, so that AH is the
+            // operand of the Mix products as it stands; several phenotypes share a variant between pairs: block order, then
+            // the pair gather below
+            const bool in_pair_order = ng == 1;
+            const double* Gsrc = in_pair_order ? Gs : Gt;
+            const long ldg_k = in_pair_order ? ldp : ldb;
+            const int ncol = in_pair_order ? npairs : nb;
+            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, (int)ldg_k, Gk, ldg_k));
             std::vector<GemmProblem> kp((size_t)groups + k2);
             long maxlen = GEMM_BK;
             for (long d = 0; d < groups; d++) {
                 GemmProblem p{};
-                p.X = Gk + bg->kin_row0[d] * ldb; p.ldx = ldb;
+                p.X = Gk + bg->kin_row0[d] * ldg_k; p.ldx = ldg_k;
                 p.E = g0->kinEp.as<double>() + bg->kin_row0[d] * g0->ld_ep; p.lde = g0->ld_ep; p.k0 = k0;
                 p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * 128; p.ldy = 128;
                 p.C = S + (size_t)d * KK * ld_ah; p.ldc = ld_ah;
-                p.M = nb * k0; p.N = KK; p.cells = bg->kin_len[d];
+                p.M = ncol * k0; p.N = KK; p.cells = bg->kin_len[d];
                 maxlen = std::max(maxlen, bg->kin_len[d]);
                 kp[d] = p;
             }
@@ -1297,18 +1349,21 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.X = bg->kin_hKd.as<double>(); p.ldx = bg->kin_ldh;
                 p.Y = S + (size_t)j * ld_ah; p.ldy = (long)KK * ld_ah;
                 p.C = ctx->ws_AH.as<double>() + (size_t)(k1 + (long)j * mk) * ld_ah; p.ldc = ld_ah;
-                p.M = (int)mk; p.N = nb * k0;
+                p.M = (int)mk; p.N = ncol * k0;
                 kp[groups + j] = p;
             }
             GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
             CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * kp.size(), hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, nb * k0, KK, maxlen, k0));
-            CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, k2, (int)mk, nb * k0, bg->kin_groups_pad, false, 0, 1, 0));
-            CRM_TRY(launch_kin_sum_e1(st, S, ld_ah, KK, k2, k1, (int)groups, (long)nb * k0, ctx->ws_AH.as<double>(), ld_ah));
-            kr_flops += 2.0 * (double)bg->kin_rows * KK * (double)k0 * nb + 2.0 * (double)bg->kin_groups_pad * mk * k2 * (double)k0 * nb;
-            const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
-            CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
-                                        ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+            CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, KK, maxlen, k0));
+            CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, k2, (int)mk, ncol * k0, bg->kin_groups_pad, false, 0, 1, 0));
+            CRM_TRY(launch_kin_sum_e1(st, S, ld_ah, KK, k2, k1, (int)groups, (long)ncol * k0, ctx->ws_AH.as<double>(), ld_ah));
+            kin_prep_flops = 2.0 * (double)bg->kin_rows * KK * (double)k0 * ncol + 2.0 * (double)bg->kin_groups_pad * mk * k2 * (double)k0 * ncol;
+            (void)kin_prep_flops;   // (outside the timed pair: the roofline figure is the Mix product's own)
+            if (!in_pair_order) {
+                const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
+                CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
+                                            ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+            }
             CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
         } else if (via_H) {
             GemmProblem p{};
@@ -1326,7 +1381,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * nz, hipMemcpyHostToDevice, st));
         if (collapsed)
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, (int)((long)k0 * ldq), mp, false, 0, 1, 0));
-        else if (via_H)
+        else if (via_H && kin_route) {
+            if (timing) CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
+            struct Restore { crm_ctx* c; ~Restore() { c->tune.tag = 0; } } restore{ctx};
+            ctx->tune.tag = 1;
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
+        } else if (via_H)
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
         else {
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, kr_split, (long)a_slab));

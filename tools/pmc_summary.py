@@ -13,17 +13,23 @@ import sys
 
 
 def blocks(path, counter):
-    """[(counter value, seconds)] per block: dispatches in time order, a block starts at each *_sync_kernel dispatch;
-    toy-sized launches before the first one are dropped."""
+    """[(counter value, seconds)] per block: dispatches in time order.  Kinship-structure route: every dispatch of the
+    tagged plain product is a block.  Direct route: a block starts at each *_sync_kernel dispatch and takes the 160-column
+    tail launch behind it; toy-sized launches before the first one are dropped."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     out = []
     for r in rows:
-        big = "sync_kernel" in r["Kernel_Name"] or float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) > 2e8
+        name = r["Kernel_Name"]
         val, sec = float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+        if "128, 1>" in name:
+            if sec > 0.02:                       # (full-size blocks only)
+                out.append([val, sec])
+            continue
+        big = "sync_kernel" in name or sec > 0.2
         if big:
             out.append([val, sec])
-        elif out and "160>" in r["Kernel_Name"]:
+        elif out and "160>" in name:
             out[-1][0] += val
             out[-1][1] += sec
     return out[1:] if len(out) > 1 else out      # the first block is the warm-up step
@@ -50,21 +56,37 @@ def variant(d):
 
 def main():
     dirs = sys.argv[1:]
-    names = ["aligned (default)", "one workgroup per tile (CRM_CONTRACTION_SYNC=0)"]
+    kin = os.environ.get("CRM_KIN_ROUTE", "1") != "0"
+    names = ["default", "one workgroup per tile (CRM_CONTRACTION_SYNC=0)"]
     variants = {names[i]: variant(d) for i, d in enumerate(dirs)}
     first = variants[names[0]]
-    alg = 9.75e9
+    if kin:
+        # operands of one launch at config 3: H'(g o E0) 5050 x 204 800 doubles read once, Mix(rho*) 5050 x 5000 per
+        # selected grid point, A~ 204 800 x 5000 written
+        alg = 8.0 * (5050 * 204800 + 5050 * 5000 + 204800 * 5000)
+        shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096,
+                 "flops_per_launch": 2.0 * 5050 * 5000 * 50 * 4096}
+        what = ("rocprofv3 --pmc over bench.py's own launches (tools/pmc_bench.sh; bench.py --steps 2 --warmup 1, cfg3): the "
+                "dominant launch of the kinship-structure route, gemm_tn_glds_kernel<false, 1, 0, false, 128, 1> = "
+                "Mix(rho*)' [H'(g o E0)] for the 4096 variants of a block, one pass per counter group; summary by "
+                "tools/pmc_summary.py")
+        note = "H'(g o E0) 8.27 GB + Mix(rho*) 0.2 GB read once, A~ 8.19 GB written"
+    else:
+        alg = 9.75e9
+        shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13}
+        what = ("rocprofv3 --pmc over bench.py's own launches (tools/pmc_bench.sh with CRM_KIN_ROUTE=0; bench.py --steps 2 "
+                "--warmup 1, cfg3, 4096 variants per launch = one gemm_tn_glds_sync_kernel<true,...> launch over 38 x 128 "
+                "columns plus one gemm_tn_glds_kernel<true,...,160> launch over the last 136, summed), one pass per counter "
+                "group; summary by tools/pmc_summary.py")
+        note = ("Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
+                "(SURVEY 8d per-unit figure x 4096)")
     out = {
-        "collected_on": "rocprofv3 --pmc over bench.py's own launches (tools/pmc_bench.sh; bench.py --steps 2 --warmup 1, cfg3, "
-                        "4096 variants per launch = one gemm_tn_glds_sync_kernel<true,...> launch over 38 x 128 columns plus one "
-                        "gemm_tn_glds_kernel<true,...,160> launch over the last 136, summed), one pass per counter group, "
-                        "kernel filter gemm_tn_glds_(sync_)?kernel<true; summary by tools/pmc_summary.py",
-        "launch_shape": {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13},
+        "collected_on": what,
+        "launch_shape": shape,
         # bench.py quotes this profile only for the same kernel form (bench.py: roofline["kernel_form"])
-        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.3.0"},
+        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.3.0", "kinship_route": kin},
         "algorithmic_bytes_per_launch": alg,
-        "algorithmic_bytes_note": "Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
-                                  "(SURVEY 8d per-unit figure x 4096)",
+        "algorithmic_bytes_note": note,
         "traffic_bytes_per_launch": first["traffic_bytes_per_launch"],
         "traffic_over_algorithmic": first["traffic_bytes_per_launch"] / alg,
         "gfx950_corrections": "FETCH_SIZE doubled (16 B/lane streams are tallied at half their size, MI355X_MICROARCH.md HBM section); "
