@@ -178,7 +178,8 @@ def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
                                                   us.shape[1], _lib.ptr(hK), hK.shape[1], rho.shape[0],
                                                   _lib.ptr(rho), float(rel_tol), ctypes.byref(h)))
     bg = _Background(h, rho, device)
-    _announce_kinship_groups(bg, halves)
+    if cache:   # (the per-SNP backgrounds of the effect-size path are never scanned: nothing to announce)
+        _announce_kinship_groups(bg, halves)
     if cache:
         _bg_cache[key] = bg
         while len(_bg_cache) > BACKGROUND_CACHE_SIZE:
@@ -317,7 +318,16 @@ def candidate_groups(G, max_groups=2048, sample_columns=64):
     # sampled entries; a row-wise np.unique, ~10x slower, only serves as the fallback for a collision
     key += 0.0  # -0.0 -> +0.0
     bits = key.view(np.uint64)
-    proj = (bits * _projection(key.shape[1])).sum(axis=1, dtype=np.uint64)
+    # (the bit patterns of small integers as doubles end in ~50 zero bits -- 1.0 is 0x3FF0000000000000 -- and a product
+    # with an odd multiplier keeps that many zero bits: mix the pattern first, splitmix64's finaliser, so that an
+    # indicator or dosage matrix does not collide into a few thousand hash values and fall back to the row-wise unique)
+    with np.errstate(over="ignore"):
+        mixed = bits ^ (bits >> np.uint64(30))
+        mixed = mixed * np.uint64(0xBF58476D1CE4E5B9)
+        mixed ^= mixed >> np.uint64(27)
+        mixed = mixed * np.uint64(0x94D049BB133111EB)
+        mixed ^= mixed >> np.uint64(31)
+        proj = (mixed * _projection(key.shape[1])).sum(axis=1, dtype=np.uint64)
     _, first, inv = np.unique(proj, return_index=True, return_inverse=True)
     inv = np.asarray(inv).reshape(-1)
     if not (bits == bits[first[inv]]).all():

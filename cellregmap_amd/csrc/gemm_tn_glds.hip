@@ -436,7 +436,10 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
                             "workgroup per tile\n", *ctx->sync_timeouts_host);
     }
     const int sync_every = ctx->tune.sync;
-    const bool sync = sync_every > 0 && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024;
+    // (long contractions only: a generation of short tiles -- the per-donor launches of the kinship-structure route, 13 stages --
+    // does not pay for its re-alignment wait: 22 ms in this form against 17 ms with one workgroup per tile; nor does the plain
+    // Mix(rho*)' product of that route, 231 against 228 ms per block)
+    const bool sync = sync_every > 0 && khatri_rao && bn == 128 && (long)mt * nt * ksplit * nz > 1024 && cells / ksplit >= 1024;
     unsigned* sync_counters = nullptr;
     if (sync) {
         CRM_TRY(ctx->sync_counters.ensure(64));

@@ -92,7 +92,7 @@ def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
     from cellregmap_amd import _lib
 
     lib, h = ctx
-    cells, B, k0, N = 40, 1300, 13, 1100         # 133 row tiles x 9 column tiles = 1197 tiles
+    cells, B, k0, N = 1040, 1300, 13, 1100       # 133 row tiles x 9 column tiles = 1197 tiles; 65 stages (the form takes >= 64)
     rng = np.random.default_rng(every)
     G = rng.normal(size=(cells, B))
     E = rng.normal(size=(cells, k0))
