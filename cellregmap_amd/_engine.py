@@ -142,7 +142,11 @@ def _kinship_groups(hK):
     if key in _kin_cache:
         _kin_cache.move_to_end(key)
         return _kin_cache[key]
-    found = detect_groups(hK, max_groups=2048, sample_columns=hK.shape[1])   # (every column: an indicator factor has one 1 per row)
+    found = None
+    # (a sample of the columns first: rows that already differ there -- the concatenated halves of an explicit mode C list --
+    # are dismissed for the price of n x 64 entries; then every column: an indicator factor has one 1 per row)
+    if hK.shape[1] <= 64 or candidate_groups(hK, max_groups=2048, sample_columns=64) is not None:
+        found = detect_groups(hK, max_groups=2048, sample_columns=hK.shape[1])
     out = None
     if found is not None:
         group, reps = found
@@ -155,12 +159,19 @@ def _kinship_groups(hK):
 
 def _announce_kinship_groups(bg, halves):
     """Tell the library about the donor structure of the kinship factor (``crm_background_set_kinship_groups``): the
-    dense scan then forms H'(g o E0) donor by donor instead of contracting every variant against Q0(rho*) over all cells."""
-    found = _kinship_groups(halves.hK)
+    dense scan then forms H'(g o E0) donor by donor instead of contracting every variant against Q0(rho*) over all cells.
+    ``halves``: the factored halves of mode C, or -- mode B, ``hS = [sqrt(rho) E1, sqrt(1 - rho) hK]`` -- the kinship factor
+    itself, which is the same structure with a single column of ones in the place of ``us``."""
+    if isinstance(halves, HadamardHalves):
+        hK, us = halves.hK, halves.us
+    else:
+        hK = np.ascontiguousarray(halves, dtype=float)
+        us = np.ones((hK.shape[0], 1))
+    found = _kinship_groups(hK)
     if found is None:
         return
     group, hKd = found
-    us = _lib.f64(halves.us)
+    us = _lib.f64(us)
     _lib.check(_lib.load().crm_background_set_kinship_groups(bg.handle, _lib.ptr(group), hKd.shape[0], _lib.ptr(hKd),
                                                              hKd.shape[1], _lib.ptr(us), us.shape[1]))
 
@@ -205,6 +216,8 @@ def _make_background_dense(E1, B, rho, device, rel_tol=0.0, cache=True):
                                          0 if Bc is None else Bc.shape[1], rho.shape[0], _lib.ptr(rho),
                                          float(rel_tol), ctypes.byref(h)))
     bg = _Background(h, rho, device)
+    if cache and Bc is not None:   # mode B: B is the kinship factor itself (anything else is dismissed on a column sample)
+        _announce_kinship_groups(bg, Bc)
     if cache:
         _bg_cache[key] = bg
         while len(_bg_cache) > BACKGROUND_CACHE_SIZE:
@@ -227,7 +240,7 @@ class BackgroundBuilder:
         flags = np.ones(nrho, np.int32) if mine is None else np.ascontiguousarray(mine, dtype=np.int32)
         E1c = _lib.f64(E1)
         h = ctypes.c_void_p()
-        self._halves = B if isinstance(B, HadamardHalves) else None
+        self._halves = B if (isinstance(B, HadamardHalves) or B is not None) else None
         if isinstance(B, HadamardHalves):
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
                                                 B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.us), B.us.shape[1],
