@@ -57,7 +57,8 @@ struct crm_background {
     long kin_rows = 0;                          // cells in donor order, every donor's run padded to a multiple of 16 rows
     std::vector<long> kin_row0, kin_len;        // first row / padded length of each donor's run
     crm::DevBuf kin_map;                        // int[kin_rows]: cell of a sorted row, -1 for padding
-    crm::DevBuf kin_Y;                          // [kin_rows x 128]: columns 0..k2-1 us, k2..k2+k1-1 E1, donor order
+    crm::DevBuf kin_Y;                          // [kin_rows x kin_ldy]: columns 0..k2-1 us, k2..k2+k1-1 E1, donor order
+    long kin_ldy = 128;
     crm::DevBuf kin_hKd;                        // [kin_groups_pad x kin_ldh]
     long kin_ldh = 0;
     // shared donor tables, most recently used first (at most DT_CACHE entries)

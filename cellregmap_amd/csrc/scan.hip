@@ -138,7 +138,7 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     const long n = bg->n;
     const int k1 = (int)(bg->cols - (long)k2 * m);
     // only backgrounds that kept their half factor H = [E1, L_1 .. L_k2] (thin branch, well-conditioned spectrum) can use it
-    if (!bg->fast_T || !bg->H.ptr || k1 < 1 || k1 + k2 > 128 || groups > 4096) return CRM_OK;
+    if (!bg->fast_T || !bg->H.ptr || k1 < 1 || k1 + k2 > 256 || groups > 4096) return CRM_OK;
     for (long i = 0; i < n; i++)
         if (group[i] < 0 || group[i] >= groups) {
             set_error("kinship groups: group index %d at cell %ld outside [0, %ld)", group[i], i, groups);
@@ -171,8 +171,9 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     bg->kin_k1 = k1;
     bg->kin_k2 = k2;
     bg->kin_ldh = round_up(m, 128);
+    bg->kin_ldy = round_up(k1 + k2, 128);
     CRM_TRY(bg->kin_map.ensure(sizeof(int) * rows));
-    CRM_TRY(bg->kin_Y.ensure(sizeof(double) * rows * 128));
+    CRM_TRY(bg->kin_Y.ensure(sizeof(double) * rows * bg->kin_ldy));
     CRM_TRY(bg->kin_hKd.ensure(sizeof(double) * bg->kin_groups_pad * bg->kin_ldh));
     ScopedBuf dU;
     CRM_TRY(dU.ensure(sizeof(double) * n * k2));
@@ -180,7 +181,7 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     CRM_HIP(hipMemcpyAsync(dU.ptr, U, sizeof(double) * n * k2, hipMemcpyHostToDevice, st));
     CRM_TRY(upload_padded(st, bg->kin_hKd.as<double>(), bg->kin_ldh, bg->kin_groups_pad, hKd, m, groups, m));
     CRM_TRY(launch_kin_operand(st, dU.as<double>(), k2, bg->H.as<double>(), bg->ldh, k1, bg->kin_map.as<int>(), rows,
-                               bg->kin_Y.as<double>(), 128));
+                               bg->kin_Y.as<double>(), bg->kin_ldy));
     CRM_HIP(hipStreamSynchronize(st));
     bg->kin = true;
     return CRM_OK;
@@ -1089,7 +1090,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             long maxlen = GEMM_BK;
             for (long d = 0; d < groups; d++) {
                 GemmProblem p{};
-                p.X = bg->kin_Y.as<double>() + bg->kin_row0[d] * 128; p.ldx = 128;
+                p.X = bg->kin_Y.as<double>() + bg->kin_row0[d] * bg->kin_ldy; p.ldx = bg->kin_ldy;
                 p.Y = Gk + bg->kin_row0[d] * ldb; p.ldy = ldb;
                 p.C = S2 + (size_t)d * KK * ldb; p.ldc = ldb;
                 p.M = KK; p.N = nb; p.cells = bg->kin_len[d];
@@ -1338,7 +1339,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 GemmProblem p{};
                 p.X = Gk + bg->kin_row0[d] * ldg_k; p.ldx = ldg_k;
                 p.E = g0->kinEp.as<double>() + bg->kin_row0[d] * g0->ld_ep; p.lde = g0->ld_ep; p.k0 = k0;
-                p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * 128; p.ldy = 128;
+                p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * bg->kin_ldy; p.ldy = bg->kin_ldy;
                 p.C = S + (size_t)d * KK * ld_ah; p.ldc = ld_ah;
                 p.M = ncol * k0; p.N = KK; p.cells = bg->kin_len[d];
                 maxlen = std::max(maxlen, bg->kin_len[d]);

@@ -41,6 +41,22 @@ def test_c_example_matches_the_python_host(tmp_path):
     blob.astype(np.float64).tofile(path)
     out = subprocess.run([_build(tmp_path), str(path)], capture_output=True, text=True, check=True)
     got = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
-    pv, info = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(GenotypePanel(c.G, groups=None))
+    # The C driver makes the minimal sequence of calls (context, background, gene, panel, scan) and does not announce the
+    # donor structure of the kinship factor, which the Python host finds by itself (crm_background_set_kinship_groups: the
+    # same statistics through another order of summation): the same route on both sides for the bit-for-bit comparison,
+    # the host's default route at the north-star tolerance
+    from cellregmap_amd import _engine, _lib
+
+    lib, ctx = _lib.load(), _engine._context(0)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    panel = GenotypePanel(c.G, groups=None)
+    _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+    try:
+        pv, info = crm.scan_interaction(panel, progress=False)
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
     assert np.array_equal(got[:, 0], pv)
     assert np.array_equal(got[:, 1], info["rho1"])
+    pv_host, info_host = crm.scan_interaction(panel, progress=False)
+    assert np.array_equal(info_host["rho1"], info["rho1"])
+    assert np.all(np.abs(pv_host - pv) <= 1e-5 * pv + 1e-13)

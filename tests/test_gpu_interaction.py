@@ -649,8 +649,8 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
         CellRegMap(c.y, c.E, W=c.W, background=half._bg, **kw).scan_interaction(panel)
 
 
-@pytest.mark.parametrize("hook", ["none", "E", "G"])
-def test_kinship_structure_route_equals_the_direct_route(hook):
+@pytest.mark.parametrize("hook,shape", [("none", "small"), ("E", "small"), ("G", "small"), ("none", "wide")])
+def test_kinship_structure_route_equals_the_direct_route(hook, shape):
     """Mode C through get_L_values with an "expanded" kinship factor (rows of a donor-level factor repeated for the cells
     of each donor, ragged donors, a DENSE donor-level factor): the dense scan of general genotypes forms
     Q0(rho*)'(g o E0) = Mix(rho*)' [H'(g o E0)] with H'(g o E0) built donor by donor (crm_background_set_kinship_groups)
@@ -660,16 +660,17 @@ def test_kinship_structure_route_equals_the_direct_route(hook):
     from oracle.crm import OracleCellRegMap, khatri_rao_halves
 
     rng = np.random.default_rng(77)
-    donors, k0, p = 9, 5, 40
-    sizes = rng.integers(7, 40, size=donors)
+    # "wide": 70 contexts, so that [us | E1] takes 140 columns (two column tiles of the per-donor launch)
+    donors, k0, p, mcols, lo, hi = (9, 5, 40, 6, 7, 40) if shape == "small" else (12, 70, 8, 3, 40, 60)
+    sizes = rng.integers(lo, hi, size=donors)
     donor = np.repeat(np.arange(donors), sizes)
     n = donor.size
-    hKd = rng.normal(size=(donors, 6))                     # donor-level factor of rank 6 < donors, dense
+    hKd = rng.normal(size=(donors, mcols))                 # donor-level factor of rank < donors, dense
     hK = hKd[donor]
     E = rng.normal(size=(n, k0))
     W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 1))], axis=1)
     G = rng.normal(size=(n, p))                            # general genotypes: the dense path
-    y = 0.5 * G[:, 3] * E[:, 0] + E @ rng.normal(size=k0) * 0.3 + hK @ rng.normal(size=6) * 0.2 + rng.normal(size=n)
+    y = 0.5 * G[:, 3] * E[:, 0] + E @ rng.normal(size=k0) * 0.3 + hK @ rng.normal(size=mcols) * 0.2 + rng.normal(size=n)
     idx = rng.permutation(n)
     hooks = {} if hook == "none" else ({"idx_E": idx} if hook == "E" else {"idx_G": idx})
     crm = CellRegMap(y, E, W=W, Ls=get_L_values(hK, E))
