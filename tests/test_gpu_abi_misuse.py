@@ -156,8 +156,20 @@ def test_the_context_is_still_sound(world):
     rc, pv = _scan(world, 0, 24)
     assert rc == OK
     c = world["c"]
-    ref, _ = CellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(GenotypePanel(c.G, groups=None), progress=False)
+    from cellregmap_amd import _engine
+
+    lib, host_ctx = world["_lib"].load(), _engine._context(0)     # (the Python host's own context, not the world's)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    # the world's background was built through the C-ABI without the donor structure of hK; the Python host announces it,
+    # so compare bit for bit on the same (direct) route and to the north-star tolerance on the host's own
+    world["_lib"].check(lib.crm_test_set_kinship_route(host_ctx, 0))
+    try:
+        ref, _ = crm.scan_interaction(GenotypePanel(c.G, groups=None), progress=False)
+    finally:
+        world["_lib"].check(lib.crm_test_set_kinship_route(host_ctx, 1))
     assert np.array_equal(pv, ref)
+    host, _ = crm.scan_interaction(GenotypePanel(c.G, groups=None), progress=False)
+    assert np.all(np.abs(host - pv) <= 1e-5 * pv + 1e-13)
 
 
 def test_out_of_device_memory_is_a_status_code(world):
