@@ -189,6 +189,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
     if (const char* e = getenv("CRM_FAST_GENE_ROTATION")) c->fast_gene_rot = atoi(e) != 0;
     if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = atoi(e) != 0;
+    if (const char* e = getenv("CRM_TILE_BAND")) c->tune.band = atoi(e) > 1 ? atoi(e) : 0;   // (0 or 1: column tile of X first, the walk before round 3)
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));

@@ -104,6 +104,7 @@ struct GemmTune {
     int sync = 1;       // > 0: large Khatri-Rao launches as 8 x 64 persistent workgroups re-aligned every `sync` generations
                         // (default: 7.3x less L2-fabric traffic, L2 hit rate 67 % -> 96 %, for 0.6 % of the kernel's time)
     int shared_h = -1;  // multi-gene scan: -1 cost model, 0 never, 1 always contract once per variant against H
+    int band = 8;       // plain products: > 1 walks the output tiles in bands of `band` column tiles (see gemm_tn_glds_kernel)
     int tag = 0;        // 1 around the scan's dominant plain product (Mix(rho*)' [H'(g o E0)] of the kinship-structure route): the
                         // launch then uses an instantiation of its own, gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>, so that
                         // kernel traces and counter passes can tell it from the other plain products of a block

@@ -25,6 +25,13 @@ typedef const char __attribute__((address_space(1))) * gbptr_t;
 __device__ inline gptr_t at_bytes(gptr_t base, unsigned byte_off) { return (gptr_t)((gbptr_t)base + byte_off); }
 // a wave-uniform global pointer pinned to scalar registers (keeps `base + lane offset` in the
 // saddr + voffset form of the load instead of a per-lane 64-bit add)
+// a pointer the compiler already keeps in scalar registers, made opaque there: without it the 64-bit adds of
+// `base + stage offset + lane offset` are re-associated into per-lane vector adds and the saddr form is lost
+__device__ inline gptr_t opaque_scalar(gptr_t p) {
+    unsigned long v = (unsigned long)p;
+    asm volatile("" : "+s"(v));
+    return (gptr_t)v;
+}
 __device__ inline gptr_t scalar_ptr(gptr_t p) {
     const unsigned long v = (unsigned long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -140,6 +147,18 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
             g_lane[q] = 8u * (unsigned)(row * (int)P.ldx + (col < nb ? col : 0));  // columns >= nb: never read back
         }
     }
+    // row bases of stage 0 for the rows this wavefront fetches, pinned to scalar registers once: inside the loop they
+    // advance by whole stages on the scalar unit (left to the compiler, the wavefront's own row offset stayed in vector
+    // registers and every row cost a 64-bit vector add and two v_readfirstlane -- 30 vector instructions per stage of the
+    // plain kernel, each taken out of the matrix pipe's time)
+    constexpr int YROWS_W = BN == 128 ? 1 : 2, YQN = BN == 160 ? 1 : GEMM_BK / (4 * YROWS_W);
+    gptr_t Yw[YQN], Xw[YQN];
+#pragma unroll
+    for (int q = 0; q < YQN; q++) {
+        const int r = (wave + 4 * q) * YROWS_W;
+        Yw[q] = scalar_ptr(Yg + (long)r * P.ldy);
+        Xw[q] = KR ? nullptr : scalar_ptr(Xg + (long)r * P.ldx);
+    }
     auto issue = [&](int BUF, int s) __attribute__((always_inline)) {
         const long roff = (long)s * GEMM_BK;
         // (re-defined inside the loop body so that the zero-extension stays next to the load and the
@@ -160,10 +179,10 @@ __device__ __forceinline__ void glds_tile(double* smem, const GemmProblem& P, in
 #pragma unroll
         for (int q = 0; q < (BN == 160 ? 0 : GEMM_BK / (4 * YROWS)); q++) {
             const int r = (wave + 4 * q) * YROWS;
-            gptr_t yrow = scalar_ptr(Yg + (roff + r) * P.ldy);
+            gptr_t yrow = opaque_scalar(Yw[q] + roff * P.ldy);
             __builtin_amdgcn_global_load_lds(at_bytes(yrow, yl), (lptr_t)(Ys + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
             if (!KR) {
-                gptr_t xrow = scalar_ptr(Xg + (roff + r) * P.ldx);
+                gptr_t xrow = opaque_scalar(Xw[q] + roff * P.ldx);
                 __builtin_amdgcn_global_load_lds(at_bytes(xrow, yl), (lptr_t)(Xs + (BUF * GEMM_BK + r) * LD), 16, 0, 0);
             }
         }
@@ -364,8 +383,19 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_glds_kernel(c
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
     const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
-    glds_tile<KR, KRQ, ECQ, TR, BN>(smem, P, tile % mtiles_max, tile / mtiles_max, (int)blockIdx.y, cells_per_split,
-                                    cells_total, split_stride, k0);
+    int tm = tile % mtiles_max, tn = tile / mtiles_max;
+    if constexpr (!KR) {
+        // plain products carry the band height of the tile walk in k0 (GemmTune::band): bands of `k0` column tiles of Y,
+        // walked column tile first, so that the workgroups in flight on an XCD (a window of consecutive tile numbers)
+        // cover a near-square block of the output and share both operands' panels in that XCD's L2
+        if (k0 > 1) {
+            const int per_band = k0 * mtiles_max, band = tile / per_band, left = tile - band * per_band;
+            const int ntiles = (int)gridDim.x / mtiles_max, bh = min(k0, ntiles - band * k0);
+            tn = band * k0 + left % bh;
+            tm = left / bh;
+        }
+    }
+    glds_tile<KR, KRQ, ECQ, TR, BN>(smem, P, tm, tn, (int)blockIdx.y, cells_per_split, cells_total, split_stride, k0);
 }
 
 // Persistent form with a soft per-XCD generation sync (the default for Khatri-Rao launches of more than 1024 tiles;
@@ -508,12 +538,13 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
 #undef CRM_GLDS_T
     } else {
         lds += (size_t)2 * GEMM_BK * 128 * sizeof(double);
+        const int band = nt >= 2 * ctx->tune.band ? ctx->tune.band : 0;
         if (ctx->tune.tag)
             hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cps, cells, split_stride, 0);
+                               cps, cells, split_stride, band);
         else
             hipLaunchKernelGGL((gemm_tn_glds_kernel<false, 1, 0>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cps, cells, split_stride, 0);
+                               cps, cells, split_stride, band);
     }
     CRM_HIP(hipGetLastError());
     if (sync)
