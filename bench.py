@@ -377,7 +377,7 @@ def main():
     # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
     form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
             "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
-            "kinship_route": bool(kin_groups)}
+            "kinship_route": bool(kin_groups), "tile_band": int(os.environ.get("CRM_TILE_BAND", "8") or 0)}
     roofline["kernel_form"] = form
     for name in ("r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
         try:

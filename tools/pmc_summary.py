@@ -80,11 +80,18 @@ def main():
                 "group; summary by tools/pmc_summary.py")
         note = ("Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
                 "(SURVEY 8d per-unit figure x 4096)")
+    # the kernel form of the profiled build: from the plain bench.py run that tools/pmc_bench.sh makes beside the passes
+    form = {"contraction_sync": True, "tail_launch": True, "library": "0.3.1", "kinship_route": kin, "tile_band": 8}
+    try:
+        line = open(os.path.join(dirs[0], "bench_plain.json")).read().strip().splitlines()[-1]
+        form = json.loads(line)["roofline"]["kernel_form"]
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
     out = {
         "collected_on": what,
         "launch_shape": shape,
         # bench.py quotes this profile only for the same kernel form (bench.py: roofline["kernel_form"])
-        "kernel_form": {"contraction_sync": True, "tail_launch": True, "library": "0.3.0", "kinship_route": kin},
+        "kernel_form": form,
         "algorithmic_bytes_per_launch": alg,
         "algorithmic_bytes_note": note,
         "traffic_bytes_per_launch": first["traffic_bytes_per_launch"],
