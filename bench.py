@@ -372,6 +372,12 @@ def main():
         "flops_per_launch": kr_fl.value / max(kr_n.value, 1),
         "share_of_step_time": round(kr_s / elapsed, 4),
     }
+    if roofline["share_of_step_time"] < 0.5:
+        # (side records only -- cfg2, mode B: short spectra leave the step spread over several kernels; the default cfg3
+        # line has this kernel at two thirds of the step)
+        roofline["dominant"] = False
+        roofline["note"] = ("the timed kernel is the route's largest single product but takes less than half of the step at "
+                            "this configuration; the kernel-stats profile of the same configuration shows the spread")
     # L2-fabric traffic of that kernel is NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes,
     # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
     # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
