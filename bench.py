@@ -322,7 +322,7 @@ def main():
                                                       None, None, None, None))
             _lib.check(lib.crm_ctx_synchronize(ctx))
 
-        run_multi(min(mb, 512))    # warm-up: work buffers, Q0 of the selected grid points
+        run_multi(min(mb, 2048))   # warm-up: work buffers at the size of a full block, Q0 of the selected grid points
         fence()
         t0 = time.perf_counter()
         run_multi(mb)

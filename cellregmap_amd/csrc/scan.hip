@@ -829,9 +829,13 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
     if (ng > 1) {
         // pair-ordered buffers (A~ and, on the shared-H route, its gathered operand) grow with
-        // min(nrho, ng) * BLK: halve the block while they would take more than 64 GB
+        // min(nrho, ng) * BLK: halve the block while they would take more than 96 GB (a third of the device; 2048 variants
+        // for 64 phenotypes at config 3 -- the per-phenotype launches of a block, null fits above all, run 1.5 times
+        // faster per variant there than on 1024)
+        const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
+        const double cap_gb = cap_env && atof(cap_env) > 0 ? atof(cap_env) : 96.0;
         while (BLK > 128 &&
-               2.0 * sizeof(double) * std::min(nrho, ng) * (double)BLK * g0->k0 * (double)bg->ldq > 64.0 * (1ull << 30))
+               2.0 * sizeof(double) * std::min(nrho, ng) * (double)BLK * g0->k0 * (double)bg->ldq > cap_gb * (1ull << 30))
             BLK /= 2;
     }
     const int max_pairs = ng > 1 ? std::min(nrho, ng) * BLK : BLK;
