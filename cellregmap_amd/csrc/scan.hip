@@ -904,9 +904,15 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     const int ks2 = pick_split(np, (long)mt_blk * (ldZ2 / GEMM_BN));
     const int ks3 = pick_split(np, (long)mt_blk * (ldZ3 / GEMM_BN));
     const long z1_sz = (long)BLK * ldZ1, z2_sz = (long)BLK * ldZ2, z3_sz = (long)BLK * ldZ3;
-    CRM_TRY(ctx->ws_Z.ensure(sizeof(double) * (size_t)(z1_sz * ks1 + z2_sz * ks2 + z3_sz * ks3)));
+    // several phenotypes: Z1 = Gt' [y o E, W o E] of all of them in ONE batched launch per block (a problem per phenotype,
+    // each with its own output region) instead of a skinny launch + reduction per phenotype -- at config 4 those 64 pairs of
+    // launches were an eighth of the scan.  The slices along the cell axis shrink with the number of problems.
+    const bool z1_batched = ng > 1;
+    const int ks1b = z1_batched ? pick_split(np, (long)mt_blk * (ldZ1 / GEMM_BN) * ng) : ks1;
+    const long z1_all = z1_batched ? z1_sz * ks1b * ng : z1_sz * ks1;
+    CRM_TRY(ctx->ws_Z.ensure(sizeof(double) * (size_t)(z1_all + z2_sz * ks2 + z3_sz * ks3)));
     double* dZ1 = ctx->ws_Z.as<double>();
-    double* dZ2 = dZ1 + z1_sz * ks1;
+    double* dZ2 = dZ1 + z1_all;
     double* dZ3 = dZ2 + z2_sz * ks2;
     // H'G of step 3: few output tiles (cols x block) against a long contraction (cells) -- slices along the cell axis
     // until the launch fills the chip twice with 128-wide tiles (mode B at config 3: 64 tiles, cfg3 mode C: 320)
@@ -946,7 +952,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* d_liu = (double*)(sm + o_liu);
     double* d_part = (double*)(sm + o_part);
     unsigned* d_queue = (unsigned*)(sm + o_queue);   // work queue of the null fits (one counter per grid point)
-    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4 + (bg->kin ? bg->kin_groups + bg->kin_k2 : 0))));
+    const int kin_probs = bg->kin ? bg->kin_groups + bg->kin_k2 : 0;
+    CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4 + kin_probs + ng)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
     const long slab = (long)(1 + c) * ldq;  // rotations of [y, W] per grid point
@@ -1439,10 +1446,28 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(launch_reduce_splits(st, dZ3, z3_sz, s3, z3_sz));
         }
         // 9.-11. per gene: Z1 = Gt' [y o E, W o E], Q and F, eigenvalues + Davies, results
+        const int s1g = collapsed ? 1 : ks1b;
+        if (z1_batched) {
+            std::vector<GemmProblem> zp((size_t)ng);
+            for (int gi = 0; gi < ng; gi++) {
+                crm_gene* g = genes[gi];
+                GemmProblem p{};
+                p.X = Gt; p.ldx = ldb; p.Y = collapsed ? g->dt_Z1.as<double>() : g->YE.as<double>(); p.ldy = g->ld_ye;
+                p.C = dZ1 + (size_t)gi * z1_sz * ks1b; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
+                zp[(size_t)gi] = p;
+            }
+            GemmProblem* d_zp = d_probs + 2 * CRM_MAX_RHO + 4 + kin_probs;
+            CRM_HIP(hipMemcpyAsync(d_zp, zp.data(), sizeof(GemmProblem) * zp.size(), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_gemm_tn(ctx, d_zp, ng, nb, k0 * (1 + c), xrows, false, 0, s1g, z1_sz));
+            if (s1g > 1)
+                for (int gi = 0; gi < ng; gi++)
+                    CRM_TRY(launch_reduce_splits(st, dZ1 + (size_t)gi * z1_sz * ks1b, z1_sz, s1g, z1_sz));
+        }
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             const ScanOut& o = outs[gi];
-            {
+            double* const dZ1g = z1_batched ? dZ1 + (size_t)gi * z1_sz * ks1b : dZ1;
+            if (!z1_batched) {
                 GemmProblem p{};
                 p.X = Gt; p.ldx = ldb; p.Y = collapsed ? g->dt_Z1.as<double>() : g->YE.as<double>(); p.ldy = g->ld_ye;
                 p.C = dZ1; p.ldc = ldZ1; p.M = nb; p.N = k0 * (1 + c);
@@ -1461,7 +1486,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             aa.fit = d_fit + (size_t)gi * BLK; aa.sorted_pos = d_pos + (size_t)gi * BLK;
             aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
-            aa.Z1 = dZ1; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
+            aa.Z1 = dZ1g; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
             aa.WW = g->WW.as<double>(); aa.Wy = g->Wy.as<double>(); aa.yy = g->yy;
             aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = ld_gW;
             aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
