@@ -295,6 +295,42 @@ int launch_kin_operand(hipStream_t st, const double* U, int k2, const double* H,
     return CRM_OK;
 }
 
+// Is the half factor what the announced structure says, H[c, k1 + j m + d] = U[c, j] hKd[group(c), d]?  out[0] = largest
+// difference, out[1] = largest |H| over those columns (bit patterns: non-negative doubles order like integers).
+__global__ void kin_verify_kernel(const double* __restrict__ H, long ldh, int k1, const double* __restrict__ U, int k2,
+                                  const int* __restrict__ group, const double* __restrict__ hKd, long ldk, long m,
+                                  unsigned long long* __restrict__ out) {
+    const long c = blockIdx.x;
+    const long g = group[c];
+    double dmax = 0.0, hmax = 0.0;
+    for (long e = threadIdx.x; e < (long)k2 * m; e += blockDim.x) {
+        const long j = e / m, d = e - j * m;
+        const double h = H[c * ldh + k1 + e];
+        const double want = U[c * k2 + j] * hKd[g * ldk + d];
+        const double diff = fabs(h - want);
+        dmax = diff > dmax || diff != diff ? diff : dmax;      // (a NaN counts as a difference)
+        hmax = fmax(hmax, fabs(h));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(dmax, off);
+        dmax = o > dmax || o != o ? o : dmax;
+        hmax = fmax(hmax, __shfl_xor(hmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (dmax != dmax) dmax = INFINITY;
+        atomicMax(&out[0], (unsigned long long)__double_as_longlong(dmax));
+        atomicMax(&out[1], (unsigned long long)__double_as_longlong(hmax));
+    }
+}
+
+int launch_kin_verify(hipStream_t st, const double* H, long ldh, int k1, const double* U, int k2, const int* group,
+                      const double* hKd, long ldk, long m, long n, unsigned long long* out) {
+    if (n <= 0) return CRM_OK;
+    hipLaunchKernelGGL(kin_verify_kernel, dim3((unsigned)n), dim3(256), 0, st, H, ldh, k1, U, k2, group, hKd, ldk, m, out);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 // AH[a, c] = sum over the donors d' of S[(d' KT + k2 + a), c]: the E1 rows of H'(g o E0) from the per-donor sums
 __global__ void kin_sum_e1_kernel(const double* __restrict__ S, long ld_s, int KT, int k2, int groups, long cols,
                                   double* __restrict__ AH, long ld_ah) {

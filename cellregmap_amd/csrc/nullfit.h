@@ -91,6 +91,8 @@ int launch_gather_rows(hipStream_t st, const double* src, long ld_src, const int
 int launch_kin_operand(hipStream_t st, const double* U, int k2, const double* H, long ldh, int k1, const int* map, long rows,
                        double* Y, long ldy);
 // E1 rows of H'(g o E0): sums of the per-donor blocks S over the donors
+int launch_kin_verify(hipStream_t st, const double* H, long ldh, int k1, const double* U, int k2, const int* group,
+                      const double* hKd, long ldk, long m, long n, unsigned long long* out);
 int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2, int k1, int groups, long cols, double* AH,
                       long ld_ah);
 // dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]

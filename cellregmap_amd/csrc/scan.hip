@@ -147,6 +147,7 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     crm_ctx* ctx = bg->ctx;
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    bg->kin = false;   // (a second announcement that fails must not leave the first one's buffers in use)
     // cells in donor order, every donor's run padded to whole stages of the contraction
     std::vector<long> count(groups, 0);
     for (long i = 0; i < n; i++) count[group[i]]++;
@@ -182,7 +183,26 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     CRM_TRY(upload_padded(st, bg->kin_hKd.as<double>(), bg->kin_ldh, bg->kin_groups_pad, hKd, m, groups, m));
     CRM_TRY(launch_kin_operand(st, dU.as<double>(), k2, bg->H.as<double>(), bg->ldh, k1, bg->kin_map.as<int>(), rows,
                                bg->kin_Y.as<double>(), bg->kin_ldy));
+    // the route rests on H[c, k1 + j m + d] = U[c, j] hKd[group(c), d] entry by entry: check it here, once, instead of
+    // returning the results of another model when a caller announces a structure its half factor does not have
+    ScopedBuf dgroup, dcheck;
+    CRM_TRY(dgroup.ensure(sizeof(int) * n));
+    CRM_TRY(dcheck.ensure(2 * sizeof(unsigned long long)));
+    unsigned long long check[2] = {0, 0};
+    CRM_HIP(hipMemcpyAsync(dgroup.ptr, group, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    CRM_HIP(hipMemsetAsync(dcheck.ptr, 0, sizeof check, st));
+    CRM_TRY(launch_kin_verify(st, bg->H.as<double>(), bg->ldh, k1, dU.as<double>(), k2, dgroup.as<int>(),
+                              bg->kin_hKd.as<double>(), bg->kin_ldh, m, n, dcheck.as<unsigned long long>()));
+    CRM_HIP(hipMemcpyAsync(check, dcheck.ptr, sizeof check, hipMemcpyDeviceToHost, st));
     CRM_HIP(hipStreamSynchronize(st));
+    double dmax, hmax;
+    memcpy(&dmax, &check[0], sizeof dmax);
+    memcpy(&hmax, &check[1], sizeof hmax);
+    if (!(dmax <= 1e-12 * hmax)) {
+        set_error("kinship groups: the half factor of this background is not U[c, j] * hKd[group(c), d] (largest difference "
+                  "%.3g against entries up to %.3g)", dmax, hmax);
+        return CRM_ERR_ARG;
+    }
     bg->kin = true;
     return CRM_OK;
     });

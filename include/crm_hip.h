@@ -78,7 +78,9 @@ int crm_background_create_hadamard(crm_ctx* ctx, long n, const double* E1, int k
  * U is the n x k2 matrix given to the constructor.  With it the interaction scan of GENERAL genotypes takes
  * Q0(rho*)'(g o E0) as Mix(rho*)'[H'(g o E0)] and forms H'(g o E0) donor by donor: 2 n (k1 + k2) k0 + 2 cols r k0 flops per
  * variant instead of 2 n r k0 (3.6 times fewer at 20 000 cells x 50 contexts x 100 donors); results agree with the direct
- * route to rounding.  Optional: without it the scan contracts against Q0 itself. */
+ * route to rounding.  Optional: without it the scan contracts against Q0 itself.  The announcement is verified against the
+ * background's own half factor entry by entry (H[c, k1 + j m + d] = U[c, j] hKd[group[c], d]): CRM_ERR_ARG when it does not
+ * hold, and the background then keeps scanning by the direct route. */
 int crm_background_set_kinship_groups(crm_background* bg, const int* group, long groups, const double* hKd, long m,
                                       const double* U, int k2);
 /* Number of donors of the kinship structure in use by this background (0: none announced, or not usable). */

@@ -172,6 +172,38 @@ def test_the_context_is_still_sound(world):
     assert np.all(np.abs(host - pv) <= 1e-5 * pv + 1e-13)
 
 
+def test_a_kinship_structure_the_half_factor_does_not_have_is_refused(world):
+    """crm_background_set_kinship_groups checks the announcement against the background's own half factor entry by entry:
+    other donor-level rows, or cells assigned to the wrong donor, are an argument error and the background keeps the direct
+    route; the right announcement is accepted before and after."""
+    from cellregmap_amd import _engine
+
+    lib, _lib, n = world["lib"], world["_lib"], world["n"]
+    bg = ctypes.c_void_p()
+    assert lib.crm_background_create(world["ctx"], n, _lib.ptr(world["E"]), world["E"].shape[1], _lib.ptr(world["hK"]),
+                                     world["hK"].shape[1], 11, _lib.ptr(world["rho"]), 0.0, ctypes.byref(bg)) == OK
+    try:
+        group, hKd = _engine._kinship_groups(world["c"].hK)
+        group, hKd, ones = np.ascontiguousarray(group, np.int32), _lib.f64(hKd), _lib.f64(np.ones((n, 1)))
+        announce = lambda g, h: lib.crm_background_set_kinship_groups(bg, _lib.ptr(g), h.shape[0], _lib.ptr(h), h.shape[1],
+                                                                      _lib.ptr(ones), 1)
+        assert lib.crm_background_kinship_groups(bg) == 0
+        assert announce(group, hKd) == OK and lib.crm_background_kinship_groups(bg) == hKd.shape[0]
+        wrong = hKd.copy()
+        wrong[1, 0] += 1e-6
+        assert announce(group, wrong) == ERR_ARG and b"half factor" in lib.crm_last_error()
+        assert lib.crm_background_kinship_groups(bg) == 0          # ... and the first announcement is gone with it
+        swapped = group.copy()
+        swapped[0] = (swapped[0] + 1) % hKd.shape[0]
+        assert announce(swapped, hKd) == ERR_ARG
+        out_of_range = group.copy()
+        out_of_range[3] = hKd.shape[0]
+        assert announce(out_of_range, hKd) == ERR_ARG and b"outside" in lib.crm_last_error()
+        assert announce(group, hKd) == OK and lib.crm_background_kinship_groups(bg) == hKd.shape[0]
+    finally:
+        lib.crm_background_destroy(bg)
+
+
 def test_out_of_device_memory_is_a_status_code(world):
     """A background that cannot fit (one grid point of 4 000 000 cells x 10 112 padded columns = 324 GB on a 288 GB device):
     the allocation fails inside the library, which releases its idle caches, tries once more and then reports
