@@ -330,8 +330,11 @@ int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int
         set_error("transposed Khatri-Rao contraction: cells=%ld, k0=%d", cells, k0);
         return CRM_ERR_ARG;
     }
-    return launch_gemm_tn_glds(ctx, probs_dev, nz, (max_m + GEMM_BM - 1) / GEMM_BM, (max_n + 127) / 128, cells, true,
-                               k0, 1, 0, true);
+    // outputs of at most 64 columns (the [us | E1] rows of the kinship-structure route at config 2: 40, in mode B: 51) through
+    // the 64-wide tile: a 128-wide one would be less than half full
+    const int bn = max_n <= 64 && ctx->tune.bn != 128 ? 64 : 128;
+    return launch_gemm_tn_glds(ctx, probs_dev, nz, (max_m + GEMM_BM - 1) / GEMM_BM, (max_n + bn - 1) / bn, cells, true,
+                               k0, 1, 0, true, bn);
 }
 
 int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n,

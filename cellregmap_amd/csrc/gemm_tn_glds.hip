@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_sync_kernel(const GemmPro
 
 int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int mt, int nt, long cells,
                         bool khatri_rao, int k0, int ksplit, long split_stride, bool transposed_out, int bn) {
-    if (bn != 128 && !((bn == 64 || bn == 160) && khatri_rao && !transposed_out)) {
+    if (bn != 128 && !(bn == 64 && khatri_rao) && !(bn == 160 && khatri_rao && !transposed_out)) {
         set_error("contraction: %d-wide LDS-DMA tiles are not built for this form", bn);
         return CRM_ERR_UNSUPPORTED;
     }
@@ -501,13 +501,13 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
             hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, T>), grid, dim3(256), lds, st,          \
                                probs_dev, mt, cps, cells, split_stride, k0);                              \
     } while (0)
-#define CRM_GLDS_64(Q)                                                                                        \
+#define CRM_GLDS_64(Q, T)                                                                                     \
     do {                                                                                                      \
         if (small)                                                                                            \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, false, 64>), grid, dim3(256), lds, st,        \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, 1, Q, T, 64>), grid, dim3(256), lds, st,            \
                                probs_dev, mt, cps, cells, split_stride, k0);                              \
         else                                                                                                  \
-            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, false, 64>), grid, dim3(256), lds, st,  \
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<true, KRQ_BIG, Q, T, 64>), grid, dim3(256), lds, st,      \
                                probs_dev, mt, cps, cells, split_stride, k0);                              \
     } while (0)
 #define CRM_GLDS_160(Q)                                                                                       \
@@ -521,7 +521,8 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
     } while (0)
 #define CRM_GLDS(Q)                              \
     do {                                         \
-        if (bn == 64) CRM_GLDS_64(Q);            \
+        if (bn == 64 && transposed_out) CRM_GLDS_64(Q, true); \
+        else if (bn == 64) CRM_GLDS_64(Q, false); \
         else if (bn == 160) CRM_GLDS_160(Q);     \
         else if (transposed_out) CRM_GLDS_T(Q, true); \
         else CRM_GLDS_T(Q, false);               \

@@ -108,7 +108,8 @@ def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
     assert_allclose(C, KR.T @ Y, rtol=0, atol=1e-11 * np.sqrt(cells))
 
 
-@pytest.mark.parametrize("cells,B,k0,N", [(64, 3, 5, 17), (1000, 37, 50, 300), (320, 130, 4, 129), (4096, 8, 128, 64)])
+@pytest.mark.parametrize("cells,B,k0,N", [(64, 3, 5, 17), (1000, 37, 50, 300), (320, 130, 4, 129), (4096, 8, 128, 64),
+                                          (208, 9, 20, 40), (224, 700, 3, 51), (1600, 64, 50, 51), (96, 40, 33, 64)])
 def test_khatri_rao_contraction_with_transposed_store(ctx, cells, B, k0, N):
     """The shared-H route of the multi-gene scan stores (KR(G,E)' H)' directly (operands of the MFMA
     swapped, stores along M)."""
