@@ -161,3 +161,35 @@ def test_the_committed_traffic_profile_is_of_this_library():
     version = _lib.load().crm_version().decode()
     assert version == cellregmap_amd.__version__
     assert form == {"contraction_sync": True, "tail_launch": True, "library": version, "kinship_route": True, "tile_band": 8}
+
+
+def test_kinship_groups_of_expanded_factors():
+    """``_engine._kinship_groups`` (what the Python host announces through crm_background_set_kinship_groups): exact donor
+    structure or nothing.  Indicator factors (one 1 per row: every sampled column looks alike) and cells in shuffled order
+    are found; rows that agree only to rounding, and factors without repeated rows, are not."""
+    from cellregmap_amd import _engine
+
+    rng = np.random.default_rng(4)
+    donors, cells = 23, 400
+    donor = rng.integers(0, donors, size=cells)
+    donor[:donors] = rng.permutation(donors)                    # every donor present, in no particular order
+    for hKd in (rng.normal(size=(donors, donors)),              # dense donor-level factor
+                np.eye(donors),                                 # indicator factor (unrelated donors), 23 columns
+                np.eye(120)[:donors]):                          # ... with more than 64 columns: the sampled pass sees mostly zeros
+        hK = np.ascontiguousarray(hKd[donor])
+        group, rows = _engine._kinship_groups(hK)
+        assert group.dtype == np.int32 and group.shape == (cells,) and rows.shape == hKd.shape
+        assert np.array_equal(rows[group], hK)
+        assert len(np.unique(group)) == donors
+    # twins: two donors with the same row fall into one group -- the structure H = us o hKd[group] holds all the same
+    twins = rng.normal(size=(donors, 9))
+    twins[5] = twins[11]
+    group, rows = _engine._kinship_groups(np.ascontiguousarray(twins[donor]))
+    assert rows.shape[0] == donors - 1 and np.array_equal(rows[group], twins[donor])
+    # a row that differs from its donor's in the last bit is a row of its own
+    hK = np.ascontiguousarray(rng.normal(size=(donors, 12))[donor])
+    hK[37, 7] = np.nextafter(hK[37, 7], np.inf)
+    group, rows = _engine._kinship_groups(hK)
+    assert rows.shape[0] == donors + 1 and np.array_equal(rows[group], hK)
+    # no repeated rows at all
+    assert _engine._kinship_groups(rng.normal(size=(300, 10))) is None
