@@ -109,6 +109,9 @@ def main():
         import torch  # (counting devices does not initialise the GPU on this image)
 
         have = torch.cuda.device_count()
+        if have == 0:
+            raise SystemExit("bench.py: this node shows no GPU (torch.cuda.device_count() == 0); the bench measures the HIP "
+                             "path and has no CPU fallback")
         if have < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (torch.cuda.device_count()); "
                              f"run with --gpus {max(have, 1)}, or CRM_BENCH_SHARE_GPU=1 for a dry run of the N > 1 code "
