@@ -658,16 +658,17 @@ class CellRegMap:
 
     # -- device objects --------------------------------------------------------------------
     def _fixed_effect_basis(self):
-        """W, or an orthogonal basis of its column space when W is rank deficient (the
-        reference's LMM and PMat only depend on span(W): economic_svd / lstsq)."""
+        """The basis of span(W) the reference's LMM works in: ``U * s`` of numpy_sugar.economic_svd(W) (singular values
+        below sqrt(eps) dropped; glimix-core ``LMM.__init__``: ``tX = ddot(U, S)``).  The scans depend on W through
+        its column space only (LMM profiles the fixed effects out, PMat solves by lstsq), the columns come out
+        mutually orthogonal, and the library then orthogonalises every variant against them in the cell axis
+        (csrc/blockops.hip: launch_ortho_block) -- together the reference's economic_svd([W, g]) basis."""
         W = self._W
         if W.shape[1] == 0:
             raise ValueError("W has no columns")
         if W.shape[1] == 1 and np.abs(W).max(initial=0.0) >= _SQRT_EPS:
             return W  # one non-zero column (norm >= its largest entry): full rank without asking the SVD
         U, s, _ = _economic_svd(W)
-        if s.shape[0] == W.shape[1]:
-            return W
         return U * s
 
     def _bind_gene(self):
@@ -817,8 +818,7 @@ class CellRegMap:
         glimix-core's LMM (beta is the minimum-norm solution)."""
         lib = _lib.load()
         U, s, Vt = _economic_svd(M)
-        full = s.shape[0] == M.shape[1]
-        X = _lib.f64(M if full else U * s)
+        X = _lib.f64(U * s)   # (mutually orthogonal columns: the basis glimix-core's LMM works in)
         y = _lib.f64(self._y)
         E0 = _lib.f64(self._E0)
         h = ctypes.c_void_p()
@@ -830,8 +830,7 @@ class CellRegMap:
             _lib.check(lib.crm_lmm_fit(h, 1, _lib.ptr(fit), _lib.ptr(beta)))
         finally:
             lib.crm_gene_destroy(h)
-        if not full:
-            beta = Vt.T @ beta
+        beta = Vt.T @ beta
         return fit[0], fit[1], fit[2], beta, int(fit[5])
 
     def _snp_background(self, gE):

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
     // per variant: everything below is k0- or (c+1)-sized; LDS carved from the dynamic segment:
     // L [P][P] (Cholesky factor of X'K^-1X), xky [P], dkx [k0][P] (D'K^-1X), sol [k0][P], uvec [k0]
     extern __shared__ double fsm[];
-    __shared__ int ok_flag;
+    __shared__ int ok_flag, keep_flag;
     const int Pd = a.c + 1;
     double* Lm = fsm;
     double* xky = Lm + Pd * Pd;
@@ -404,15 +404,17 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
                 L(i, j) = (plain_xx(i, j) - Ge[(long)(k0 + i) * KT + (k0 + j)]) * inv;
             xky[i] = (plain_xy(i) - Ge[(long)(k0 + i) * KT + (k0 + c + 1)]) * inv;
         }
-        if (!fit.use_g) {  // g in span(W): the projection is the one of W alone
-            for (int j = 0; j < c; j++) L(c, j) = 0.0;
-            L(c, c) = 1.0;
-            xky[c] = 0.0;
-        }
+        // (whether the variant is a column of the projection is PMat's own decision, below -- not the null fit's use_g:
+        // the reference's LMM and its PMat apply different rank rules to [W, g])
+        bool keep = true;
         for (int j = 0; j < P && ok; j++) {
             double d = L(j, j);
             for (int k = 0; k < j; k++) d -= L(j, k) * L(j, k);
-            if (!(d > 0.0)) { ok = false; break; }
+            if (!(d > 0.0)) {
+                if (j == c) keep = false;   // no component outside span(W) at all
+                else ok = false;
+                break;
+            }
             const double l = sqrt(d);
             L(j, j) = l;
             for (int i = j + 1; i < P; i++) {
@@ -421,6 +423,70 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
                 L(i, j) = s / l;
             }
         }
+        if (ok && keep) {
+            // PMat solves with numpy's lstsq(rcond=None) on X'K^-1X in the basis of X = [W, g] AS GIVEN (_math.py:33-37,
+            // :91-93): a singular value below eps * (c + 1) * the largest is cut off -- a rule of its own, apart from the
+            // LMM's economic_svd (absolute sqrt(eps) on the singular values of X, use_g above): with columns of norm
+            // ~ sqrt(n) a variant can be kept by the null fit and still be cut here.  The matrix at hand is the one of
+            // [W', x] with x = g - W' a (a: the block's projection coefficients; none on the collapsed path), i.e.
+            // A_given = T' (L L') T, T = [[I, a], [0, 1]] up to an orthogonal change of W's basis, which leaves the
+            // singular values alone.  Smallest one: the Rayleigh quotient of the near-null vector (-(a + b), 1), b the
+            // K-metric regression of x on W' -- s / (1 + |a + b|^2) with s the Schur complement (last pivot squared);
+            // largest one: a few power iterations through the factor.  Cutting that direction leaves the projection of W
+            // alone (to the order of the singular-value ratio).
+            double* vv = dkxm;           // scratch [P] + [P]: dkxm and solm are adjacent, 2 k0 P >= 2 P doubles, and are
+            double* ww = dkxm + P;       // only filled after the barrier below
+            double nrm2 = 1.0;
+            {
+                // b = L_WW^-T L(c, 0..c-1)'
+                for (int i = c - 1; i >= 0; i--) {
+                    double sacc = L(c, i);
+                    for (int k = i + 1; k < c; k++) sacc -= L(k, i) * vv[k];
+                    vv[i] = sacc / L(i, i);
+                }
+                for (int j = 0; j < c; j++) {
+                    const double t = vv[j] + (a.coef ? a.coef[(long)j * a.ld_coef + b] : 0.0);
+                    nrm2 += t * t;
+                }
+            }
+            const double lam_min = L(c, c) * L(c, c) / nrm2;
+            // power iteration on T' L L' T
+            for (int i = 0; i < P; i++) vv[i] = 1.0;
+            double lam_max = 0.0;
+            for (int it = 0; it < 12; it++) {
+                // u = T v
+                const double vl = vv[c];
+                for (int j = 0; j < c; j++) ww[j] = vv[j] + (a.coef ? a.coef[(long)j * a.ld_coef + b] : 0.0) * vl;
+                ww[c] = vl;
+                // w = L' u (in vv), then u = L w (in ww)
+                for (int i = 0; i < P; i++) {
+                    double sacc = 0.0;
+                    for (int k = i; k < P; k++) sacc += L(k, i) * ww[k];
+                    vv[i] = sacc;
+                }
+                for (int i = P - 1; i >= 0; i--) {
+                    double sacc = 0.0;
+                    for (int k = 0; k <= i; k++) sacc += L(i, k) * vv[k];
+                    ww[i] = sacc;
+                }
+                // v = T' u
+                double last = ww[c];
+                for (int j = 0; j < c; j++) last += (a.coef ? a.coef[(long)j * a.ld_coef + b] : 0.0) * ww[j];
+                double n2 = last * last;
+                for (int j = 0; j < c; j++) n2 += ww[j] * ww[j];
+                lam_max = sqrt(n2);
+                if (!(lam_max > 0.0)) break;
+                for (int j = 0; j < c; j++) vv[j] = ww[j] / lam_max;
+                vv[c] = last / lam_max;
+            }
+            if (lam_min <= 2.220446049250313e-16 * (double)P * lam_max) keep = false;
+        }
+        if (!keep) {  // the projection is the one of W alone
+            for (int j = 0; j < c; j++) L(c, j) = 0.0;
+            L(c, c) = 1.0;
+            xky[c] = 0.0;
+        }
+        keep_flag = keep ? 1 : 0;
         if (ok) {
             for (int i = 0; i < P; i++) {
                 double s = xky[i];
@@ -437,6 +503,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
     }
     __syncthreads();
     const bool ok = ok_flag != 0;
+    const bool keep_g = keep_flag != 0;
     // D'K^-1 X rows and their solves, one context per thread
     for (int j = tid; j < k0; j += blockDim.x) {
         double row[PMAX];
@@ -445,7 +512,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
             if (i < c) plain = a.Z1[(long)b * a.ldZ1 + (long)(1 + i) * k0 + j];
             else plain = a.Z2[(long)b * a.ldZ2 + j];
             double v = (plain - Ge[(long)j * KT + (k0 + i)]) * inv;
-            if (i == c && !fit.use_g) v = 0.0;
+            if (i == c && !keep_g) v = 0.0;
             row[i] = v;
             dkx(j, i) = v;
         }

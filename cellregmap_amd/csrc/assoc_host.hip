@@ -38,6 +38,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
 
     CRM_TRY(ctx->ws_T.ensure(sizeof(double) * (size_t)BLK * ldT));
     CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
+    if (!fast) CRM_TRY(ctx->ws_Gx.ensure(sizeof(double) * (size_t)np * ldb));
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_gg = carve(sizeof(double) * BLK), o_gy = carve(sizeof(double) * BLK),
@@ -46,7 +47,9 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
                  o_fit = carve(sizeof(NullFitOut) * BLK), o_lml = carve(sizeof(double) * BLK),
                  o_pv = carve(sizeof(double) * BLK), o_prep = carve(sizeof(double) * fastscan_prep_doubles()),
                  o_wts = carve(sizeof(double) * ldq), o_zero = carve(sizeof(double) * ldq),
-                 o_part = carve(variant_stats_workspace(BLK, std::min(c, CRM_MAX_COV)));
+                 o_part = carve(variant_stats_workspace(BLK, std::min(c, CRM_MAX_COV))),
+                 o_coef = carve(sizeof(double) * (size_t)c * ldb), o_thr = carve(sizeof(double) * BLK),
+                 o_drop = carve(sizeof(int) * BLK);
     CRM_TRY(ctx->ws_small.ensure(off));
     char* sm = ctx->ws_small.as<char>();
     double* d_gg = (double*)(sm + o_gg);
@@ -60,6 +63,9 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     double* d_wts = (double*)(sm + o_wts);
     double* d_zero = (double*)(sm + o_zero);
     double* d_part = (double*)(sm + o_part);
+    double* d_coef = (double*)(sm + o_coef);
+    double* d_thr = (double*)(sm + o_thr);
+    int* d_drop = (int*)(sm + o_drop);
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4)));
     const double* d_y = gene->yW.as<double>();
     const double* d_W = gene->yW.as<double>() + 1;
@@ -113,6 +119,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     alt.rho[0] = fa.rho[ri];
     alt.rho[0].T = ctx->ws_T.as<double>();
     alt.rho[0].ldT = ldT;
+    alt.g_drop = d_drop;   // (full refit: LMM(y, [W, g]) reduces [W, g] by economic_svd, see launch_ortho_block)
     AssocArgs aa{};
     aa.T = ctx->ws_T.as<double>(); aa.ldT = ldT;
     aa.ty = fa.rho[ri].ty; aa.tW = fa.rho[ri].tW; aa.ldW = ldq; aa.S0 = fa.rho[ri].S0;
@@ -130,6 +137,16 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
             CRM_TRY(launch_gather_block(st, panel->G.as<double>() + first + done, panel->ld, np, n, nullptr, nullptr,
                                         nb, Gb, ldb, (int)ldb));
         CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, ld_gW));
+        if (!fast) {
+            // the per-SNP refit works in the basis of economic_svd([W, g]) (glimix-core LMM): the block orthogonalised
+            // against W in the cell axis, as in the interaction scan; the FastScanner's lstsq keeps the raw columns
+            double* Gx = ctx->ws_Gx.as<double>();
+            CRM_TRY(launch_ortho_block(st, Gb, ldb, np, nb, (int)ldb, d_W, gene->ld_yw, c, gene->Wproj.as<double>(), d_gW, ld_gW,
+                                       d_coef, ldb, d_thr, Gx, ldb));
+            CRM_TRY(launch_variant_stats(st, Gx, ldb, np, nb, d_y, d_W, gene->ld_yw, c, d_part, d_gg, d_gy, d_gW, ld_gW));
+            CRM_TRY(launch_ortho_rank(st, d_gg, d_thr, nb, d_drop));
+            Gb = Gx;
+        }
         GemmProblem p{};
         CRM_TRY(crm_background_require_q0(bg, ri));
         p.X = Gb; p.ldx = ldb; p.Y = bg->Q0[ri].as<double>(); p.ldy = ldq;

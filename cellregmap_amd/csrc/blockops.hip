@@ -351,6 +351,114 @@ int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2
     return CRM_OK;
 }
 
+// ---- the variant in the fixed effects' own basis (cellregmap/_cellregmap.py:345-352) ----------------------------------
+// The reference's LMM never works with X = [W, g] as given: glimix-core reduces it by numpy_sugar.economic_svd (an
+// orthonormal basis of its column space, singular values below sqrt(eps) dropped) before anything is rotated or solved.
+// The same here: W arrives with mutually orthogonal columns (crm_gene_create), and each block's variants are made
+// orthogonal to them IN THE CELL AXIS before the rotations and the n-length sums --
+//     gx = g - W a,   a_j = W_j'g / W_j'W_j
+// so that a variant nearly collinear with the covariates costs eps sqrt(cond) like the reference's basis, not the
+// eps cond of a Cholesky factorisation of [W, g]'K^-1[W, g] in the raw basis.  span([W, gx]) = span([W, g]): the
+// projection matrix of the score test and every likelihood are unchanged; only the fixed effects' role of g is
+// affected (the test direction g o E0 keeps the variant as given).
+//
+// coef[j * ld_coef + b] = a_j of variant b (zero in the padding columns); thr[b] = the reference's rank rule turned into
+// a bound on |gx|^2: the smallest singular value of [W, g] lies below sqrt(eps) (economic_svd then drops that
+// direction) exactly when  |gx|^2 < eps (1 + sum_j h_j^2 / (d_j^2 (d_j^2 - eps))),  h = V'(W'g), (V, d^2) the
+// eigen-decomposition of W'W -- the secular equation of the arrowhead matrix [W, g]'[W, g] in W's own orthogonal
+// basis, evaluated at eps.  proj (crm_gene::Wproj): (W'W)^-1 [c x c], V [c x c] (column j = eigenvector j), d^2 [c];
+// for the mutually orthogonal columns the Python host passes all three are diagonal.
+__global__ void ortho_coef_kernel(const double* __restrict__ gW, long ld_gW, const double* __restrict__ proj, int c,
+                                  int variants, int cols, double* __restrict__ coef, long ld_coef,
+                                  double* __restrict__ thr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= cols) return;
+    constexpr double EPS = 2.220446049250313e-16;
+    const double* __restrict__ inv = proj;
+    const double* __restrict__ V = proj + (long)c * c;
+    const double* __restrict__ d2 = V + (long)c * c;
+    const double* __restrict__ h = gW + (long)b * ld_gW;
+    double t = 1.0;
+    for (int j = 0; j < c; j++) {
+        double a = 0.0;
+        if (b < variants) {
+            double hv = 0.0;
+            for (int k = 0; k < c; k++) {
+                a = fma(inv[j * c + k], h[k], a);
+                hv = fma(V[k * c + j], h[k], hv);
+            }
+            t += (hv / d2[j]) * (hv / (d2[j] - EPS));
+        }
+        coef[(long)j * ld_coef + b] = a;
+    }
+    if (b < variants) thr[b] = EPS * t;
+}
+
+__global__ __launch_bounds__(256) void ortho_apply_kernel(const double* __restrict__ G, long ldg,
+                                                         const double* __restrict__ W, long ldw, int c,
+                                                         const double* __restrict__ coef, long ld_coef, int cols,
+                                                         double* __restrict__ Gx, long ldx) {
+    const int b = blockIdx.y * blockDim.x + threadIdx.x;
+    const long i = blockIdx.x;
+    if (b >= cols) return;
+    double v = G[i * ldg + b];
+    for (int j = 0; j < c; j++) v = fma(-W[i * ldw + j], coef[(long)j * ld_coef + b], v);
+    Gx[i * ldx + b] = v;
+}
+
+// drop[b] = 1 when the variant's own direction falls under the reference's rank rule (gg: |gx|^2 of the block)
+__global__ void ortho_rank_kernel(const double* __restrict__ gg, const double* __restrict__ thr, int variants,
+                                  int* __restrict__ drop) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < variants) drop[b] = gg[b] < thr[b] ? 1 : 0;
+}
+
+// Collapsed path (donor-level sums only): near[b] = 1 when the variant keeps less than `tau` of its squared norm
+// outside span(W) -- the scan then repeats such variants on the dense path, where they are orthogonalised in the cell axis.
+__global__ void collinear_flag_kernel(const double* __restrict__ gg, const double* __restrict__ gW, long ld_gW,
+                                      const double* __restrict__ proj, int c, int variants, double tau,
+                                      int* __restrict__ near) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= variants) return;
+    const double* __restrict__ h = gW + (long)b * ld_gW;
+    double rest = gg[b];
+    for (int j = 0; j < c; j++) {
+        double a = 0.0;
+        for (int k = 0; k < c; k++) a = fma(proj[j * c + k], h[k], a);
+        rest -= h[j] * a;
+    }
+    near[b] = rest > tau * gg[b] ? 0 : 1;
+}
+
+int launch_ortho_block(hipStream_t st, const double* G, long ldg, long cells_pad, int variants, int cols,
+                       const double* W, long ldw, int c, const double* proj, const double* gW, long ld_gW,
+                       double* coef, long ld_coef, double* thr, double* Gx, long ldx) {
+    if (cols <= 0) return CRM_OK;
+    hipLaunchKernelGGL(ortho_coef_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, gW, ld_gW, proj, c, variants, cols,
+                       coef, ld_coef, thr);
+    CRM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ortho_apply_kernel, dim3((unsigned)cells_pad, (cols + 255) / 256), dim3(256), 0, st, G, ldg, W,
+                       ldw, c, coef, ld_coef, cols, Gx, ldx);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_ortho_rank(hipStream_t st, const double* gg, const double* thr, int variants, int* drop) {
+    if (variants <= 0) return CRM_OK;
+    hipLaunchKernelGGL(ortho_rank_kernel, dim3((variants + 255) / 256), dim3(256), 0, st, gg, thr, variants, drop);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+int launch_collinear_flag(hipStream_t st, const double* gg, const double* gW, long ld_gW, const double* proj, int c,
+                          int variants, double tau, int* near) {
+    if (variants <= 0) return CRM_OK;
+    hipLaunchKernelGGL(collinear_flag_kernel, dim3((variants + 255) / 256), dim3(256), 0, st, gg, gW, ld_gW, proj, c,
+                       variants, tau, near);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols) {

@@ -81,6 +81,7 @@ struct crm_ctx {
     // of 11 x 10 050^2) back to the driver costs 1.3 s per call and mapping them again up to as much; per-SNP
     // backgrounds of the effect-size path call the constructor once per variant.  Released by crm_ctx_trim,
     // crm_ctx_destroy, or when another allocation would otherwise fail.
+    long dense_repeats = 0;   // variants a collapsed scan repeated on the dense path (nearly collinear with W)
     long tail_launches = 0;   // blocks whose last columns took the 160-column-tile launch (crm_test_tail_launches)
     crm::EighWork* eigh_ws = nullptr;
     bool eigh_ws_busy = false;
@@ -90,10 +91,10 @@ struct crm_ctx {
     size_t timed_used = 0;
     double kr_flops = 0.0;
     // scan workspace (grown on demand, reused across calls)
-    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
+    crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gx, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
     crm::DevBuf ws_Gk, ws_S, ws_S2;   // kinship-structure route: the block in donor order, the per-donor sums (step 6 / step 3)
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&sync_counters, &ws_S, &ws_S2, &ws_Gk, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&sync_counters, &ws_S, &ws_S2, &ws_Gk, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gx, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };
 

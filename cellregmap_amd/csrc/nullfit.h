@@ -41,6 +41,8 @@ struct NullFitArgs {
     const double* gy;  // [variants]
     const double* gW;  // [variants x ld_gW]
     long ld_gW;
+    const int* g_drop; // [variants] 1: the variant's direction falls under the reference's rank rule (launch_ortho_rank);
+                       // null: decided here from the last pivot of the Cholesky factor of X'X (relative 1e-12)
     NullFitTrial* trial;  // [variants x nrho]
     NullFitOut* out;      // [variants]
 };
@@ -77,6 +79,16 @@ int launch_variant_stats(hipStream_t st, const double* G, long ldg, long cells, 
                          const double* y, const double* W, long ldw, int c, double* partial,
                          double* gg, double* gy, double* gW, long ld_gW);
 size_t variant_stats_workspace(int variants, int c);
+// The block in the fixed effects' own basis (blockops.hip): Gx = G - W coef with coef = (W'W)^-1 W'g (gW = W'g of the
+// block as launch_variant_stats leaves it; proj = crm_gene::Wproj), thr = the bound on |gx|^2 below which
+// numpy_sugar.economic_svd drops the variant's direction from [W, g].  coef: [c x ld_coef], ld_coef >= cols.
+int launch_ortho_block(hipStream_t st, const double* G, long ldg, long cells_pad, int variants, int cols,
+                       const double* W, long ldw, int c, const double* proj, const double* gW, long ld_gW,
+                       double* coef, long ld_coef, double* thr, double* Gx, long ldx);
+int launch_ortho_rank(hipStream_t st, const double* gg, const double* thr, int variants, int* drop);
+// near[b] = 1 when gg - gW'(W'W)^-1 gW <= tau gg (donor-level sums: the collapsed path's guard)
+int launch_collinear_flag(hipStream_t st, const double* gg, const double* gW, long ld_gW, const double* proj, int c,
+                          int variants, double tau, int* near);
 // out[i, b] = src[row(i), col(b)]: optional row permutation (idx_G) and column order (sorted by rho*).
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
@@ -138,6 +150,8 @@ struct AssembleArgs {
     const double* Z3; long ldZ3;   // [variants x k0(k0+1)/2] E' diag(gt^2) E (upper, row-major pairs)
     const double* WW; const double* Wy; double yy;
     const double* gg; const double* gy; const double* gW; long ld_gW;
+    const double* coef; long ld_coef;   // [c x ld_coef] projection coefficients of the block's variants onto W
+                                        // (launch_ortho_block; null where the block was not orthogonalised)
     double* Q;   // [variants]
     double* F;   // [variants x k0 x k0]
 };

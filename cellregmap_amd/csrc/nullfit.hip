@@ -164,8 +164,14 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
 #pragma unroll
             for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
             if (j == P - 1) {
-                if (!(d > 1e-12 * A[j][j])) {
+                // the reference's rule on the singular values of [W, g] where the block was orthogonalised against W
+                // (g_drop, blockops.hip); else the relative size of the last pivot
+                if (a.g_drop ? a.g_drop[b] != 0 : !(d > 1e-12 * A[j][j])) {
                     use_g = false;
+                    break;
+                }
+                if (!(d > 0.0)) {
+                    ok = false;
                     break;
                 }
             } else if (!(d > 0.0)) {

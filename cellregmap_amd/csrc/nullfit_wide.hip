@@ -209,8 +209,11 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
         }
         __syncthreads();
         bool dropped = false;
-        const bool ok = block_cholesky(sh.H, P, sh.scal, logdetXX, 1e-12, dropped);
-        if (dropped) use_g = false;
+        // (g_drop: the reference's rule on the singular values of [W, g], decided where the block was orthogonalised
+        // against W -- blockops.hip; the factorisation then stops before the variant's row)
+        const bool flagged = a.g_drop && a.g_drop[b] != 0;
+        const bool ok = block_cholesky(sh.H, flagged ? c : P, sh.scal, logdetXX, a.g_drop ? 0.0 : 1e-12, dropped);
+        if (dropped || flagged) use_g = false;
         if (!ok) logdetXX = NAN;
         __syncthreads();
     }

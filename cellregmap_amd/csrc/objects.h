@@ -81,6 +81,7 @@ struct crm_gene {
     crm::DevBuf yW;   // [n_pad x ld_yw]: column 0 = y, columns 1..c = W
     crm::DevBuf E0;   // [n_pad x lde]
     crm::DevBuf WW, Wy;
+    crm::DevBuf Wproj;   // (W'W)^-1 [c x c], eigenvectors V of W'W [c x c], eigenvalues d^2 [c]: launch_ortho_block
     double yy = 0.0;
     crm::DevBuf rot;  // [nrho][(1+c) x ldq]: rows Q0(rho)'y, Q0(rho)'W_i
     // features of the (possibly row-permuted) contexts, rebuilt per scan call

@@ -299,6 +299,88 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     }
     for (int a = 0; a < c; a++)
         for (int b = 0; b < a; b++) WW[a * c + b] = WW[b * c + a];
+    // What the orthogonalisation of the variants against W needs (blockops.hip: launch_ortho_block): (W'W)^-1 and the
+    // eigen-decomposition W'W = V diag(d^2) V'.  Mutually orthogonal columns -- what the Python host passes: U diag(s) of
+    // the thin SVD, the basis glimix-core's LMM works in -- need no arithmetic; anything else goes through a cyclic
+    // Jacobi iteration on the c x c Gram matrix, which resolves W's small singular values only down to ~1e-7 of the
+    // largest: beyond that, or below the reference's own rank rule (numpy_sugar.economic_svd: sqrt(eps)), the call is
+    // refused and the caller asked for a basis of span(W) -- the scans depend on W through its column space only.
+    {
+        constexpr double EPS = 2.220446049250313e-16;
+        std::vector<double> proj((size_t)2 * c * c + c, 0.0);
+        double* inv = proj.data();
+        double* V = inv + (size_t)c * c;
+        double* d2 = V + (size_t)c * c;
+        bool diagonal = true;
+        for (int a = 0; a < c && diagonal; a++)
+            for (int b = a + 1; b < c; b++)
+                if (std::fabs(WW[a * c + b]) > 1e-13 * std::sqrt(WW[a * c + a] * WW[b * c + b])) { diagonal = false; break; }
+        if (diagonal) {
+            for (int a = 0; a < c; a++) {
+                if (!(WW[a * c + a] >= EPS)) {
+                    set_error("gene: covariate column %d has norm %.3g, below the reference's rank rule (sqrt(eps)): pass a "
+                              "basis of span(W)", a, std::sqrt(std::max(WW[a * c + a], 0.0)));
+                    return fail(CRM_ERR_NUMERIC);
+                }
+                V[a * c + a] = 1.0;
+                d2[a] = WW[a * c + a];
+                inv[a * c + a] = 1.0 / WW[a * c + a];
+            }
+        } else {
+            std::vector<double> A(WW);
+            for (int a = 0; a < c; a++) V[a * c + a] = 1.0;
+            for (int sweep = 0; sweep < 60; sweep++) {
+                double offd = 0.0, diag = 0.0;
+                for (int a = 0; a < c; a++)
+                    for (int b = 0; b < c; b++) (a == b ? diag : offd) += A[a * c + b] * A[a * c + b];
+                if (offd <= 1e-32 * diag) break;
+                for (int pi = 0; pi < c - 1; pi++)
+                    for (int qi = pi + 1; qi < c; qi++) {
+                        const double apq = A[pi * c + qi];
+                        if (apq == 0.0) continue;
+                        const double theta = (A[qi * c + qi] - A[pi * c + pi]) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                        for (int k = 0; k < c; k++) {
+                            const double akp = A[k * c + pi], akq = A[k * c + qi];
+                            A[k * c + pi] = cs * akp - sn * akq;
+                            A[k * c + qi] = sn * akp + cs * akq;
+                        }
+                        for (int k = 0; k < c; k++) {
+                            const double apk = A[pi * c + k], aqk = A[qi * c + k];
+                            A[pi * c + k] = cs * apk - sn * aqk;
+                            A[qi * c + k] = sn * apk + cs * aqk;
+                        }
+                        for (int k = 0; k < c; k++) {
+                            const double vkp = V[k * c + pi], vkq = V[k * c + qi];
+                            V[k * c + pi] = cs * vkp - sn * vkq;
+                            V[k * c + qi] = sn * vkp + cs * vkq;
+                        }
+                    }
+            }
+            double lmax = 0.0, lmin = INFINITY;
+            for (int a = 0; a < c; a++) {
+                d2[a] = A[a * c + a];
+                lmax = std::max(lmax, d2[a]);
+                lmin = std::min(lmin, d2[a]);
+            }
+            if (!(lmin >= EPS) || !(lmin > 1e-13 * lmax)) {
+                set_error("gene: the covariates are rank deficient or too ill-conditioned for columns that are not mutually "
+                          "orthogonal (eigenvalues of W'W from %.3g to %.3g): pass an orthogonal basis of span(W), e.g. "
+                          "U diag(s) of its thin SVD", lmin, lmax);
+                return fail(CRM_ERR_NUMERIC);
+            }
+            for (int a = 0; a < c; a++)
+                for (int b = 0; b < c; b++) {
+                    double acc = 0.0;
+                    for (int k = 0; k < c; k++) acc += V[a * c + k] * V[b * c + k] / d2[k];
+                    inv[a * c + b] = acc;
+                }
+        }
+        if ((rc = g->Wproj.ensure(sizeof(double) * proj.size())) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemcpyAsync(g->Wproj.ptr, proj.data(), sizeof(double) * proj.size(), hipMemcpyHostToDevice, ctx->stream));
+        CRM_HIP(hipStreamSynchronize(ctx->stream));   // (proj lives on this stack frame)
+    }
     if ((rc = g->WW.ensure(sizeof(double) * c * c)) != CRM_OK) return fail(rc);
     if ((rc = g->Wy.ensure(sizeof(double) * c)) != CRM_OK) return fail(rc);
     CRM_HIP(hipMemcpyAsync(g->WW.ptr, WW.data(), sizeof(double) * c * c, hipMemcpyHostToDevice, ctx->stream));
@@ -366,7 +448,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
-    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
+    for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->Wproj, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
                     &g->dt_Zt, &g->kinEp})
         b->release();
     delete g;
@@ -778,6 +860,10 @@ extern "C" {
 
 namespace crm {
 
+// Collapsed path: a variant that keeps less than this share of its squared norm outside span(W) is repeated on the dense
+// path (the donor-level sums can only form [W, g]'K^-1[W, g] in the raw basis: eps / share instead of eps / sqrt(share))
+constexpr double COLLINEAR_TAU = 1e-2;
+
 struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: count*k0, F: count*k0*k0)
     double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
     int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
@@ -790,8 +876,13 @@ struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: co
 // on the phenotype is done once per block: the block copies, T(rho) = G'Q0(rho), the Khatri-Rao
 // contraction per (variant, rho) pair that at least one gene selected, and the y-free side
 // contractions.  Per gene: g'y, the null fits, E'(g o y), assembly, eigenvalues and Davies.
-static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
-                     const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs) {
+//
+// allow_collapse = false keeps a grouped panel on the dense path; near_out (collapsed passes only) receives the positions
+// (relative to `first`) of the variants that are nearly collinear with the covariates -- scan_core repeats those on the
+// dense path, where the block is orthogonalised against W in the cell axis (blockops.hip: launch_ortho_block).
+static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
+                     const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs, bool allow_collapse,
+                     std::vector<long>* near_out) {
     const int ng = (int)genes.size();
     crm_gene* g0 = genes[0];
     crm_background* bg = g0->bg;
@@ -915,10 +1006,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
     CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldp));
     CRM_TRY(ctx->ws_G2.ensure(sizeof(double) * (size_t)np * ldb));
-    if (idx_G) {  // (unused when the scan ends up on the collapsed path)
+    if (idx_G)   // (unused when the scan ends up on the collapsed path)
         CRM_TRY(ctx->ws_Gt.ensure(sizeof(double) * (size_t)np * ldb));
-        CRM_TRY(ctx->ws_GG.ensure(sizeof(double) * (size_t)np * ldb));
-    }
     const int mt_blk = (BLK + GEMM_BM - 1) / GEMM_BM;
     const int ks1 = pick_split(np, (long)mt_blk * (ldZ1 / GEMM_BN));
     const int ks2 = pick_split(np, (long)mt_blk * (ldZ2 / GEMM_BN));
@@ -955,7 +1044,9 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                  o_ord = carve(sizeof(int) * max_pairs), o_Q = carve(sizeof(double) * BLK),
                  o_pv = carve(sizeof(double) * BLK), o_lam = carve(sizeof(double) * BLK * k0),
                  o_if = carve(sizeof(int) * BLK), o_liu = carve(sizeof(double) * BLK),
-                 o_part = carve(stats_ws), o_queue = carve(sizeof(unsigned) * CRM_MAX_RHO);
+                 o_part = carve(stats_ws), o_queue = carve(sizeof(unsigned) * CRM_MAX_RHO),
+                 o_coef = carve(sizeof(double) * (size_t)c * ldb), o_thr = carve(sizeof(double) * BLK),
+                 o_drop = carve(sizeof(int) * BLK), o_near = carve(sizeof(int) * BLK);
     CRM_TRY(ctx->ws_small.ensure(off));
     char* sm = ctx->ws_small.as<char>();
     double* d_gg = (double*)(sm + o_gg);
@@ -972,6 +1063,10 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* d_liu = (double*)(sm + o_liu);
     double* d_part = (double*)(sm + o_part);
     unsigned* d_queue = (unsigned*)(sm + o_queue);   // work queue of the null fits (one counter per grid point)
+    double* d_coef = (double*)(sm + o_coef);         // [c][ldb] projection coefficients of the block onto W
+    double* d_thr = (double*)(sm + o_thr);           // the reference's rank rule as a bound on |gx|^2
+    int* d_drop = (int*)(sm + o_drop);               // 1: the variant's direction is dropped from [W, g]
+    int* d_near = (int*)(sm + o_near);               // collapsed path: 1 = repeat this variant on the dense path
     const int kin_probs = bg->kin ? bg->kin_groups + bg->kin_k2 : 0;
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4 + kin_probs + ng)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
@@ -983,7 +1078,12 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     const size_t bd_bytes = grouped ? sizeof(double) * (size_t)nrho * panel->m_pad * k0 * ldq : 0;
     // (with the genotype permutation hook the test direction is constant within the permuted groups;
     // its mixed table needs the indicators as Khatri-Rao "contexts": m <= 128)
-    const bool collapsed = grouped && ctx->collapse && bd_bytes <= ((size_t)48 << 30) && (!idx_G || panel->m <= 128);
+    const bool collapsed = grouped && ctx->collapse && allow_collapse && bd_bytes <= ((size_t)48 << 30) &&
+                           (!idx_G || panel->m <= 128);
+    if (!collapsed) {   // the block in the fixed effects' own basis, and its product with the test direction
+        CRM_TRY(ctx->ws_Gx.ensure(sizeof(double) * (size_t)np * ldb));
+        CRM_TRY(ctx->ws_GG.ensure(sizeof(double) * (size_t)np * ldb));
+    }
     const bool cross = collapsed && idx_G;
     const long ld_ah = round_up((long)BLK * k0, 128) + 128, ld_xg = round_up((long)max_pairs * k0, 128) + 128;
     // Kinship-structure route (objects.h, crm_background::kin): H'(g o E0) donor by donor, then Mix(rho*)' -- the dense
@@ -1072,6 +1172,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
     std::vector<GemmProblem> probs(CRM_MAX_RHO + 4);
     std::vector<int> pair_of((size_t)nrho * BLK);
+    std::vector<int> h_near(BLK);
 
     for (long done = 0; done < count; done += BLK) {
         const int nb = (int)std::min<long>(BLK, count - done);
@@ -1096,14 +1197,28 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 CRM_TRY(launch_gather_block(st, panel->G.as<double>() + col0, panel->ld, np, n, d_idxG, nullptr, nb, Gt, ldb, (int)ldb));
             }
         }
-        // 2. g'g, g'W (shared) and g'y per gene
+        // 2. The fixed effects' role of the variants: Gx = G - W (W'W)^-1 W'G, orthogonalised against the covariates in
+        //    the cell axis as the reference's economic_svd([W, g]) basis is (blockops.hip); the test direction keeps G.
+        //    Then g'g, g'W (shared) and g'y per gene of that role.  The collapsed path works on donor-level sums and
+        //    cannot do this: it marks the variants that are nearly collinear with W for a second, dense pass.
+        double* Gx = Gb;
+        if (!collapsed) {
+            Gx = ctx->ws_Gx.as<double>();
+            CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g0->yW.as<double>(), g0->yW.as<double>() + 1, g0->ld_yw, c, d_part, d_gg, d_gy, d_gW, ld_gW));
+            CRM_TRY(launch_ortho_block(st, Gb, ldb, np, nb, (int)ldb, g0->yW.as<double>() + 1, g0->ld_yw, c, g0->Wproj.as<double>(),
+                                       d_gW, ld_gW, d_coef, ldb, d_thr, Gx, ldb));
+        }
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             if (collapsed)
                 CRM_TRY(launch_donor_stats(st, Gb, ldb, (int)panel->m, nb, g->dt_sums.as<double>(), c, d_gg, d_gy + (size_t)gi * BLK, d_gW, ld_gW));
             else
-                CRM_TRY(launch_variant_stats(st, Gb, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, ld_gW));
+                CRM_TRY(launch_variant_stats(st, Gx, ldb, np, nb, g->yW.as<double>(), g->yW.as<double>() + 1, g->ld_yw, c, d_part, d_gg, d_gy + (size_t)gi * BLK, d_gW, ld_gW));
         }
+        if (collapsed) {
+            if (near_out) CRM_TRY(launch_collinear_flag(st, d_gg, d_gW, ld_gW, g0->Wproj.as<double>(), c, nb, COLLINEAR_TAU, d_near));
+        } else
+            CRM_TRY(launch_ortho_rank(st, d_gg, d_thr, nb, d_drop));
         // 3. T(rho) = G' Q0(rho) for all grid points.  With Q0(rho) = H Mix(rho) the n-length work is
         //    done once, (H'G), followed by eleven small products Mix(rho)'(H'G): 2 n cols + 2 cols sum r
         //    flops per variant instead of 2 n sum r.
@@ -1116,7 +1231,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             double* S2 = ctx->ws_S2.as<double>();
             const int k1 = bg->kin_k1, k2 = bg->kin_k2;
             const long groups = bg->kin_groups, mk = bg->kin_cols;
-            CRM_TRY(launch_gather_rows(st, Gb, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
+            CRM_TRY(launch_gather_rows(st, Gx, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
             std::vector<GemmProblem> kp((size_t)groups + k2);
             long maxlen = GEMM_BK;
             for (long d = 0; d < groups; d++) {
@@ -1144,7 +1259,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
         } else if (fastT) {
             GemmProblem p{};
-            p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gb; p.ldy = ldb;
+            p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gx; p.ldy = ldb;
             p.C = ctx->ws_TH.as<double>(); p.ldc = ldb; p.M = (int)bg->cols; p.N = nb;
             CRM_HIP(hipMemcpyAsync(d_probs, &p, sizeof p, hipMemcpyHostToDevice, st));
             CRM_TRY(launch_gemm_tn(ctx, d_probs, 1, (int)bg->cols, nb, np, false, 0, ks_h, th_slab));
@@ -1156,7 +1271,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.X = ctx->ws_TH.as<double>(); p.ldx = ldb;
                 p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
             } else {
-                p.X = Gb; p.ldx = ldb;
+                p.X = Gx; p.ldx = ldb;
                 p.Y = collapsed ? tab->TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
             }
             p.C = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; p.ldc = ldT;
@@ -1181,6 +1296,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
             fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = ld_gW;
+            fa.g_drop = collapsed ? nullptr : d_drop;
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             fa.probe = ctx->probe_on ? 1 : 0; fa.probe_x = ctx->probe_x;
             CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));
@@ -1199,7 +1315,11 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
         CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
+        if (collapsed && near_out) CRM_HIP(hipMemcpyAsync(h_near.data(), d_near, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));
+        if (collapsed && near_out)
+            for (int b = 0; b < nb; b++)
+                if (h_near[b]) near_out->push_back(done + b);
         for (int gi = 0; gi < ng; gi++)
             for (int b = 0; b < nb; b++) {
                 const int ri = h_fit[(size_t)gi * BLK + b].rho_index;
@@ -1441,8 +1561,8 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         // 7. elementwise products for the side contractions
         double* G2 = ctx->ws_G2.as<double>();
-        double* GG = (idx_G && !collapsed) ? ctx->ws_GG.as<double>() : nullptr;
-        CRM_TRY(launch_square_block(st, Gt, Gb, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
+        double* GG = !collapsed ? ctx->ws_GG.as<double>() : nullptr;   // (test direction) o (fixed-effect role)
+        CRM_TRY(launch_square_block(st, Gt, Gx, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
         if (!GG) GG = G2;
         // 8. y-free side contractions: Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
         const int s1 = collapsed ? 1 : ks1, s2 = collapsed ? 1 : ks2, s3 = collapsed ? 1 : ks3;
@@ -1509,6 +1629,7 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             aa.Z1 = dZ1g; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
             aa.WW = g->WW.as<double>(); aa.Wy = g->Wy.as<double>(); aa.yy = g->yy;
             aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = ld_gW;
+            aa.coef = collapsed ? nullptr : d_coef; aa.ld_coef = ldb;
             aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
             CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
             CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));
@@ -1546,6 +1667,40 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     return CRM_OK;
 }
 
+// The scan of [first, first + count): one pass, plus -- after a collapsed pass -- a dense pass over every run of variants
+// the collapsed one marked as nearly collinear with the covariates (their results are overwritten).
+static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long first, long count,
+                     const int* idx_E, const int* idx_G, const std::vector<ScanOut>& outs) {
+    std::vector<long> near;
+    CRM_TRY(scan_pass(genes, panel, first, count, idx_E, idx_G, outs, true, &near));
+    crm_ctx* ctx = genes[0]->ctx;
+    if (near.empty() || ctx->probe_on) return CRM_OK;
+    const int k0 = genes[0]->k0;
+    struct Quiet {   // (the repeated variants were reported as done by the first pass)
+        crm_ctx* c; void (*saved)(long, long, void*);
+        explicit Quiet(crm_ctx* c_) : c(c_), saved(c_->progress) { c->progress = nullptr; }
+        ~Quiet() { c->progress = saved; }
+    } quiet(ctx);
+    ctx->dense_repeats += (long)near.size();
+    for (size_t i = 0; i < near.size();) {
+        size_t j = i + 1;
+        while (j < near.size() && near[j] == near[j - 1] + 1) j++;
+        const long off = near[i], len = (long)(j - i);
+        std::vector<ScanOut> shifted(outs);
+        for (ScanOut& o : shifted) {
+            auto at = [&](double* p, long stride) { return p ? p + off * stride : nullptr; };
+            o.pv = at(o.pv, 1); o.rho1 = at(o.rho1, 1); o.e2 = at(o.e2, 1); o.g2 = at(o.g2, 1); o.eps2 = at(o.eps2, 1);
+            o.Q = at(o.Q, 1); o.lml = at(o.lml, 1); o.delta = at(o.delta, 1); o.scale = at(o.scale, 1);
+            o.lambda = at(o.lambda, k0); o.F = at(o.F, (long)k0 * k0); o.liu = at(o.liu, 1);
+            if (o.ifault) o.ifault += off;
+            if (o.flags) o.flags += off;
+        }
+        CRM_TRY(scan_pass(genes, panel, first + off, len, idx_E, idx_G, shifted, false, nullptr));
+        i = j;
+    }
+    return CRM_OK;
+}
+
 }  // namespace crm
 
 extern "C" {
@@ -1579,6 +1734,8 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
 }
 
 long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
+
+long crm_test_dense_repeats(const crm_ctx* ctx) { return ctx ? ctx->dense_repeats : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
     return crm::guarded_on("crm_test_set_shared_h", ctx, [&]() -> int {

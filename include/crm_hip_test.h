@@ -44,6 +44,9 @@ int crm_test_set_kinship_route(crm_ctx* ctx, int on);
 /* Number of Khatri-Rao blocks of this context's scans whose last columns went through the 160-column-tile launch
  * (scan.hip: spectra with r mod 128 <= 32); tests use it to know which form they exercised. */
 long crm_test_tail_launches(const crm_ctx* ctx);
+/* Variants that scans on the donor-collapsed path repeated on the dense path because they were nearly collinear with the
+ * covariates (scan.hip: COLLINEAR_TAU; the dense path orthogonalises the block against W in the cell axis). */
+long crm_test_dense_repeats(const crm_ctx* ctx);
 /* The same product stored transposed: CT (N x (B*k0)). */
 int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                            const double* E, const double* Y, double* CT);

@@ -62,6 +62,103 @@ def test_genotype_inside_span_of_covariates_and_rank_deficient_W():
             assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
 
 
+def _variants_at_the_rank_rule(W, n, targets, seed=3):
+    """Columns base + e u (base in span(W), u a unit vector orthogonal to it) whose smallest singular value in [W, g]
+    is targets[col] * sqrt(eps); returns {col: vector} and whether numpy_sugar.economic_svd keeps three directions."""
+    from oracle.sugar import economic_svd, epsilon
+
+    rng = np.random.default_rng(seed)
+    Qw, _ = np.linalg.qr(W)
+    u = rng.normal(size=n)
+    u -= Qw @ (Qw.T @ u)
+    u /= np.linalg.norm(u)
+    base = W @ np.array([0.7, -0.4])
+    cols, kept = {}, {}
+    for col, target in targets.items():
+        lo, hi = 1e-14, 1e-4
+        for _ in range(200):
+            mid = np.sqrt(lo * hi)
+            small = np.linalg.svd(np.c_[W, base + mid * u], compute_uv=False)[-1]
+            lo, hi = (mid, hi) if small < target * epsilon.small else (lo, mid)
+        cols[col] = base + hi * u
+        kept[col] = economic_svd(np.c_[W, cols[col]])[1].shape[0] == 3
+    return cols, kept
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.003])
+def test_variant_on_either_side_of_the_references_rank_rule(scale):
+    """glimix-core's LMM reduces X = [W, g] by numpy_sugar.economic_svd: a direction whose singular value lies below
+    sqrt(eps) = 1.49e-8 (absolute) is dropped.  The engine applies the same rule to the smallest singular value of
+    [W, g] (csrc/blockops.hip: ortho_coef_kernel -- the secular equation of [W, g]'[W, g] at eps): variants built to sit
+    at 0.5 and at 2 times the threshold come out on the oracle's side of it (MODEL_G_IN_SPAN_W, the null fit's degrees
+    of freedom).  The projection of the score test follows ANOTHER rule of the reference -- PMat's lstsq(rcond=None) on
+    X'K^-1X, relative eps (c + 1) (_math.py:33-37) -- which the engine decides separately (csrc/assemble.hip:
+    finalize_kernel).  scale = 1 (columns of norm ~ sqrt(n)): lstsq cuts both built variants; the one below the LMM's
+    threshold is compared (the one above it sits where the oracle's own LMM solves its fixed effects by a truncated
+    lstsq while counting the direction in its degrees of freedom -- a corner nothing pins).
+    scale = 0.003 (tiny columns): lstsq keeps both, the LMM drops one -- the two rules part, and the engine parts with
+    them."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from fuzz_cases import random_problem
+    from oracle.crm import OracleCellRegMap
+
+    y, E, W, G, kw = random_problem(120, 3, 2, 4, 6, seed=11, mode="B")
+    W = scale * W
+    cols, kept = _variants_at_the_rank_rule(W, y.size, {1: 0.5, 3: 2.0})
+    assert kept == {1: False, 3: True}
+    G = G.copy()
+    for col, g in cols.items():
+        G[:, col] = g
+    crm = CellRegMap(y, E, W=W, **kw)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, **kw).scan_interaction(G, return_stats=True)
+    panel = GenotypePanel(G, groups=None)
+    pv, info = crm.scan_interaction_info(panel)
+    assert list((info["model_flags"] & 4) != 0) == [False, True, False, False], info["model_flags"]
+    pv2, info2, st = crm.scan_interaction(panel, return_stats=True)
+    assert_allclose(info2["rho1"], oinfo["rho1"], atol=1e-12)
+    for j in (0, 2):      # untouched variants at the usual bar
+        assert abs(st["Q"][j] - ost["Q"][j]) <= 1e-6 * ost["Q"][j] and abs(pv2[j] - opv[j]) <= P_RTOL * opv[j]
+    # The built ones.  Where PMat keeps the variant (scale 0.003) the reference's own projection is solved by lstsq on a
+    # 3 x 3 matrix of condition (0.04 / 7e-9)^2 ~ 3e13 in the raw basis: its Q carries eps * cond ~ 1e-3 of noise, which
+    # the orthogonalised basis here does not (measured difference 1e-4)
+    tol = 1e-5 if scale == 1.0 else 2e-3
+    for j in ((1,) if scale == 1.0 else (1, 3)):
+        assert abs(st["lml"][j] - ost["lml"][j]) <= 1e-8 * abs(ost["lml"][j]), (j, st["lml"][j], ost["lml"][j])
+        assert abs(st["Q"][j] - ost["Q"][j]) <= tol * ost["Q"][j], (j, st["Q"][j], ost["Q"][j])
+        assert abs(pv2[j] - opv[j]) <= 10 * tol * opv[j], (j, pv2[j], opv[j])
+
+
+@pytest.mark.parametrize("problem", [238, 344])
+def test_nearly_collinear_variants_in_the_fixed_effects_own_basis(problem):
+    """Two-donor problems of the fuzz stream (tools/fuzz_scan.py verbatim 400 2026, problems 238 and 344: the two
+    donors' dosages nearly coincide on many variants, which then keep 1e-4 ... 1e-2 of their squared norm outside
+    span(W)).  Round 3 solved the fixed effects by Cholesky in the raw [W, g] basis and its likelihood was 1e-13 ... 2e-11
+    off the oracle's there; with the variants orthogonalised against W in the cell axis (the reference's economic_svd
+    basis; csrc/blockops.hip) the log-likelihoods agree to 1e-13 on the dense path and on the collapsed path, which
+    hands the nearly collinear variants to the dense one.  Under the verbatim procedure Q still differs by one stopping
+    tolerance of Brent's search (1.8e-6 here) on a quarter of these variants: their likelihood is flat enough for the
+    last comparison of the search to be decided by the last bits, with the objective equal to 2e-15 at fixed points
+    (profiles/r04_collinear_diag.json) -- so Q and p are held to the oracle-vs-oracle envelope, not to 1e-6."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
+    from fuzz_cases import build_case, fuzz_cases
+    from oracle.crm import OracleCellRegMap
+
+    case = [c for c in fuzz_cases(400, seed=2026) if c[0] == problem][0]
+    y, E, W, G, kw, hooks = build_case(case)
+    crm = CellRegMap(y, E, W=W, **kw)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, **kw).scan_interaction(G, return_stats=True, **hooks)
+    lib, ctx = _lib.load(), _engine._context(0)
+    before = lib.crm_test_dense_repeats(ctx)
+    for groups in (None, "auto"):
+        pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
+        assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+        assert np.max(np.abs(st["lml"] - ost["lml"]) / np.abs(ost["lml"])) < 1e-13
+        qscale = np.maximum(np.abs(ost["Q"]), [np.trace(F) for F in ost["F"]])
+        assert np.max(np.abs(st["Q"] - ost["Q"]) / qscale) < 2e-5
+        assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL)
+    assert lib.crm_test_dense_repeats(ctx) > before      # the collapsed scan did hand variants to the dense path
+
+
 def test_zero_genotype_gives_nan_not_a_crash():
     """g = 0 makes dK = 0: chiscore raises "No eigenvalue is bigger than 0" and the reference's whole
     scan dies; the engine flags that variant with NaN and carries on."""

@@ -49,8 +49,32 @@ def _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, k0, q_rtol=1e-6, d
     assert np.all(np.abs(pv[pick] - opv) <= p_rtol * opv + P_ATOL), np.c_[pv[pick], opv]
 
 
-@pytest.fixture(scope="module")
-def cfg2():
+ROUTES = ["kinship", "direct"]
+
+
+class _route:
+    """The two product routes of the dense scan: the kinship-structure route (default whenever the kinship factor is
+    donor-expanded: H'(g o E0) donor by donor, then Mix(rho*)') and the direct Khatri-Rao contraction against Q0(rho*) --
+    what a cell-level kinship factor gets.  ``with _route("direct")`` switches the first one off on the test context."""
+
+    def __init__(self, name):
+        self.on = {"kinship": 1, "direct": 0}[name]
+
+    def __enter__(self):
+        from cellregmap_amd import _engine, _lib
+
+        self.lib, self.ctx = _lib.load(), _engine._context(0)
+        _lib.check(self.lib.crm_test_set_kinship_route(self.ctx, self.on))
+
+    def __exit__(self, *exc):
+        from cellregmap_amd import _lib
+
+        _lib.check(self.lib.crm_test_set_kinship_route(self.ctx, 1))
+
+
+@pytest.fixture(scope="module", params=ROUTES)
+def cfg2(request):
+    """BASELINE config 2, every test below once per route (the hook stays set while the parameter's tests run)."""
     from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
     from cellregmap_amd.synth import make_config
 
@@ -58,8 +82,9 @@ def cfg2():
     Ls = get_L_values(c.hK, c.E)
     crm = CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
     dense = GenotypePanel(c.G, groups=None)
-    pv, info, st = crm.scan_interaction(dense, return_stats=True)
-    return c, Ls, crm, dense, pv, info, st
+    with _route(request.param):
+        pv, info, st = crm.scan_interaction(dense, return_stats=True)
+        yield c, Ls, crm, dense, pv, info, st
 
 
 def test_oracle_spot_check_at_config2(cfg2):
@@ -183,10 +208,16 @@ def test_planted_effects_are_found(cfg2):
     assert np.median(others) > 0.1
 
 
-def test_config3_block_headline_size():
+@pytest.mark.parametrize("route", ROUTES)
+def test_config3_block_headline_size(route):
     """BASELINE config 3 (the bench workload: 20 000 cells x 50 contexts, mode C, r ~ 5 000) on one
-    block of variants: the oracle on 32 seeded random variants (device's decompositions), dense path ==
-    donor-collapsed path, affine invariance of the phenotype, and the factorisation behind it."""
+    block of variants, once per product route: the oracle on 32 seeded random variants (device's decompositions),
+    dense path == donor-collapsed path, affine invariance of the phenotype, and the factorisation behind it."""
+    with _route(route):
+        _config3_block(route)
+
+
+def _config3_block(route):
     from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values
     from cellregmap_amd.synth import make_config
 
@@ -199,22 +230,24 @@ def test_config3_block_headline_size():
     fallbacks = _lib.load().crm_test_sync_fallbacks(_engine._context(0))
     pv, info, st = crm.scan_interaction(dense, return_stats=True)
     assert np.all(np.isfinite(pv)) and np.all((pv > 0) & (pv <= 1))
-    # the contraction of this block ran in its persistent per-XCD form (3 900 tiles); on a GPU this process has to itself
-    # none of its bounded waits runs out (a context that saw them time out would leave that form: crm_test_sync_fallbacks)
+    # the direct route's contraction of this block runs in its persistent per-XCD form (3 900 tiles); on a GPU this process
+    # has to itself none of its bounded waits runs out (a context that saw them time out would leave that form:
+    # crm_test_sync_fallbacks)
     assert _lib.load().crm_test_sync_fallbacks(_engine._context(0)) == fallbacks
 
-    # factorisation: Q0 S0 Q0' v == hS hS' v for one interior grid point, Q0 orthonormal
-    i = 6
-    rho = crm._rho1[i]
-    Q0, S0 = crm._bg.read(i, n)
-    v = np.random.default_rng(0).normal(size=(n, 2))
-    KE = c.E @ (c.E.T @ v)
-    u = Ls.us
-    lhs = rho * KE + (1 - rho) * sum(u[:, [j]] * (c.hK @ (c.hK.T @ (u[:, [j]] * v))) for j in range(u.shape[1]))
-    rhs = Q0 @ (S0[:, None] * (Q0.T @ v))
-    assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
-    G = Q0.T @ Q0
-    assert np.abs(G - np.eye(G.shape[0])).max() < 1e-11
+    if route == "kinship":   # (the background does not depend on the scan's route: once is enough)
+        # factorisation: Q0 S0 Q0' v == hS hS' v for one interior grid point, Q0 orthonormal
+        i = 6
+        rho = crm._rho1[i]
+        Q0, S0 = crm._bg.read(i, n)
+        v = np.random.default_rng(0).normal(size=(n, 2))
+        KE = c.E @ (c.E.T @ v)
+        u = Ls.us
+        lhs = rho * KE + (1 - rho) * sum(u[:, [j]] * (c.hK @ (c.hK.T @ (u[:, [j]] * v))) for j in range(u.shape[1]))
+        rhs = Q0 @ (S0[:, None] * (Q0.T @ v))
+        assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(lhs).max()
+        G = Q0.T @ Q0
+        assert np.abs(G - np.eye(G.shape[0])).max() < 1e-11
 
     # oracle on 32 seeded random variants (+ the planted ones), sharing the device's decompositions:
     # rho*, delta, lml, Q, F, the eigenvalues of F and p
@@ -237,11 +270,18 @@ def test_config3_block_headline_size():
     assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
 
 
-def test_config4_per_gpu_shape_64_genes_against_one_panel():
+@pytest.mark.parametrize("route", ROUTES)
+def test_config4_per_gpu_shape_64_genes_against_one_panel(route):
     """BASELINE config 4's per-GPU shape: 64 phenotypes x one block of the config-3 panel in one pass
-    (``scan_interaction_many``; over 8 GPUs each rank runs exactly this on its shard of the variants).
+    (``scan_interaction_many``; over 8 GPUs each rank runs exactly this on its shard of the variants), once per product
+    route (direct: the cost model picks between one contraction per (variant, rho*) pair and the shared-H form).
     A few (gene, variant) pairs against the oracle on the device's decompositions; the pass against the
     single-gene scan for one gene; the genes must not all agree on rho* (else the pair logic is idle)."""
+    with _route(route):
+        _config4_shape()
+
+
+def _config4_shape():
     from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, scan_interaction_many
     from cellregmap_amd.synth import make_config
 
@@ -279,7 +319,13 @@ def test_config4_per_gpu_shape_64_genes_against_one_panel():
         del o
 
 
-def test_config5_hundred_thousand_cells():
+@pytest.mark.parametrize("route", ROUTES)
+def test_config5_hundred_thousand_cells(route):
+    with _route(route):
+        _config5(route)
+
+
+def _config5(route):
     """BASELINE config 5 (100 000 cells x 50 contexts, mode C: 10 050 columns, Q0 set ~ 89 GB in HBM) on one
     block of variants: the factorisation behind the background (random probes: the r x r Gram is 2e13 flop
     on the host), dense path == donor-collapsed path, affine invariance of the phenotype, and the oracle on
@@ -306,18 +352,19 @@ def test_config5_hundred_thousand_cells():
     # planted GxC variants (10, 11) come out on top
     assert set(np.argsort(pv)[:2]) == {10, 11}
 
-    # donor-collapsed path
-    pv_c, info_c, st_c = crm.scan_interaction(GenotypePanel(c.G), return_stats=True)
-    assert_allclose(info_c["rho1"], info["rho1"], atol=1e-12)
-    assert_allclose(st_c["Q"], st["Q"], rtol=5e-6)
-    assert np.all(np.abs(pv_c - pv) <= P_RTOL * pv + P_ATOL)
+    if route == "kinship":   # (neither depends on the dense scan's route: once is enough)
+        # donor-collapsed path
+        pv_c, info_c, st_c = crm.scan_interaction(GenotypePanel(c.G), return_stats=True)
+        assert_allclose(info_c["rho1"], info["rho1"], atol=1e-12)
+        assert_allclose(st_c["Q"], st["Q"], rtol=5e-6)
+        assert np.all(np.abs(pv_c - pv) <= P_RTOL * pv + P_ATOL)
 
-    # y -> a y + b on the same background
-    crm2 = CellRegMap(2.5 * c.y + 3.0, c.E, W=c.W, Ls=Ls, background=crm._bg)
-    pv2, info2 = crm2.scan_interaction(dense)
-    assert_allclose(info2["rho1"], info["rho1"], atol=1e-12)
-    assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
-    del crm2
+        # y -> a y + b on the same background
+        crm2 = CellRegMap(2.5 * c.y + 3.0, c.E, W=c.W, Ls=Ls, background=crm._bg)
+        pv2, info2 = crm2.scan_interaction(dense)
+        assert_allclose(info2["rho1"], info["rho1"], atol=1e-12)
+        assert np.all(np.abs(pv2 - pv) <= P_RTOL * pv + P_ATOL)
+        del crm2
 
     # the grid point most variants selected, and a neighbour
     idx = np.rint(info["rho1"] * 10).astype(int)
