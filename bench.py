@@ -70,7 +70,8 @@ def _free_port():
 
 
 def _launch_ranks(n, argv):
-    """One process per GPU through torch.distributed.run on 127.0.0.1; returns its exit code."""
+    """One process per GPU through torch.distributed.run on 127.0.0.1; returns its exit code (a failed rank makes the
+    launcher -- a fresh child process, never a re-exec of this one -- exit non-zero, and so does this script)."""
     import subprocess
 
     env = dict(os.environ)
@@ -78,6 +79,81 @@ def _launch_ranks(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
     return subprocess.call(cmd, env=env)
+
+
+class Comm:
+    """The process group the bench talks through.  ``nccl`` (= RCCL over xGMI) is the one the contract asks for; a ``gloo``
+    group over the same ranks is created beside it and takes over -- for every later collective -- if the first RCCL
+    collectives of the run raise (a communicator that cannot start: IPC handles, topology, a hung peer running into the
+    timeout).  Variants are independent, so a run on the slower group still measures the same scan; the line says which
+    group carried it (``multi_gpu.group``)."""
+
+    def __init__(self, dist, torch, share_gpu, local_rank):
+        self.dist, self.torch = dist, torch
+        self.group, self.backend, self.note = None, None, None
+        if dist is None:
+            return
+        import datetime
+
+        timeout = datetime.timedelta(seconds=int(os.environ.get("CRM_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
+        if share_gpu:   # dry run of the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+            dist.init_process_group("gloo", timeout=timeout)
+            self.backend = "gloo"
+            return
+        # (a collective that fails or times out must come back as an exception in this process, not as an abort of it)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
+        self.backend = "nccl"
+        self.safe = dist.new_group(backend="gloo", timeout=timeout)   # (rendezvous over the TCP store: no GPU involved)
+
+    def canary(self):
+        """First collectives of the run on RCCL, checked: an all_reduce and an all_gather of a few bytes."""
+        if self.dist is None or self.backend != "nccl":
+            return
+        dist, torch = self.dist, self.torch
+        ok = 1
+        try:
+            t = torch.ones(8, device="cuda")
+            dist.all_reduce(t)
+            parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, t)
+            torch.cuda.synchronize()
+            if float(t[0].item()) != float(dist.get_world_size()):
+                raise RuntimeError("all_reduce returned %r" % float(t[0].item()))
+        except Exception as exc:  # noqa: BLE001
+            ok = 0
+            self.note = "RCCL failed on its first collectives (%s: %s)" % (type(exc).__name__, str(exc)[:160])
+        # every rank must take the same group from here on: agree over gloo
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.safe)
+        if int(flag.item()) == 0:
+            self.group, self.backend = self.safe, "gloo"
+            self.note = (self.note or "RCCL failed on another rank") + "; every collective of this run went over gloo (host TCP)"
+
+    @property
+    def device(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
+
+    def max(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def table(self, row, rank, world):
+        """Every rank's row of floats on every rank (a world x len(row) nested list)."""
+        if self.dist is None:
+            return [list(map(float, row))]
+        t = self.torch.zeros((world, len(row)), dtype=self.torch.float64, device=self.device)
+        t[rank] = self.torch.tensor(list(map(float, row)), dtype=self.torch.float64)
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().tolist()
 
 
 def main():
@@ -130,15 +206,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:   # dry run of the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+        if share_gpu:
             local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
+    comm = Comm(dist, torch, share_gpu, local_rank)
 
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
     from cellregmap_amd.distributed import gather_variant_results, sharded_background, variant_shard
@@ -157,15 +228,9 @@ def main():
     def fence():
         _lib.check(lib.crm_ctx_synchronize(ctx))
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
 
-    def max_over_ranks(x):
-        if dist is None:
-            return float(x)
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    max_over_ranks = comm.max
 
     # ---- synthetic data (not timed): the cohort, this rank's shard of the config's fixed panel, and -- when
     #      that shard is shorter than a few batches -- a panel of its own for the weak-scaling steps
@@ -191,24 +256,33 @@ def main():
     toy = make_cohort(6, 16, 3, 8, seed=1)
     CellRegMap(toy.y, toy.E, W=toy.W, hK=toy.hK, device=local_rank).scan_interaction(toy.G)
     _engine._bg_cache.clear()
-    if dist is not None:
-        dist.all_reduce(torch.zeros(1, device="cuda"))
+    comm.canary()     # RCCL's first collectives, checked; on failure every rank moves to the gloo group
     fence()
 
     # ---- constructor (timed inside the end-to-end figure of the full-panel leg) --------------------------------
     t_start = time.perf_counter()
     Ls = get_L_values(cohort.hK, cohort.E)
     bg_kw = {"Ls": Ls} if args.mode == "C" else {"hK": cohort.hK}
+    exchange = {}
+    uploaded = {}
+
+    def upload_full_panel():
+        # (called by sharded_background while its collective is in flight: PCIe beside xGMI)
+        t0_ = time.perf_counter()
+        uploaded["panel"] = GenotypePanel(G_full, device=local_rank, groups=None)   # dense: general genotypes
+        _lib.check(lib.crm_ctx_synchronize(ctx))
+        uploaded["seconds"] = time.perf_counter() - t0_
+
     if world > 1 or (dist is not None and os.environ.get("CRM_BENCH_FORCE_EXCHANGE")):
         bg = sharded_background(cohort.E, Ls if args.mode == "C" else cohort.hK, _engine._RHO_GRID, device=local_rank,
-                                force_exchange=world == 1,
-                                tensor_device=torch.device("cuda", 0) if share_gpu else None)
+                                group=comm.group, force_exchange=world == 1,
+                                overlap=upload_full_panel if G_full is not None else None, info=exchange)
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, background=bg, **bg_kw)
     else:
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)
     crm._bind_gene()
     _lib.check(lib.crm_ctx_synchronize(ctx))
-    t_ctor = time.perf_counter() - t_start
+    t_ctor = time.perf_counter() - t_start     # (N > 1: includes the panel upload that ran beside the exchange)
     ranks = [crm._bg.rank(i) for i in range(len(crm._rho1))]
     gene = crm._gene
     cols = cohort.E.shape[1] + (Ls.us.shape[1] * Ls.hK.shape[1] if args.mode == "C" else cohort.hK.shape[1])
@@ -223,28 +297,41 @@ def main():
     fpanel_kept = None
     fpv = None
     if G_full is not None:
-        t0 = time.perf_counter()
-        fpanel = GenotypePanel(G_full, device=local_rank, groups=None)  # dense: general genotypes
-        _lib.check(lib.crm_ctx_synchronize(ctx))
-        t_up = time.perf_counter() - t0
+        if "panel" not in uploaded:
+            upload_full_panel()
+        fpanel, t_up = uploaded["panel"], uploaded["seconds"]
         fpv, frho = np.empty(f_count), np.empty(f_count)
         fence()
         t0 = time.perf_counter()
         scan(fpanel, 0, f_count, fpv, frho)
+        _lib.check(lib.crm_ctx_synchronize(ctx))
+        t_scan_mine = time.perf_counter() - t0
         fence()
         t_scan = max_over_ranks(time.perf_counter() - t0)
         t0 = time.perf_counter()
+        gather_note = None
         if dist is not None:
-            got = gather_variant_results({"pv": fpv, "rho1": frho}, p_total)
-            assert got["pv"].shape == (p_total,)
-            torch.cuda.synchronize()
+            try:
+                got = gather_variant_results({"pv": fpv, "rho1": frho}, p_total, comm.group)
+                assert got["pv"].shape == (p_total,)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001 -- the shard results are still valid; say what happened
+                gather_note = "gather of the results failed (%s: %s)" % (type(exc).__name__, str(exc)[:160])
         t_gather = time.perf_counter() - t0
         t_e2e = max_over_ranks(time.perf_counter() - t_start)
+        per_rank = comm.table([exchange.get("decompose_s", t_ctor), exchange.get("exchange_s", 0.0), t_up, t_scan_mine, t_gather,
+                               1.0 if exchange.get("exchange", "ok") in ("ok", "not needed") else 0.0], rank, world)
         full_panel = {"variants": p_total, "variants_per_rank": f_count, "constructor_s": round(max_over_ranks(t_ctor), 3),
                       "upload_s": round(max_over_ranks(t_up), 3), "scan_s": round(t_scan, 3), "gather_s": round(t_gather, 4),
                       "end_to_end_s": round(t_e2e, 3), "scan_only_rate": round(p_total / t_scan, 1),
                       "end_to_end_rate": round(p_total / t_e2e, 1), "scaling": "strong",
-                      "background": "grid points decomposed by different ranks, broadcast over RCCL" if world > 1 else "one rank",
+                      "background": ("grid points decomposed by different ranks, spectra + mixing matrices packed per owner and "
+                                     "exchanged in one all_gather (%s); the panel upload runs while it is in flight" % comm.backend)
+                                    if world > 1 else "one rank",
+                      "per_rank_s": {"columns": ["decompose", "exchange", "upload", "scan", "gather", "exchange_ok"],
+                                     "rows": [[round(v, 4) for v in row] for row in per_rank]},
+                      "exchange": exchange.get("exchange"), "exchanged_bytes_rank0": exchange.get("exchanged_bytes"),
+                      "gather": gather_note or ("ok" if world > 1 else None),
                       "note": "the fixed panel of the config sharded over the ranks; end to end = constructor + "
                               "panel upload (host float64) + scan + gather, max over ranks"}
         if f_count >= weak_blocks * batch:
@@ -286,7 +373,7 @@ def main():
     pv_dense = pv.copy()
     if dist is not None:
         # the path's one data-path collective: gather the shard results on every rank (RCCL over xGMI)
-        full = gather_variant_results({"pv": pv, "rho1": rho1, "Q": Q}, p_need * world)
+        full = gather_variant_results({"pv": pv, "rho1": rho1, "Q": Q}, p_need * world, comm.group)
         assert full["pv"].shape == (p_need * world,)
         torch.cuda.synchronize()
     total_variants = steps * batch * world
@@ -530,7 +617,9 @@ def main():
             8.0 * n + 8.0 * (n * float(sum(ranks)) + n * k0 + n * (c_cov + 1)) / p_total + 40.0),
         "setup_s": {"synthetic_data": round(t_data, 2), "background_constructor": round(t_ctor, 2)},
         "speedup_vs_cpu_baseline": None if not cpu else round(value / cpu["value"], 1),
-        "multi_gpu": {"ranks": world, "collective": "all_gather of the per-variant results (RCCL)" if world > 1 else None,
+        "multi_gpu": {"ranks": world, "group": comm.backend, "group_note": comm.note,
+                      "collectives": ("constructor: all_reduce of the ranks + one all_gather of the packed spectra / mixing "
+                                      "matrices; results: one all_gather of the per-variant outputs") if world > 1 else None,
                       "note": "per-N values are whatever this run measured on this node; the repository holds no measured N > 1 "
                               "run of its own (its build sessions only ever had one GPU) and models no scaling figure"},
         "full_panel": full_panel,

@@ -53,25 +53,42 @@ def grid_point_owner(i, world):
     return i % world
 
 
-def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_device=None, force_exchange=False):
+def owned_grid_points(nrho, rank, world):
+    return [i for i in range(nrho) if grid_point_owner(i, world) == rank]
+
+
+def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_device=None, force_exchange=False,
+                       overlap=None, info=None):
     """The background of ``CellRegMap(...)`` (cellregmap/_cellregmap.py:101-131: one economic
     eigendecomposition per grid point of rho) built ONCE per job instead of once per rank: rank r decomposes
-    the grid points i with i % world == r, the ranks are all-gathered (they fix the common leading
-    dimension), and every Q0(rho) / S0(rho) (and mixing matrix) is broadcast by its owner -- RCCL over xGMI
-    when the group is ``nccl`` (~0.8 GB per grid point at BASELINE config 3).  Returns the
-    sealed background; pass it as ``CellRegMap(..., background=...)``.
+    the grid points i with i % world == r, the ranks are all-reduced (they fix the common leading
+    dimension), and what the others need of every grid point -- spectrum and mixing matrix (0.2 GB per grid point
+    at BASELINE config 3; Q0 itself only where there is no mixing matrix) -- is exchanged in ONE collective: every
+    rank packs the slots of its grid points into one buffer and a single ``all_gather`` (RCCL over xGMI when the
+    group is ``nccl``) hands every rank every buffer.  Returns the sealed background; pass it as
+    ``CellRegMap(..., background=...)``.
 
     ``B``: what the constructor concatenates behind sqrt(rho) E1 -- ``None`` (mode A), hK (mode B), the
     ``HadamardHalves`` of ``get_L_values`` or their concatenation (mode C).
     ``builder``: factory ``mine -> object with rank / complete / layout / export_slot / import_slot / seal``
     (tests inject a numpy one); default: the HIP library's ``BackgroundBuilder``.
+    ``overlap``: callable run while the collective is in flight (the caller's panel upload: PCIe beside xGMI);
+    its return value lands in ``info["overlap_result"]``.
+    ``info``: dict that receives the phase timings (``decompose_s``, ``exchange_s`` = pack + collective + unpack,
+    ``overlap_s``), the bytes this rank contributed, and ``exchange`` = "ok" / "not needed" / "failed: ...".
+    If anything in the exchange raises -- a collective, an import -- this rank falls back to decomposing every grid
+    point itself (the 0.9 s single-GPU constructor): the result is the same background either way, so ranks need
+    not agree on which way they took.
 
     Order of initialisation in a process that uses torch on the GPU and this library: torch first
     (``torch.cuda.set_device`` / ``init_process_group(..., device_id=...)``), then the first call into the
     library -- both then share one HIP runtime and device pointers can be handed across."""
+    import time
+
     import torch
     import torch.distributed as dist
 
+    info = {} if info is None else info
     rho = np.asarray(rho, float)
     nrho = rho.shape[0]
     if dist.is_available() and dist.is_initialized():
@@ -84,33 +101,79 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
 
         def builder(flags):
             return BackgroundBuilder(E1, B, rho, device=device, mine=flags)
-    b = builder(mine)
-    if world == 1 and not (force_exchange and dist.is_available() and dist.is_initialized()):
-        b.complete([b.rank(i) for i in range(nrho)])
-        return b.seal()
+
+    def everything_here():
+        full = builder(np.ones(nrho, np.int32))
+        full.complete([full.rank(i) for i in range(nrho)])
+        return full.seal()
+
+    t0 = time.perf_counter()
+    exchanging = world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
+    if not exchanging:
+        bg = everything_here()
+        info.update(decompose_s=time.perf_counter() - t0, exchange_s=0.0, exchange="not needed", exchanged_bytes=0)
+        if overlap is not None:
+            info["overlap_result"] = overlap()
+        return bg
     # (force_exchange: a world of one still runs the collective calls and copies every slot out and back in --
     # the whole exchange path on a single GPU)
-    nccl = dist.get_backend(group) == "nccl"
-    dev = tensor_device if tensor_device is not None else (torch.device("cuda", device) if nccl else torch.device("cpu"))
-    ranks = torch.tensor([b.rank(i) if mine[i] else -1 for i in range(nrho)], dtype=torch.int64, device=dev)
-    dist.all_reduce(ranks, op=dist.ReduceOp.MAX, group=group)
-    b.complete(ranks.cpu().numpy())
-    for what, size in b.layout().items():
-        buf = torch.empty(size, dtype=torch.float64, device=dev)
-        for i in range(nrho):
-            owner = grid_point_owner(i, world)
-            if owner == rank:
-                b.export_slot(i, what, buf)
-            src = owner if group is None else dist.get_global_rank(group, owner)
-            dist.broadcast(buf, src=src, group=group)
-            if buf.is_cuda:
-                # RCCL returns once the broadcast is queued on its stream; the library copies on its own stream, and
-                # the owner's next export reuses this buffer: wait for the collective itself
-                torch.cuda.current_stream(buf.device).synchronize()
-            if owner != rank or force_exchange:
-                b.import_slot(i, what, buf)
-        del buf
-    return b.seal()
+    try:
+        b = builder(mine)
+        info["decompose_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        nccl = dist.get_backend(group) == "nccl"
+        dev = tensor_device if tensor_device is not None else (torch.device("cuda", device) if nccl else torch.device("cpu"))
+        ranks = torch.tensor([b.rank(i) if mine[i] else -1 for i in range(nrho)], dtype=torch.int64, device=dev)
+        dist.all_reduce(ranks, op=dist.ReduceOp.MAX, group=group)
+        b.complete(ranks.cpu().numpy())
+        layout = b.layout()                                   # slot name -> doubles, the same on every rank
+        per_point = int(sum(layout.values()))
+        most = (nrho + world - 1) // world                    # grid points of the busiest rank: every piece has that size
+        pack = torch.zeros(most * per_point, dtype=torch.float64, device=dev)
+        for k, i in enumerate(owned_grid_points(nrho, rank, world)):
+            off = k * per_point
+            for what, size in layout.items():
+                b.export_slot(i, what, pack[off:off + size])
+                off += size
+        # (gloo has no all_gather of GPU tensors: device buffers -- the two-ranks-on-one-GPU test -- travel through host copies)
+        staged = (not nccl) and pack.is_cuda
+        wire = pack.cpu() if staged else pack
+        everything = torch.empty(world * most * per_point, dtype=torch.float64, device=wire.device)
+        work = dist.all_gather(list(everything.chunk(world)), wire, group=group, async_op=True)
+        if overlap is not None:
+            t2 = time.perf_counter()
+            info["overlap_result"] = overlap()
+            info["overlap_s"] = time.perf_counter() - t2
+        work.wait()
+        if staged:
+            everything = everything.to(dev)
+        if everything.is_cuda:
+            # the wait orders torch's current stream behind the collective; the library copies on its own stream
+            torch.cuda.current_stream(everything.device).synchronize()
+        for r in range(world):
+            if r == rank and not force_exchange:
+                continue
+            for k, i in enumerate(owned_grid_points(nrho, r, world)):
+                off = (r * most + k) * per_point
+                for what, size in layout.items():
+                    b.import_slot(i, what, everything[off:off + size])
+                    off += size
+        bg = b.seal()
+        info.update(exchange_s=time.perf_counter() - t1 - info.get("overlap_s", 0.0), exchange="ok",
+                    exchanged_bytes=8 * int(mine.sum()) * per_point, collectives=2)
+        return bg
+    except Exception as exc:  # noqa: BLE001 -- whatever went wrong, every rank can still build the whole background alone
+        import warnings
+
+        warnings.warn(f"rank {rank}: the exchange of the background failed ({type(exc).__name__}: {exc}); decomposing every grid "
+                      "point on this rank instead", RuntimeWarning, stacklevel=2)
+        t3 = time.perf_counter()
+        b = None
+        bg = everything_here()
+        info.update(exchange="failed: %s: %s" % (type(exc).__name__, str(exc)[:200]), fallback_s=time.perf_counter() - t3)
+        if overlap is not None and "overlap_result" not in info:
+            info["overlap_result"] = overlap()
+        return bg
 
 
 def _my_columns(G, p_total, rank, world):

@@ -190,7 +190,56 @@ def _ctor_worker(rank, world, port, q):
 
         c = make_cohort(6, 10, 3, 4, seed=13)
         rho = np.linspace(0, 1, 11)
-        b = sharded_background(c.E, c.hK, rho, builder=lambda mine: _NumpyBuilder(c.E, c.hK, rho, mine))
+        info = {}
+        b = sharded_background(c.E, c.hK, rho, builder=lambda mine: _NumpyBuilder(c.E, c.hK, rho, mine),
+                               overlap=lambda: "uploaded while the collective ran", info=info)
+        # one packed all_gather (+ the all_reduce of the ranks), the overlap hook ran, timings recorded
+        assert info["exchange"] == "ok" and info["collectives"] == 2, info
+        assert info["overlap_result"] == "uploaded while the collective ran"
+        assert info["exchanged_bytes"] == 8 * len(b.decomposed) * (b.n * b.ldq + b.ldq)
+        assert all(k in info for k in ("decompose_s", "exchange_s", "overlap_s"))
+        q.put((rank, b.decomposed, b.ranks, {i: (s["Q0"].copy(), s["S0"].copy()) for i, s in b.slots.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _ctor_worker_failing(rank, world, port, q, how):
+    """The exchange goes wrong -- the collective itself raises on every rank ("collective"), or one rank cannot take
+    what it received ("import", rank 1 only): the affected ranks decompose every grid point themselves."""
+    sys.path.insert(0, ROOT)
+    import warnings
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cellregmap_amd import distributed
+        from cellregmap_amd.synth import make_cohort
+
+        c = make_cohort(6, 10, 3, 4, seed=13)
+        rho = np.linspace(0, 1, 11)
+
+        class Builder(_NumpyBuilder):
+            def import_slot(self, i, what, tensor):
+                if how == "import" and rank == 1:
+                    raise RuntimeError("simulated: the received slot cannot be copied in")
+                super().import_slot(i, what, tensor)
+
+        if how == "collective":
+            def broken(*a, **k):
+                raise RuntimeError("simulated: ncclCommInitRank failed")
+            dist.all_gather = broken
+        info = {}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            b = distributed.sharded_background(c.E, c.hK, rho, builder=lambda mine: Builder(c.E, c.hK, rho, mine), info=info,
+                                               overlap=lambda: 7)
+        failed = how == "collective" or rank == 1
+        assert info["exchange"].startswith("failed: RuntimeError: simulated") == failed, info
+        assert any("decomposing every grid point on this rank" in str(w.message) for w in caught) == failed
+        assert info["overlap_result"] == 7
         q.put((rank, b.decomposed, b.ranks, {i: (s["Q0"].copy(), s["S0"].copy()) for i, s in b.slots.items()}))
     finally:
         dist.destroy_process_group()
@@ -222,6 +271,41 @@ def test_sharded_constructor_two_ranks():
     assert ref.decomposed == list(range(11))
     assert results[0][1] == [0, 2, 4, 6, 8, 10] and results[1][1] == [1, 3, 5, 7, 9]
     for rank, _, ranks, slots in results:
+        assert ranks == ref.ranks
+        for i in range(11):
+            assert np.array_equal(slots[i][0], ref.slots[i]["Q0"]) and np.array_equal(slots[i][1], ref.slots[i]["S0"])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("how", ["collective", "import"])
+def test_sharded_constructor_falls_back_to_a_local_build_when_the_exchange_fails(how):
+    """A rank whose exchange raises -- the collective itself (RCCL that cannot start: every rank), or the import of what
+    it received (one rank) -- decomposes all eleven grid points itself and ends up with the same background as the
+    ranks that exchanged; nobody has to agree on which way was taken."""
+    import torch.multiprocessing as mp
+
+    from cellregmap_amd.distributed import sharded_background
+    from cellregmap_amd.synth import make_cohort
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ctor_worker_failing, args=(r, 2, port, q, how)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = make_cohort(6, 10, 3, 4, seed=13)
+    rho = np.linspace(0, 1, 11)
+    ref = sharded_background(c.E, c.hK, rho, builder=lambda mine: _NumpyBuilder(c.E, c.hK, rho, mine))
+    for rank, decomposed, ranks, slots in results:
+        assert decomposed == (list(range(11)) if how == "collective" or rank == 1 else [0, 2, 4, 6, 8, 10])
         assert ranks == ref.ranks
         for i in range(11):
             assert np.array_equal(slots[i][0], ref.slots[i]["Q0"]) and np.array_equal(slots[i][1], ref.slots[i]["S0"])

@@ -2,7 +2,8 @@
 
 The process group is gloo (RCCL refuses two ranks on one device) but everything else is the real N > 1 path of
 bench.py --gpus N: rank r decomposes the grid points i % 2 == r with the HIP eigen-solver, spectra / mixing
-matrices (or Q0 on the eigh branch) travel between the two processes as CUDA tensors, each rank uploads only its
+matrices (or Q0 on the eigh branch) are packed per owner and exchanged in one all_gather (exported to / imported from
+CUDA tensors; gloo carries host copies of them), each rank uploads only its
 own shard of the panel, scans it, and the per-variant results are all-gathered.  Rank 0 writes the gathered result
 and the constructor's spectra to ``out`` (npz); the test compares them with the oracle and a one-process run."""
 import os
@@ -42,7 +43,13 @@ def main():
     else:
         B = crm.get_L_values(c.hK, c.E)
         kw = dict(Ls=B)
-    bg = sharded_background(c.E, B, rho, device=0, tensor_device=None if host else torch.device("cuda", 0))
+    info = {}
+    bg = sharded_background(c.E, B, rho, device=0, tensor_device=None if host else torch.device("cuda", 0), info=info,
+                            overlap=lambda: "ran beside the collective")
+    # the packed exchange itself must have carried the grid points (a silent fall-back to a local build would pass the
+    # comparisons below just as well)
+    assert info["exchange"] == "ok" and info["collectives"] == 2 and info["exchanged_bytes"] > 0, info
+    assert info["overlap_result"] == "ran beside the collective"
     obj = crm.CellRegMap(c.y, c.E, W=c.W, background=bg, **kw)
     first, count = variant_shard(p, rank, world)
     shard = np.ascontiguousarray(c.G[:, first:first + count])
