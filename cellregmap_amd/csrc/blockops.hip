@@ -459,6 +459,44 @@ int launch_collinear_flag(hipStream_t st, const double* gg, const double* gW, lo
     return CRM_OK;
 }
 
+// ---- E1 rows of the folded kinship-structure form through pair products (scan.hip, step 6) --------------------------
+// P[c, a k0 + i] = H[c, a] * Ep[c, i]  (a < k1: the E1 columns of the half factor; Ep: the scan's (permuted) contexts)
+__global__ void pair_features_kernel(const double* __restrict__ H, long ldh, int k1, const double* __restrict__ Ep,
+                                     long ld_ep, int k0, double* __restrict__ P, long ldp) {
+    const long c = blockIdx.x;
+    for (int q = threadIdx.x; q < ldp; q += blockDim.x) {
+        const int a = q / k0, i = q - a * k0;
+        P[c * ldp + q] = a < k1 ? H[c * ldh + a] * Ep[c * ld_ep + i] : 0.0;
+    }
+}
+
+int launch_pair_features(hipStream_t st, const double* H, long ldh, int k1, const double* Ep, long ld_ep, int k0,
+                         long cells_pad, double* P, long ldp) {
+    if (cells_pad <= 0) return CRM_OK;
+    hipLaunchKernelGGL(pair_features_kernel, dim3((unsigned)cells_pad), dim3(256), 0, st, H, ldh, k1, Ep, ld_ep, k0, P, ldp);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+// S[a, b k0 + i] = C[b, a k0 + i]  (b < variants, a < k1, i < k0): k0-long runs are contiguous on both sides
+__global__ void pair_rows_kernel(const double* __restrict__ C, long ldc, int variants, int k1, int k0,
+                                 double* __restrict__ S, long lds) {
+    const int a = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // b k0 + i
+    if (e >= (long)variants * k0) return;
+    const long b = e / k0;
+    const int i = (int)(e - b * k0);
+    S[(long)a * lds + e] = C[b * ldc + (long)a * k0 + i];
+}
+
+int launch_pair_rows(hipStream_t st, const double* C, long ldc, int variants, int k1, int k0, double* S, long lds) {
+    if (variants <= 0 || k1 <= 0) return CRM_OK;
+    dim3 grid((unsigned)(((long)variants * k0 + 255) / 256), (unsigned)k1);
+    hipLaunchKernelGGL(pair_rows_kernel, grid, dim3(256), 0, st, C, ldc, variants, k1, k0, S, lds);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols) {

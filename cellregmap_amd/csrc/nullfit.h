@@ -107,6 +107,10 @@ int launch_kin_verify(hipStream_t st, const double* H, long ldh, int k1, const d
                       const double* hKd, long ldk, long m, long n, unsigned long long* out);
 int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2, int k1, int groups, long cols, double* AH,
                       long ld_ah);
+// pair products P[c, a k0 + i] = H[c, a] Ep[c, i] (a < k1), and the rows S[a, b k0 + i] = C[b, a k0 + i] of a product G'P
+int launch_pair_features(hipStream_t st, const double* H, long ldh, int k1, const double* Ep, long ld_ep, int k0,
+                         long cells_pad, double* P, long ldp);
+int launch_pair_rows(hipStream_t st, const double* C, long ldc, int variants, int k1, int k0, double* S, long lds);
 // dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]
 int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
                         long cells, const int* row_index, int variants, double* dst, long ld_dst,

@@ -61,6 +61,15 @@ struct crm_background {
     long kin_ldy = 128;
     crm::DevBuf kin_hKd;                        // [kin_groups_pad x kin_ldh]
     long kin_ldh = 0;
+    // The donor-level factor folded into the mixing matrices: with rows ordered [E1_a ; (d', us_j)],
+    //   Q0(rho)'(g o E0) = MixK(rho)' [sum over all cells for E1_a ; S[d', us_j, .]],
+    //   MixK(rho)[a, :] = Mix(rho)[a, :],   MixK(rho)[k1 + d' k2 + j, :] = sum_d hKd[d', d] Mix(rho)[k1 + j m + d, :]
+    // -- the contraction over the donors is done once per grid point, when the structure is announced, instead of once
+    // per block of variants; the per-donor sums S are then the operand of the Mix product as they stand.  Taken when
+    // k1 + donors k2 is no more than a quarter longer than cols = k1 + m k2 (donor-level factors of full rank).
+    bool kin_fold = false;
+    long kin_kdim = 0;                          // k1 + kin_groups * k2, padded to whole stages of the contraction
+    crm::DevBuf MixK[crm::CRM_MAX_RHO];        // [kin_kdim x ldq]
     // shared donor tables, most recently used first (at most DT_CACHE entries)
     static constexpr int DT_CACHE = 2;
     std::vector<crm_donor_tables*> dt_cache;
@@ -87,6 +96,7 @@ struct crm_gene {
     // features of the (possibly row-permuted) contexts, rebuilt per scan call
     crm::DevBuf Ep, YE, EE, idx;
     crm::DevBuf kinEp;    // the (permuted) contexts in the donor order of the background's kinship structure
+    crm::DevBuf kinP;     // pair products E1_a o E0_i of the folded kinship-structure form (E1 rows of step 6)
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
     unsigned long e0_key = 0;    // content hash of E0 (key of the background's shared donor tables)

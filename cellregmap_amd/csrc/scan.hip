@@ -36,6 +36,12 @@ static unsigned long content_key(const void* data, size_t bytes, unsigned long s
 
 static int pick_split(long cells_pad, long blocks_without_split) { return split_for(cells_pad, blocks_without_split); }
 
+static int ctx_cus(const crm_ctx* ctx) {
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+    return cus;
+}
+
 // flags[0] |= any non-finite entry; flags[1] |= any cell differing from its group's representative
 __global__ void verify_panel_kernel(const double* __restrict__ G, long ld, long p, const int* __restrict__ group,
                                     const long* __restrict__ rep, int* __restrict__ flags) {
@@ -117,6 +123,7 @@ void crm_background_destroy(crm_background* bg) {
     bg->kin_map.release();
     bg->kin_Y.release();
     bg->kin_hKd.release();
+    for (int i = 0; i < CRM_MAX_RHO; i++) bg->MixK[i].release();
     for (crm_donor_tables* t : bg->dt_cache) {
         t->release();
         delete t;
@@ -202,6 +209,45 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
         set_error("kinship groups: the half factor of this background is not U[c, j] * hKd[group(c), d] (largest difference "
                   "%.3g against entries up to %.3g)", dmax, hmax);
         return CRM_ERR_ARG;
+    }
+    // Fold the donor-level factor into the mixing matrices (objects.h: kin_fold) -- one small product per (grid point, j):
+    // MixK[k1 + d' k2 + j, :] = sum_d hKd[d', d] Mix[k1 + j m + d, :], the contraction over d in stages of 16 rows (the
+    // rows of hKd' beyond m are zero; the rows of Mix they meet belong to the next j or to Mix's own zero padding, which
+    // must exist: cols + padding <= ldh).
+    bg->kin_fold = false;
+    const long kfold = k1 + groups * (long)k2, m_pad = round_up(m, GEMM_BK);
+    const char* fold_env = getenv("CRM_KIN_FOLD");
+    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && !(fold_env && atoi(fold_env) == 0)) {
+        const long kdim = round_up(kfold, GEMM_BK), ldq = bg->ldq, ld_t = round_up(groups, 128);
+        ScopedBuf hKdT, probs_dev;
+        CRM_TRY(hKdT.ensure(sizeof(double) * m_pad * ld_t));
+        {
+            std::vector<double> t((size_t)m_pad * ld_t, 0.0);
+            for (long dd = 0; dd < groups; dd++)
+                for (long d = 0; d < m; d++) t[(size_t)d * ld_t + dd] = hKd[dd * m + d];
+            CRM_HIP(hipMemcpyAsync(hKdT.ptr, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, st));
+            CRM_HIP(hipStreamSynchronize(st));
+        }
+        std::vector<GemmProblem> pr((size_t)bg->nrho * k2);
+        for (int i = 0; i < bg->nrho; i++) {
+            CRM_TRY(bg->MixK[i].ensure(sizeof(double) * kdim * ldq));
+            CRM_HIP(hipMemsetAsync(bg->MixK[i].ptr, 0, sizeof(double) * kdim * ldq, st));
+            CRM_HIP(hipMemcpyAsync(bg->MixK[i].ptr, bg->Mix[i].ptr, sizeof(double) * (size_t)k1 * ldq, hipMemcpyDeviceToDevice, st));
+            for (int j = 0; j < k2; j++) {
+                GemmProblem p{};
+                p.X = hKdT.as<double>(); p.ldx = ld_t;
+                p.Y = bg->Mix[i].as<double>() + (size_t)(k1 + (long)j * m) * ldq; p.ldy = ldq;
+                p.C = bg->MixK[i].as<double>() + (size_t)(k1 + j) * ldq; p.ldc = (long)k2 * ldq;
+                p.M = (int)groups; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+                pr[(size_t)i * k2 + j] = p;
+            }
+        }
+        CRM_TRY(probs_dev.ensure(sizeof(GemmProblem) * pr.size()));
+        CRM_HIP(hipMemcpyAsync(probs_dev.ptr, pr.data(), sizeof(GemmProblem) * pr.size(), hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(ctx, probs_dev.as<GemmProblem>(), (int)pr.size(), (int)groups, (int)ldq, m_pad, false, 0, 1, 0));
+        CRM_HIP(hipStreamSynchronize(st));
+        bg->kin_kdim = kdim;
+        bg->kin_fold = true;
     }
     bg->kin = true;
     return CRM_OK;
@@ -449,7 +495,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->Wproj, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
-                    &g->dt_Zt, &g->kinEp})
+                    &g->dt_Zt, &g->kinEp, &g->kinP})
         b->release();
     delete g;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
@@ -1026,7 +1072,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // H'G of step 3: few output tiles (cols x block) against a long contraction (cells) -- slices along the cell axis
     // until the launch fills the chip twice with 128-wide tiles (mode B at config 3: 64 tiles, cfg3 mode C: 320)
     int ks_h = 1;
-    const long th_slab = (long)bg->ldh * ldb;
+    // (rows of the operand of the rotations' Mix products: the half factor's columns, or -- folded kinship structure,
+    // objects.h: kin_fold -- k1 + donors k2)
+    const long th_slab = std::max<long>(bg->ldh, bg->kin && bg->kin_fold ? bg->kin_kdim : 0) * ldb;
     if (bg->fast_T) {
         const long tiles_h = (long)((bg->cols + GEMM_BM - 1) / GEMM_BM) * ((BLK + 127) / 128);
         while (tiles_h * ks_h < 1024 && ks_h < 16 && np / GEMM_BK / (ks_h + 1) >= 16) ks_h++;
@@ -1067,7 +1115,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     double* d_thr = (double*)(sm + o_thr);           // the reference's rank rule as a bound on |gx|^2
     int* d_drop = (int*)(sm + o_drop);               // 1: the variant's direction is dropped from [W, g]
     int* d_near = (int*)(sm + o_near);               // collapsed path: 1 = repeat this variant on the dense path
-    const int kin_probs = bg->kin ? bg->kin_groups + bg->kin_k2 : 0;
+    const int kin_probs = bg->kin ? bg->kin_groups + bg->kin_k2 + 16 : 0;
     CRM_TRY(ctx->ws_probs.ensure(sizeof(GemmProblem) * (2 * CRM_MAX_RHO + 4 + kin_probs + ng)));
     GemmProblem* d_probs = ctx->ws_probs.as<GemmProblem>();
 
@@ -1089,14 +1137,50 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // Kinship-structure route (objects.h, crm_background::kin): H'(g o E0) donor by donor, then Mix(rho*)' -- the dense
     // scan's default whenever the background knows the donor structure of its kinship factor.  S: per-donor sums.
     const int KK = bg->kin ? bg->kin_k1 + bg->kin_k2 : 0;   // rows of S per donor: [us | E1]
-    const size_t s_bytes = bg->kin ? sizeof(double) * (size_t)bg->kin_groups_pad * KK * ld_ah : 0;
+    // folded form (objects.h: kin_fold): S holds [E1 rows ; (donor, us_j) rows] and is the operand of the Mix product itself
+    const bool fold = bg->kin && bg->kin_fold;
+    const size_t s_bytes = !bg->kin ? 0 : sizeof(double) * (fold ? (size_t)bg->kin_kdim : (size_t)bg->kin_groups_pad * KK) * ld_ah;
     const bool kin_route = bg->kin && bg->fast_T && ctx->fast_T && !collapsed && ctx->kin_route && s_bytes <= ((size_t)48 << 30);
-    if (bg->fast_T && ctx->fast_T && (ng > 1 || kin_route) && !collapsed) {  // operands of the routes through H (step 6)
-        CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
-        if (ng > 1) CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)bg->ldh * ld_xg));
-        CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
+    const bool kfold = kin_route && fold;
+    const long kdim = kfold ? bg->kin_kdim : bg->ldh;       // contraction length of the products with the mixing matrices
+    // cell-axis slices of the folded form's all-cells launches for the E1 rows (few output tiles, long contraction)
+    int fold_split6 = 1, fold_split3 = 1;
+    // E1 rows of step 6: as a plain product G'P with the pair products P = E1_a o E0_i (n x k1 k0; the contraction kernel's
+    // best form) followed by a re-ordering of its rows, unless P would be large (> 8 GB): then as a Khatri-Rao contraction
+    // over all cells with the transposed store (64-wide tiles when k1 <= 64: 50 of 64 columns at config 3)
+    const long ldP = round_up((long)(bg->kin ? bg->kin_k1 : 0) * k0, 128);
+    const bool e1_pairs = kfold && sizeof(double) * (double)np * (double)ldP <= 8.0 * (1ull << 30) && !getenv("CRM_KIN_E1_KR");
+    if (kfold) {
+        const long tiles6 = e1_pairs ? ((long)BLK + GEMM_BM - 1) / GEMM_BM * (ldP / 128) : ((long)BLK * k0 + GEMM_BM - 1) / GEMM_BM;
+        const long slots6 = e1_pairs || bg->kin_k1 > 64 ? 512 : 768;
+        double best = 0.0;
+        for (int sps = 1; sps <= 8 && np / GEMM_BK / sps >= 64; sps++) {
+            const double rounds = (double)(tiles6 * sps) / (double)slots6, eff = rounds / std::ceil(rounds);
+            if (eff > best + 0.02) { best = eff; fold_split6 = sps; }
+        }
+        const long tiles3 = (long)((bg->kin_k1 + GEMM_BM - 1) / GEMM_BM) * ((BLK + 127) / 128);
+        while (tiles3 * fold_split3 < 1024 && fold_split3 < 16 && np / GEMM_BK / (fold_split3 + 1) >= 16) fold_split3++;
     }
-    if (kin_route) {
+    if (bg->fast_T && ctx->fast_T && (ng > 1 || kin_route) && !collapsed) {  // operands of the routes through H (step 6)
+        if (kfold) {
+            // (scratch of the sliced all-cells launch for the E1 rows)
+            CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)fold_split6 *
+                                      (e1_pairs ? (size_t)(std::max<long>(BLK, max_pairs) + 128) * ldP : (size_t)bg->kin_k1 * ld_ah)));
+        } else {
+            CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
+            CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
+        }
+        if (ng > 1) CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)kdim * ld_xg));
+    }
+    if (kfold) {
+        CRM_TRY(ctx->ws_S.ensure(s_bytes));
+        CRM_TRY(ctx->ws_Gk.ensure(sizeof(double) * (size_t)bg->kin_rows * std::max(ldb, ldp)));
+        CRM_TRY(ctx->ws_S2.ensure(sizeof(double) * (size_t)fold_split3 * bg->kin_k1 * ldb));
+        // rows between k1 + donors k2 and the padded contraction length stay zero
+        const long used = bg->kin_k1 + bg->kin_groups * (long)bg->kin_k2;
+        if (kdim > used)
+            CRM_HIP(hipMemsetAsync(ctx->ws_S.as<double>() + (size_t)used * ld_ah, 0, sizeof(double) * (size_t)(kdim - used) * ld_ah, st));
+    } else if (kin_route) {
         CRM_TRY(ctx->ws_S.ensure(s_bytes));
         CRM_TRY(ctx->ws_Gk.ensure(sizeof(double) * (size_t)bg->kin_rows * std::max(ldb, ldp)));
         CRM_TRY(ctx->ws_S2.ensure(sizeof(double) * (size_t)bg->kin_groups_pad * KK * ldb));
@@ -1167,6 +1251,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_TRY(launch_gather_rows(st, d_Ep, g0->ld_ep, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ep,
                                    g0->kinEp.as<double>(), g0->ld_ep));
     }
+    if (e1_pairs) {
+        CRM_TRY(g0->kinP.ensure(sizeof(double) * (size_t)np * ldP));
+        CRM_TRY(launch_pair_features(st, bg->H.as<double>(), bg->ldh, bg->kin_k1, d_Ep, g0->ld_ep, k0, np, g0->kinP.as<double>(), ldP));
+    }
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit((size_t)BLK * ng);
     std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
@@ -1224,7 +1312,40 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         //    flops per variant instead of 2 n sum r.
         const bool fastT = !collapsed && bg->fast_T && ctx->fast_T;
         if (!fastT && !collapsed) CRM_TRY(crm_background_require_q0(bg, -1));
-        if (fastT && kin_route) {
+        if (fastT && kfold) {
+            // folded form: rows [0, k1) = E1'G over all cells (sliced along the cell axis), rows k1 + d' k2 + j = per-donor
+            // us_j'G over the donor's own cells; the contraction over the donors sits in MixK (objects.h)
+            double* Gk = ctx->ws_Gk.as<double>();
+            double* TH = ctx->ws_TH.as<double>();
+            const int k1 = bg->kin_k1, k2 = bg->kin_k2;
+            const long groups = bg->kin_groups;
+            CRM_TRY(launch_gather_rows(st, Gx, ldb, bg->kin_map.as<int>(), bg->kin_rows, (int)ldb, Gk, ldb));
+            std::vector<GemmProblem> kp((size_t)groups + 1);
+            long maxlen = GEMM_BK;
+            for (long d = 0; d < groups; d++) {
+                GemmProblem p{};
+                p.X = bg->kin_Y.as<double>() + bg->kin_row0[d] * bg->kin_ldy; p.ldx = bg->kin_ldy;
+                p.Y = Gk + bg->kin_row0[d] * ldb; p.ldy = ldb;
+                p.C = TH + (size_t)(k1 + d * k2) * ldb; p.ldc = ldb;
+                p.M = k2; p.N = nb; p.cells = bg->kin_len[d];
+                maxlen = std::max(maxlen, bg->kin_len[d]);
+                kp[d] = p;
+            }
+            {
+                GemmProblem p{};
+                p.X = bg->H.as<double>(); p.ldx = bg->ldh; p.Y = Gx; p.ldy = ldb;
+                p.C = ctx->ws_S2.as<double>(); p.ldc = ldb; p.M = k1; p.N = nb;
+                kp[groups] = p;
+            }
+            GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+            CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * kp.size(), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, k2, nb, maxlen, false, 0, 1, 0));
+            const long e1_slab = (long)k1 * ldb;
+            CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, k1, nb, np, false, 0, fold_split3, e1_slab));
+            CRM_TRY(launch_reduce_splits(st, ctx->ws_S2.as<double>(), e1_slab, fold_split3, e1_slab));
+            CRM_HIP(hipMemcpyAsync(TH, ctx->ws_S2.ptr, sizeof(double) * (size_t)e1_slab, hipMemcpyDeviceToDevice, st));
+            CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+        } else if (fastT && kin_route) {
             // H'G donor by donor (as H'(g o E0) in step 6): per donor [us | E1]' G over its own cells, then the L rows by a
             // contraction over the donors with hKd and the E1 rows as sums over the donors
             double* Gk = ctx->ws_Gk.as<double>();
@@ -1269,7 +1390,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             GemmProblem p{};
             if (fastT) {
                 p.X = ctx->ws_TH.as<double>(); p.ldx = ldb;
-                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+                p.Y = kfold ? bg->MixK[i].as<double>() : bg->Mix[i].as<double>(); p.ldy = ldq;
             } else {
                 p.X = Gx; p.ldx = ldb;
                 p.Y = collapsed ? tab->TZ.as<double>() + (size_t)i * mp * ldq : bg->Q0[i].as<double>(); p.ldy = ldq;
@@ -1278,8 +1399,56 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             p.M = nb; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
             probs[i] = p;
         }
-        CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, nrho, nb, (int)ldq, fastT ? bg->ldh : xrows, false, 0, 1, 0));
+        // The eleven products run as one launch of equally long tiles, i.e. in rounds of as many tiles as the chip holds
+        // workgroups (two per CU): at config 3, 12 832 tiles are 25.06 rounds of 512 and the last 0.06 costs a whole one.
+        // The smallest problems that make up that remainder (there: rho = 1, r = 50, 32 tiles) are taken out and run cut
+        // along the contraction axis instead -- a sixteenth of a round plus a reduction.
+        int n_main = nrho, n_cut = 0;
+        int cut_ks = 1;
+        GemmProblem cut_probs[CRM_MAX_RHO];
+        double* cut_dst[CRM_MAX_RHO];
+        if (fastT && !getenv("CRM_ROT_NO_CUT")) {
+            const long slots = 2L * ctx_cus(ctx), mtl = (nb + GEMM_BM - 1) / GEMM_BM;
+            long tiles[CRM_MAX_RHO], total = 0;
+            int order[CRM_MAX_RHO];
+            for (int i = 0; i < nrho; i++) { tiles[i] = mtl * ((probs[i].N + 127) / 128); total += tiles[i]; order[i] = i; }
+            std::sort(order, order + nrho, [&](int a, int b) { return tiles[a] < tiles[b]; });
+            const long need = total % slots;
+            long acc = 0;
+            int take = 0;
+            while (take < nrho - 1 && acc < need) acc += tiles[order[take++]];
+            if (total > slots && need > 0 && acc >= need && acc <= slots / 4) {
+                bool is_cut[CRM_MAX_RHO] = {false};
+                long cut_doubles = 0;
+                for (int q = 0; q < take; q++) is_cut[order[q]] = true;
+                while ((long)(cut_ks + 1) * acc <= slots && cut_ks < 16 && kdim / GEMM_BK / (cut_ks + 1) >= 8) cut_ks++;
+                n_main = 0;
+                for (int i = 0; i < nrho; i++) {
+                    if (!is_cut[i]) { probs[n_main++] = probs[i]; continue; }
+                    GemmProblem c = probs[i];
+                    cut_dst[n_cut] = c.C;
+                    c.ldc = round_up(c.N, 128);
+                    cut_doubles += (long)BLK * c.ldc;
+                    cut_probs[n_cut++] = c;
+                }
+                CRM_TRY(ctx->ws_Tcut.ensure(sizeof(double) * (size_t)cut_doubles * cut_ks));
+                long at = 0;
+                for (int q = 0; q < n_cut; q++) {
+                    cut_probs[q].C = ctx->ws_Tcut.as<double>() + at;
+                    at += (long)BLK * cut_probs[q].ldc;
+                }
+                CRM_HIP(hipMemcpyAsync(d_probs + 1 + nrho, cut_probs, sizeof(GemmProblem) * n_cut, hipMemcpyHostToDevice, st));
+                int cut_maxn = 1;
+                for (int q = 0; q < n_cut; q++) cut_maxn = std::max(cut_maxn, cut_probs[q].N);
+                CRM_TRY(launch_gemm_tn(ctx, d_probs + 1 + nrho, n_cut, nb, cut_maxn, kdim, false, 0, cut_ks, cut_doubles));
+                CRM_TRY(launch_reduce_splits(st, ctx->ws_Tcut.as<double>(), cut_doubles, cut_ks, cut_doubles));
+                for (int q = 0; q < n_cut; q++)
+                    CRM_HIP(hipMemcpy2DAsync(cut_dst[q], sizeof(double) * ldT, cut_probs[q].C, sizeof(double) * cut_probs[q].ldc,
+                                             sizeof(double) * cut_probs[q].N, nb, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * n_main, hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, n_main, nb, (int)ldq, fastT ? kdim : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
         trace_push("crm null fits");
         for (int gi = 0; gi < ng; gi++) {
@@ -1425,18 +1594,20 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.Y = tab->Bd.as<double>() + (size_t)i * mp * k0 * ldq; p.ldy = (long)k0 * ldq;
                 p.ldc = (long)k0 * ldA;
                 p.M = cnt[i]; p.N = (int)((long)k0 * ldq);
-            } else if (via_H && kin_route && ng == 1) {   // (AH is in pair order already, see below)
-                p.X = ctx->ws_AH.as<double>() + (size_t)start[i] * k0; p.ldx = ld_ah;
-                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+            } else if (via_H && kin_route && ng == 1) {   // (AH / S is in pair order already, see below)
+                p.X = (kfold ? ctx->ws_S.as<double>() : ctx->ws_AH.as<double>()) + (size_t)start[i] * k0; p.ldx = ld_ah;
+                p.Y = kfold ? bg->MixK[i].as<double>() : bg->Mix[i].as<double>(); p.ldy = ldq;
                 p.ldc = ldA;
                 p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-                kr_flops += 2.0 * (double)bg->cols * (double)bg->r[i] * (double)k0 * (double)cnt[i];
+                kr_flops += 2.0 * (double)(kfold ? bg->kin_k1 + bg->kin_groups * (long)bg->kin_k2 : bg->cols) * (double)bg->r[i] *
+                            (double)k0 * (double)cnt[i];
             } else if (via_H) {
                 p.X = ctx->ws_XG.as<double>() + (size_t)start[i] * k0; p.ldx = ld_xg;
-                p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+                p.Y = kfold ? bg->MixK[i].as<double>() : bg->Mix[i].as<double>(); p.ldy = ldq;
                 p.ldc = ldA;
                 p.M = cnt[i] * k0; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-                kr_flops += 2.0 * (double)bg->ldh * (double)bg->r[i] * (double)k0 * (double)cnt[i];
+                kr_flops += 2.0 * (double)(kfold ? bg->kin_k1 + bg->kin_groups * (long)bg->kin_k2 : bg->cols) * (double)bg->r[i] *
+                            (double)k0 * (double)cnt[i];
             } else {
                 p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;
                 p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
@@ -1467,7 +1638,77 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             if (!kin_route) CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
         double kin_prep_flops = 0.0;
-        if (via_H && kin_route) {
+        if (via_H && kfold) {
+            // Folded form (objects.h: kin_fold): S = [E1 rows ; (donor, us_j) rows] of "H'(g o E0) before the contraction over
+            // the donors", which MixK carries.  (a) the block in donor order; (b) per donor d' the Khatri-Rao contraction over
+            // its own cells against us (transposed store into rows k1 + d' k2 + j); (c) the E1 rows by one Khatri-Rao
+            // contraction over ALL cells against the E1 columns of the half factor, cut into slices along the cell axis so
+            // that its few output tiles fill the chip, summed, and copied into rows [0, k1).
+            double* Gk = ctx->ws_Gk.as<double>();
+            double* S = ctx->ws_S.as<double>();
+            const int k1 = bg->kin_k1, k2 = bg->kin_k2;
+            const long groups = bg->kin_groups;
+            const bool in_pair_order = ng == 1;
+            const double* Gsrc = in_pair_order ? Gs : Gt;
+            const long ldg_k = in_pair_order ? ldp : ldb;
+            const int ncol = in_pair_order ? npairs : nb;
+            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, (int)ldg_k, Gk, ldg_k));
+            std::vector<GemmProblem> kp((size_t)groups + fold_split6);
+            long maxlen = GEMM_BK;
+            for (long d = 0; d < groups; d++) {
+                GemmProblem p{};
+                p.X = Gk + bg->kin_row0[d] * ldg_k; p.ldx = ldg_k;
+                p.E = g0->kinEp.as<double>() + bg->kin_row0[d] * g0->ld_ep; p.lde = g0->ld_ep; p.k0 = k0;
+                p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * bg->kin_ldy; p.ldy = bg->kin_ldy;
+                p.C = S + (size_t)(k1 + d * k2) * ld_ah; p.ldc = ld_ah;
+                p.M = ncol * k0; p.N = k2; p.cells = bg->kin_len[d];
+                maxlen = std::max(maxlen, bg->kin_len[d]);
+                kp[d] = p;
+            }
+            // slices of whole stages along the cell axis, the last one shorter
+            const long stages_all = np / GEMM_BK, per = (stages_all + fold_split6 - 1) / fold_split6;
+            const long e1_slab = (long)k1 * ld_ah;
+            int slices = 0;
+            long chunk_max = GEMM_BK;
+            if (e1_pairs) {
+                GemmProblem p{};
+                p.X = Gsrc; p.ldx = ldg_k; p.Y = g0->kinP.as<double>(); p.ldy = ldP;
+                p.C = ctx->ws_AH.as<double>(); p.ldc = ldP; p.M = ncol; p.N = k1 * k0;
+                kp[groups] = p;
+            }
+            for (int sps = 0; sps < fold_split6 && !e1_pairs; sps++) {
+                const long s0 = sps * per, s1 = std::min(stages_all, s0 + per);
+                if (s1 <= s0) break;
+                GemmProblem p{};
+                p.X = Gsrc + s0 * GEMM_BK * ldg_k; p.ldx = ldg_k;
+                p.E = d_Ep + s0 * GEMM_BK * g0->ld_ep; p.lde = g0->ld_ep; p.k0 = k0;
+                p.Y = bg->H.as<double>() + s0 * GEMM_BK * bg->ldh; p.ldy = bg->ldh;
+                p.C = ctx->ws_AH.as<double>() + (size_t)sps * e1_slab; p.ldc = ld_ah;
+                p.M = ncol * k0; p.N = k1; p.cells = (s1 - s0) * GEMM_BK;
+                chunk_max = std::max(chunk_max, p.cells);
+                kp[groups + slices++] = p;
+            }
+            GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+            CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * (size_t)(groups + std::max(slices, 1)), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, k2, maxlen, k0));
+            if (e1_pairs) {
+                const long p_slab = (long)(std::max<long>(BLK, max_pairs) + 128) * ldP;
+                CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, ncol, k1 * k0, np, false, 0, fold_split6, p_slab));
+                CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), (long)ncol * ldP, fold_split6, p_slab));
+                CRM_TRY(launch_pair_rows(st, ctx->ws_AH.as<double>(), ldP, ncol, k1, k0, S, ld_ah));
+            } else {
+                CRM_TRY(launch_kr_transposed(ctx, d_kp + groups, slices, ncol * k0, k1, chunk_max, k0));
+                CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), e1_slab, slices, e1_slab));
+                CRM_HIP(hipMemcpyAsync(S, ctx->ws_AH.ptr, sizeof(double) * (size_t)e1_slab, hipMemcpyDeviceToDevice, st));
+            }
+            kin_prep_flops = 2.0 * (double)bg->kin_rows * k2 * (double)k0 * ncol + 2.0 * (double)np * k1 * (double)k0 * ncol;
+            (void)kin_prep_flops;
+            if (!in_pair_order) {
+                const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
+                CRM_TRY(launch_gather_slabs(st, S, ld_ah, kdim, d_ord, npairs, k0, ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+            }
+            CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+        } else if (via_H && kin_route) {
             // AH = H'(g o E0) without an n-length contraction against the cols columns of H:
             // (a) the block in donor order; (b) per donor d' the Khatri-Rao contraction over its own cells against
             // [us | E1] (transposed store: S[(d' KK + q), (b, i)]); (c) the L rows: for every j a contraction over the
@@ -1537,9 +1778,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             if (timing) CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
             struct Restore { crm_ctx* c; ~Restore() { c->tune.tag = 0; } } restore{ctx};
             ctx->tune.tag = 1;
-            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, kdim, false, 0, 1, 0));
         } else if (via_H)
-            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, bg->ldh, false, 0, 1, 0));
+            CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, kdim, false, 0, 1, 0));
         else {
             CRM_TRY(launch_gemm_tn(ctx, d_probs, nz, max_m, max_n, np, true, k0, kr_split, (long)a_slab));
             CRM_TRY(launch_reduce_splits(st, ctx->ws_A.as<double>(), (long)npairs * k0 * ldA, kr_split, (long)a_slab));
