@@ -235,7 +235,9 @@ def main():
     # ---- synthetic data (not timed): the cohort, this rank's shard of the config's fixed panel, and -- when
     #      that shard is shorter than a few batches -- a panel of its own for the weak-scaling steps
     t0 = time.time()
-    cohort = make_cohort(donors, cells, k0, 16, seed=20)  # phenotype, contexts, kinship factor
+    # phenotype, contexts, kinship factor (U sqrt(S) of the donor-block K as the reference's simulator forms it: a dense
+    # donor-expanded n x m factor; SURVEY.md 8d, cellregmap_amd/synth.py: kinship_factor)
+    cohort = make_cohort(donors, cells, k0, 16, seed=20, kinship="rotated")
     f_first, f_count = variant_shard(p_total, rank, world)
     G_full = None
     if args.full_panel:
@@ -582,6 +584,8 @@ def main():
                 config4["oracle_check"] = c4_check
         cpu = {
             "value": round(m / t_cpu, 4), "unit": "variant-tests/s", "cores": int(nthreads), "kind": "port",
+            "cores_note": ("threads of the host BLAS as this run used them: OpenBLAS caps its pool (64 in this image) below "
+                           "the host's %d logical cpus" % (os.cpu_count() or 0)),
             "sample": f"{m} variants drawn at random (seed 2024) from the {min(steps, weak_blocks) * batch} this run scanned, "
                       f"median of {len(times)} repeats ({', '.join('%.1f s' % t for t in times)}); scan only (decomposition "
                       f"shared with the GPU run); host has {os.cpu_count()} logical cpus",

@@ -6,6 +6,7 @@ numerical happens in the HIP library through the C-ABI of ``include/crm_hip.h``.
 There is no CPU path here: without the library or without a GPU, calls raise.
 """
 import ctypes
+import threading
 import hashlib
 import weakref
 from collections import OrderedDict
@@ -172,8 +173,16 @@ def _announce_kinship_groups(bg, halves):
         return
     group, hKd = found
     us = _lib.f64(us)
-    _lib.check(_lib.load().crm_background_set_kinship_groups(bg.handle, _lib.ptr(group), hKd.shape[0], _lib.ptr(hKd),
-                                                             hKd.shape[1], _lib.ptr(us), us.shape[1]))
+    rc = _lib.load().crm_background_set_kinship_groups(bg.handle, _lib.ptr(group), hKd.shape[0], _lib.ptr(hKd),
+                                                       hKd.shape[1], _lib.ptr(us), us.shape[1])
+    if rc != 0:
+        # The announcement is an optimisation: a structure the library refuses (or scratch memory it cannot get) leaves the
+        # background as it is, scanning by the direct route (include/crm_hip.h).  Say so, do not fail the constructor.
+        import warnings
+
+        msg = _lib.load().crm_last_error()
+        warnings.warn("kinship structure not used (libcrm_hip status %d: %s); scans take the direct route"
+                      % (rc, msg.decode() if msg else ""), RuntimeWarning, stacklevel=3)
 
 
 def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
@@ -493,7 +502,7 @@ def _release_gene(lib, handle, _background_kept_alive):
 _PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
 
 
-_progress_stack = {}   # device -> callbacks installed by the scans in flight (innermost last)
+_progress_stack = {}   # (device, thread) -> callbacks installed by the scans in flight on that thread (innermost last)
 
 
 def _progress_default():
@@ -545,13 +554,14 @@ class _progress:
                     except BaseException as exc:  # noqa: BLE001 -- re-raised in __exit__
                         self.error = exc
         self._cb = _PROGRESS_CB(cb)   # (kept alive until __exit__)
-        _progress_stack.setdefault(self.device, []).append(self._cb)
+        self._key = (self.device, threading.get_ident())   # (the library keeps one callback per calling thread)
+        _progress_stack.setdefault(self._key, []).append(self._cb)
         _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), ctypes.cast(self._cb, ctypes.c_void_p), None))
         return self
 
     def __exit__(self, *exc):
         if self.progress:
-            stack = _progress_stack[self.device]
+            stack = _progress_stack[self._key]
             stack.remove(self._cb)
             outer = ctypes.cast(stack[-1], ctypes.c_void_p) if stack else None
             _lib.check(_lib.load().crm_set_progress_callback(_context(self.device), outer, None))

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <mutex>
 
+#include <map>
+
 #include "crm_internal.h"
 #include "eigh.h"
 
@@ -80,6 +82,23 @@ static void check_redzone(const void* ptr, size_t bytes) {
     }
 }
 
+// The fill of a fresh allocation runs on a stream of the library's own (non-blocking, one per device) and only that
+// stream is waited for: on the legacy null stream every allocation would be an ordering point for all blocking streams of
+// the process (torch's default stream among them).
+static hipStream_t fill_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(dev);
+    if (it != streams.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;   // (null stream as a last resort)
+    streams[dev] = st;
+    return st;
+}
+
 int DevBuf::ensure(size_t need) {
     if (need <= bytes) return CRM_OK;
     if (ptr) {
@@ -107,8 +126,9 @@ int DevBuf::ensure(size_t need) {
     // Fresh allocations never carry the previous tenant's bytes into a kernel: they are zero-filled (poison mode: 0xFF,
     // above).  The fill runs on the null stream and is waited for here: the contexts' streams are non-blocking and would
     // not order themselves behind it.
-    CRM_HIP(hipMemsetAsync(ptr, poison_mode() ? 0xFF : 0, total, nullptr));
-    CRM_HIP(hipStreamSynchronize(nullptr));
+    hipStream_t fs = fill_stream();
+    CRM_HIP(hipMemsetAsync(ptr, poison_mode() ? 0xFF : 0, total, fs));
+    CRM_HIP(hipStreamSynchronize(fs));
     return CRM_OK;
 }
 
@@ -188,7 +208,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
     if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
     if (const char* e = getenv("CRM_FAST_GENE_ROTATION")) c->fast_gene_rot = atoi(e) != 0;
-    if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = atoi(e) != 0;
+    if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("CRM_TILE_BAND")) c->tune.band = atoi(e) > 1 ? atoi(e) : 0;   // (0 or 1: column tile of X first, the walk before round 3)
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
@@ -269,8 +289,8 @@ int crm_set_null_fit_polish(crm_ctx* c, int on) {
 int crm_set_progress_callback(crm_ctx* c, void (*callback)(long, long, void*), void* user) {
     return crm::guarded_on("crm_set_progress_callback", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
-    c->progress = callback;
-    c->progress_user = user;
+    if (callback) c->progress[std::this_thread::get_id()] = crm_ctx::Progress{callback, user};
+    else c->progress.erase(std::this_thread::get_id());
     return CRM_OK;
     });
 }
@@ -339,7 +359,7 @@ long crm_test_overruns(void) { return crm::overruns_detected(); }
 int crm_test_set_kinship_route(crm_ctx* c, int on) {
     return crm::guarded_on("crm_test_set_kinship_route", c, [&]() -> int {
     if (!c) return CRM_ERR_ARG;
-    c->kin_route = on != 0;
+    c->kin_route = on < 0 ? 0 : (on > 2 ? 2 : on);
     return CRM_OK;
     });
 }

@@ -163,7 +163,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
         if (out_pvalue) CRM_HIP(hipMemcpyAsync(out_pvalue + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
         if (out_alt_lml) CRM_HIP(hipMemcpyAsync(out_alt_lml + done, d_lml, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
         CRM_HIP(hipStreamSynchronize(st));
-        if (ctx->progress) ctx->progress(done + nb, count, ctx->progress_user);   // (the reference's tqdm, :270)
+        ctx->report(done + nb, count);   // (the reference's tqdm, :270)
     }
     return CRM_OK;
     });

@@ -1,6 +1,8 @@
 // Internal object layouts behind the opaque C-ABI handles.
 #pragma once
+#include <map>
 #include <mutex>
+#include <thread>
 #include <utility>
 
 #include "crm_common.h"
@@ -62,11 +64,20 @@ struct crm_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them
-    bool kin_route = true;      // H'(g o E0) donor by donor when the background knows its kinship structure (CRM_KIN_ROUTE=0)
+    int kin_route = 1;          // H'(g o E0) donor by donor when the background knows its kinship structure: 0 never
+                                // (CRM_KIN_ROUTE=0), 1 when its flop count pays (scan.hip), 2 always
     bool fast_gene_rot = true;  // Q0(rho)'[y, W] of a gene through the mixing matrices as well (else against Q0 itself)
     bool collapse = true;  // use the donor-collapsed path for grouped panels
-    void (*progress)(long done, long total, void* user) = nullptr;  // called after every block of a scan
-    void* progress_user = nullptr;
+    // Progress callbacks, one per calling thread (crm_set_progress_callback installs it for the thread that calls it; a
+    // scan reports to the callback of the thread it runs on): two threads scanning on one device each see their own bar.
+    struct Progress { void (*fn)(long done, long total, void* user) = nullptr; void* user = nullptr; };
+    std::map<std::thread::id, Progress> progress;
+    bool progress_muted = false;   // a scan's second (dense) pass over variants the first one already reported
+    void report(long done, long total) {   // (called with the context's lock held)
+        if (progress_muted) return;
+        auto it = progress.find(std::this_thread::get_id());
+        if (it != progress.end() && it->second.fn) it->second.fn(done, total, it->second.user);
+    }
     bool in_scan = false;  // a scan is running on this context (its work buffers are in use: no second one from a callback)
     bool polish = false;  // opt-in: refine the null-fit optimum beyond Brent's 1e-6 (nullfit.hip)
     bool probe_on = false;       // crm_test_null_fit_probe: scans stop after the null-fit kernels and keep the trial records

@@ -111,6 +111,7 @@ int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, 
 void crm_background_destroy(crm_background* bg) {
     try {
     if (!bg) return;
+    std::lock_guard<std::recursive_mutex> lock(bg->ctx->mu);   // (reachable from a finalizer on any thread)
     (void)hipSetDevice(bg->ctx->device);
     (void)hipStreamSynchronize(bg->ctx->stream);
     for (int i = 0; i < CRM_MAX_RHO; i++) {
@@ -254,7 +255,15 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     });
 }
 
-int crm_background_kinship_groups(const crm_background* bg) { return (bg && bg->kin) ? (int)bg->kin_groups : 0; }
+int crm_background_kinship_groups(const crm_background* bg) {
+    if (!bg) return 0;
+    try {
+        std::lock_guard<std::recursive_mutex> lock(bg->ctx->mu);
+        return bg->kin ? (int)bg->kin_groups : 0;
+    } catch (...) {
+        return 0;
+    }
+}
 
 int crm_background_rank(const crm_background* bg, int i) {
     return crm::guarded_on("crm_background_rank", bg ? bg->ctx : nullptr, [&]() -> int {
@@ -491,6 +500,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
 void crm_gene_destroy(crm_gene* g) {
     try {
     if (!g) return;
+    std::lock_guard<std::recursive_mutex> lock(g->ctx->mu);   // (reachable from a finalizer on any thread)
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
@@ -527,6 +537,7 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
 void crm_panel_destroy(crm_panel* P) {
     try {
     if (!P) return;
+    std::lock_guard<std::recursive_mutex> lock(P->ctx->mu);   // (reachable from a finalizer on any thread)
     (void)hipSetDevice(P->ctx->device);
     (void)hipStreamSynchronize(P->ctx->stream);
     P->G.release();
@@ -1140,7 +1151,21 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // folded form (objects.h: kin_fold): S holds [E1 rows ; (donor, us_j) rows] and is the operand of the Mix product itself
     const bool fold = bg->kin && bg->kin_fold;
     const size_t s_bytes = !bg->kin ? 0 : sizeof(double) * (fold ? (size_t)bg->kin_kdim : (size_t)bg->kin_groups_pad * KK) * ld_ah;
-    const bool kin_route = bg->kin && bg->fast_T && ctx->fast_T && !collapsed && ctx->kin_route && s_bytes <= ((size_t)48 << 30);
+    // The route pays when its flops per variant -- per-donor sums over runs padded to whole 16-cell stages, the E1 rows /
+    // the contraction over the donors, and the product with the mixing matrix -- stay under the direct contraction's
+    // 2 n r k0 (thousands of tiny donors: every run is mostly padding); a multi-gene test that forces one of the other
+    // two routes (crm_test_set_shared_h 0 / 1) gets that route.
+    bool kin_pays = false;
+    if (bg->kin) {
+        double rbar = 1.0;
+        for (int i = 0; i < nrho; i++) rbar = std::max(rbar, (double)bg->r[i]);
+        const double kk = fold ? (double)bg->kin_kdim : (double)bg->ldh;
+        const double prep = fold ? 2.0 * bg->kin_rows * bg->kin_k2 + 2.0 * (double)np * bg->kin_k1
+                                 : 2.0 * bg->kin_rows * KK + 2.0 * (double)bg->kin_groups_pad * bg->kin_cols * bg->kin_k2;
+        kin_pays = prep + 2.0 * kk * rbar < 0.9 * 2.0 * (double)n * rbar || ctx->kin_route >= 2;
+    }
+    const bool kin_route = bg->kin && bg->fast_T && ctx->fast_T && !collapsed && ctx->kin_route > 0 && kin_pays &&
+                           !(ng > 1 && ctx->tune.shared_h >= 0) && s_bytes <= ((size_t)48 << 30);
     const bool kfold = kin_route && fold;
     const long kdim = kfold ? bg->kin_kdim : bg->ldh;       // contraction length of the products with the mixing matrices
     // cell-axis slices of the folded form's all-cells launches for the E1 rows (few output tiles, long contraction)
@@ -1903,7 +1928,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // the per-gene device buffers (Z1, Q, F, pv) are reused by the next gene
             CRM_HIP(hipStreamSynchronize(st));
         }
-        if (ctx->progress) ctx->progress(done + nb, count, ctx->progress_user);   // (the reference's tqdm, :340)
+        ctx->report(done + nb, count);   // (the reference's tqdm, :340)
     }
     return CRM_OK;
 }
@@ -1918,9 +1943,9 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     if (near.empty() || ctx->probe_on) return CRM_OK;
     const int k0 = genes[0]->k0;
     struct Quiet {   // (the repeated variants were reported as done by the first pass)
-        crm_ctx* c; void (*saved)(long, long, void*);
-        explicit Quiet(crm_ctx* c_) : c(c_), saved(c_->progress) { c->progress = nullptr; }
-        ~Quiet() { c->progress = saved; }
+        crm_ctx* c;
+        explicit Quiet(crm_ctx* c_) : c(c_) { c->progress_muted = true; }
+        ~Quiet() { c->progress_muted = false; }
     } quiet(ctx);
     ctx->dense_repeats += (long)near.size();
     for (size_t i = 0; i < near.size();) {

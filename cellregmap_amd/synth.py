@@ -53,8 +53,34 @@ def donor_genotypes(n_donors, n_variants, rng, maf_min=0.05, maf_max=0.45):
     return G, mafs
 
 
+def kinship_factor(donor_of_cell, n_donors, kind="indicator", seed=20):
+    """The kinship factor hK with hK hK' = K, K the donor-block relatedness matrix Z Z' / mean diag + 1e-8 I of the
+    reference's simulator (``sample_covariance_matrix`` + ``jitter``, _simulate.py:83-102) cut at sqrt(eps) like its
+    ``_symmetric_decomp`` (:477-479: ``economic_svd`` drops the jitter's n - m directions).
+
+    ``indicator``: hK = Z (donor indicators; Z Z' has unit diagonal) -- the sparse factor of that K.
+    ``rotated``: hK = U sqrt(S) as the reference forms it.  The m kept eigenvalues of K are the donors' cell counts
+    (+ 1e-8); for equal counts the eigenspace is degenerate and LAPACK returns some rotation of Z / sqrt(n_d) inside
+    it, so U sqrt(S) = Z D R with D = diag(sqrt(n_d + 1e-8) / sqrt(n_d)) and R orthogonal: a DENSE n x m factor whose
+    rows are constant within a donor.  R is drawn here from a seeded stream (the n x n decomposition itself is out of
+    reach at 20 000 cells; tests/test_synth_cpu.py checks this form against ``economic_svd`` of K at small n)."""
+    n = donor_of_cell.shape[0]
+    Z = np.zeros((n, n_donors))
+    Z[np.arange(n), donor_of_cell] = 1.0
+    if kind == "indicator":
+        return Z
+    if kind != "rotated":
+        raise ValueError(f"kinship factor {kind!r}: 'indicator' or 'rotated'")
+    counts = np.bincount(donor_of_cell, minlength=n_donors).astype(float)
+    R, _ = np.linalg.qr(np.random.default_rng(seed + 977).normal(size=(n_donors, n_donors)))
+    return Z @ (np.sqrt((counts + 1e-8) / counts)[:, None] * R)
+
+
 def make_cohort(n_donors, cells_per_donor, n_contexts, n_variants, seed=20,
-                g_causals=(5, 6), gxe_causals=(10, 11), with_phenotype=True, dtype=np.float64):
+                g_causals=(5, 6), gxe_causals=(10, 11), with_phenotype=True, dtype=np.float64, kinship="indicator",
+                components=None):
+    """``kinship``: see ``kinship_factor``.  ``components``: a dict that receives the phenotype's moment-normalised
+    parts (offset, y_g, y_gxe, y_k, y_e, y_n), as the reference's ``Simulation`` tuple exposes them."""
     rng = np.random.default_rng(seed)
     n = n_donors * cells_per_donor
     Gd, mafs = donor_genotypes(n_donors, n_variants, rng)
@@ -65,30 +91,38 @@ def make_cohort(n_donors, cells_per_donor, n_contexts, n_variants, seed=20,
     E = column_normalize(rng.normal(size=(n, n_contexts)))
     W = np.ones((n, 1))
     # donor-block kinship: K = Z Z' / mean diag + 1e-8 I ;  hK = U sqrt(S) (rank n_donors)
-    hK = np.zeros((n, n_donors))
-    hK[np.arange(n), donor_of_cell] = 1.0  # Z; Z Z' has unit diagonal already
+    hK = kinship_factor(donor_of_cell, n_donors, kinship, seed)
     var = variances()
     if not with_phenotype:
         return Cohort(None, W, E, G, hK, donor_of_cell, mafs, var)
-    y = np.full(n, 0.3)
+    offset = 0.3
+    parts = {"y_g": np.zeros(n), "y_gxe": np.zeros(n)}
     g_causals = [c for c in g_causals if c < n_variants]
     gxe_causals = [c for c in gxe_causals if c < n_variants]
     if g_causals:
         beta = rng.choice([1.0, -1.0], size=len(g_causals)) * np.sqrt(var["g"] / len(g_causals))
-        y += _moments(G[:, g_causals] @ beta, var["g"])
+        parts["y_g"] = _moments(G[:, g_causals] @ beta, var["g"])
     if gxe_causals:
         ygxe = np.zeros(n)
         for c in gxe_causals:
             alpha = rng.normal(size=n_contexts) * np.sqrt(var["gxe"] / len(gxe_causals))
             ygxe += G[:, c] * (E @ alpha)
-        y += _moments(ygxe, var["gxe"])
+        parts["y_gxe"] = _moments(ygxe, var["gxe"])
     # population-structure x context term: sum_i diag(E[:, i]) hK u_i
     yk = np.zeros(n)
     for i in range(n_contexts):
         yk += E[:, i] * (hK @ rng.normal(size=n_donors))
-    y += _moments(yk, var["k"])
-    y += _moments(E @ rng.normal(size=n_contexts), var["e"])
-    y += _moments(rng.normal(size=n), var["n"])
+    parts["y_k"] = _moments(yk, var["k"])
+    parts["y_e"] = _moments(E @ rng.normal(size=n_contexts), var["e"])
+    parts["y_n"] = _moments(rng.normal(size=n), var["n"])
+    # (the same order of additions as before the parts were kept: goldens built on y stay bit-identical)
+    y = np.full(n, offset)
+    for key in ("y_g", "y_gxe", "y_k", "y_e", "y_n"):
+        if key in ("y_g", "y_gxe") and not (g_causals if key == "y_g" else gxe_causals):
+            continue
+        y += parts[key]
+    if components is not None:
+        components.update(parts, offset=offset)
     return Cohort(y, W, E, G, hK, donor_of_cell, mafs, var)
 
 

@@ -14,8 +14,9 @@
  * stream + one set of work buffers.  Calls that touch one context -- directly or
  * through a background, gene or panel created on it -- are serialised by the
  * library (a lock per context), so handles may be used from several threads;
- * distinct contexts run concurrently.  Settings (crm_set_*) belong to the
- * context, not to the calling thread.
+ * distinct contexts run concurrently (the destroy entry points take the same
+ * lock).  Settings (crm_set_*) belong to the context, not to the calling thread --
+ * except the progress callback, which is kept per calling thread.
  */
 #ifndef CRM_HIP_H
 #define CRM_HIP_H
@@ -208,9 +209,10 @@ int crm_cov_solve(crm_background* bg, int rho_index, double v0, double v1, const
 /* Block size (variants per internal batch); 0 restores the default (automatic: up to 4096 variants of
  * the interaction scan while its largest work buffer stays within 16 GB; 1024 for the association scans). */
 int crm_set_block_variants(crm_ctx* ctx, int variants);
-/* Progress of the scans on this context: `callback(done, total, user)` is called on the calling thread after
- * every internal block of variants (the reference shows a tqdm bar over variants, _cellregmap.py:270,340);
- * NULL switches it off. */
+/* Progress of the scans the CALLING THREAD runs on this context: `callback(done, total, user)` is called on that thread
+ * after every internal block of variants (the reference shows a tqdm bar over variants, _cellregmap.py:270,340); NULL
+ * switches it off.  The callback is kept per calling thread: two threads that scan on one context each install and see
+ * their own. */
 int crm_set_progress_callback(crm_ctx* ctx, void (*callback)(long done, long total, void* user), void* user);
 /* on = 1 (default): for backgrounds built on the device with a well-conditioned kept spectrum
  * (S_max <= 1e6 S_min), the rotations G'Q0(rho) of the dense scan are taken as Mix(rho)'(H'G) with

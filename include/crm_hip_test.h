@@ -39,7 +39,8 @@ int crm_test_contract_kr(crm_ctx* ctx, long cells, int B, int k0, int N, const d
  * background keeps H). */
 int crm_test_set_shared_h(crm_ctx* ctx, int mode);
 /* on = 0: scans on this context contract against Q0(rho*) over all cells even when the background knows the donor
- * structure of its kinship factor (crm_background_set_kinship_groups); default 1 (environment: CRM_KIN_ROUTE=0). */
+ * structure of its kinship factor (crm_background_set_kinship_groups); 1 (default): the kinship-structure route where its
+ * flop count is below the direct contraction's; 2: always (environment: CRM_KIN_ROUTE=0 / 1 / 2). */
 int crm_test_set_kinship_route(crm_ctx* ctx, int on);
 /* Number of Khatri-Rao blocks of this context's scans whose last columns went through the 160-column-tile launch
  * (scan.hip: spectra with r mod 128 <= 32); tests use it to know which form they exercised. */

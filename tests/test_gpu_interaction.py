@@ -649,7 +649,8 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
         CellRegMap(c.y, c.E, W=c.W, background=half._bg, **kw).scan_interaction(panel)
 
 
-@pytest.mark.parametrize("hook,shape", [("none", "small"), ("E", "small"), ("G", "small"), ("none", "wide")])
+@pytest.mark.parametrize("hook,shape", [("none", "small"), ("E", "small"), ("G", "small"), ("none", "wide"),
+                                        ("none", "full"), ("G", "full")])
 def test_kinship_structure_route_equals_the_direct_route(hook, shape):
     """Mode C through get_L_values with an "expanded" kinship factor (rows of a donor-level factor repeated for the cells
     of each donor, ragged donors, a DENSE donor-level factor): the dense scan of general genotypes forms
@@ -661,7 +662,10 @@ def test_kinship_structure_route_equals_the_direct_route(hook, shape):
 
     rng = np.random.default_rng(77)
     # "wide": 70 contexts, so that [us | E1] takes 140 columns (two column tiles of the per-donor launch)
-    donors, k0, p, mcols, lo, hi = (9, 5, 40, 6, 7, 40) if shape == "small" else (12, 70, 8, 3, 40, 60)
+    # "full": a dense donor-level factor of full rank (as many columns as donors) -- the library then folds it into the
+    # mixing matrices (crm_background::kin_fold) and the per-donor sums are the operand of the Mix product as they stand;
+    # "small" / "wide" keep the contraction over the donors per block (rank-deficient factor: the folded operand would be longer)
+    donors, k0, p, mcols, lo, hi = {"small": (9, 5, 40, 6, 7, 40), "wide": (12, 70, 8, 3, 40, 60), "full": (9, 5, 40, 9, 7, 40)}[shape]
     sizes = rng.integers(lo, hi, size=donors)
     donor = np.repeat(np.arange(donors), sizes)
     n = donor.size
@@ -678,29 +682,34 @@ def test_kinship_structure_route_equals_the_direct_route(hook, shape):
     panel = GenotypePanel(G, groups=None)
     assert lib.crm_background_kinship_groups(crm._bg.handle) == donors      # the structure was found and is in use
     # the two routes with the null-fit optimum pinned (polish), so that the comparison is not about where Brent stops
-    _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
     try:
-        ppv, pinfo, pst = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
-        _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
-        pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 2))      # (always: at these sizes the route's flop count does not pay)
+        try:
+            ppv, pinfo, pst = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+            _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+            pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+        finally:
+            _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
+            _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+        assert np.array_equal(pinfo["rho1"], info0["rho1"])
+        assert_allclose(pst["delta"], st0["delta"], rtol=1e-8)
+        scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
+        assert np.all(np.abs(pst["Q"] - st0["Q"]) <= 1e-9 * scale)
+        assert np.all(np.abs(pst["F"] - st0["F"]) <= 1e-9 * np.abs(st0["F"]).max(axis=(1, 2), keepdims=True))
+        assert np.all(np.abs(ppv - pv0) <= 2e-6 * pv0 + 1e-13)
+        # ... and the reference's procedure verbatim against the oracle
+        pv, info, st = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+        opv, oinfo, ost = OracleCellRegMap(y, E, W=W, Ls=khatri_rao_halves(hK, E)).scan_interaction(G, return_stats=True, **hooks)
+        _compare(pv, info, st, opv, oinfo, ost)
+        # several phenotypes in one pass take the same route for H'(g o E0)
+        ys = [y, y[rng.permutation(n)], rng.normal(size=n)]
+        crms = [crm] + [CellRegMap(v, E, W=W, Ls=get_L_values(hK, E), background=crm._bg) for v in ys[1:]]
+        mpv, minfo = scan_interaction_many(crms, panel, **hooks)
+        for i, obj in enumerate(crms):
+            spv, sinfo = obj.scan_interaction(panel, progress=False, **hooks)
+            assert np.array_equal(minfo["rho1"][i], sinfo["rho1"])
+            assert np.all(np.abs(mpv[i] - spv) <= 1e-7 * spv + 1e-13)
     finally:
         _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
-    assert np.array_equal(pinfo["rho1"], info0["rho1"])
-    assert_allclose(pst["delta"], st0["delta"], rtol=1e-8)
-    scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
-    assert np.all(np.abs(pst["Q"] - st0["Q"]) <= 1e-9 * scale)
-    assert np.all(np.abs(pst["F"] - st0["F"]) <= 1e-9 * np.abs(st0["F"]).max(axis=(1, 2), keepdims=True))
-    assert np.all(np.abs(ppv - pv0) <= 2e-6 * pv0 + 1e-13)
-    # ... and the reference's procedure verbatim against the oracle
-    pv, info, st = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
-    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, Ls=khatri_rao_halves(hK, E)).scan_interaction(G, return_stats=True, **hooks)
-    _compare(pv, info, st, opv, oinfo, ost)
-    # several phenotypes in one pass take the same route for H'(g o E0)
-    ys = [y, y[rng.permutation(n)], rng.normal(size=n)]
-    crms = [crm] + [CellRegMap(v, E, W=W, Ls=get_L_values(hK, E), background=crm._bg) for v in ys[1:]]
-    mpv, minfo = scan_interaction_many(crms, panel, **hooks)
-    for i, obj in enumerate(crms):
-        spv, sinfo = obj.scan_interaction(panel, progress=False, **hooks)
-        assert np.array_equal(minfo["rho1"][i], sinfo["rho1"])
-        assert np.all(np.abs(mpv[i] - spv) <= 1e-7 * spv + 1e-13)
