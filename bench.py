@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--polish", type=int, default=0)
     ap.add_argument("--collapsed", type=int, default=1, help="also time the donor-collapsed path (N=1)")
     ap.add_argument("--full-panel", type=int, default=1, help="strong-scaling leg on the config's fixed panel")
+    ap.add_argument("--kinship", default="indicator", choices=["indicator", "rotated"],
+                    help="kinship factor of the synthetic cohort: donor indicators, or the dense U sqrt(S) of the same K")
     ap.add_argument("--genes", type=int, default=64, help="phenotypes of the config-4 leg (0 = skip)")
     ap.add_argument("--genes-variants", type=int, default=0,
                     help="variants of the config-4 leg, all ranks together (0 = the config's whole fixed panel when "
@@ -235,9 +237,10 @@ def main():
     # ---- synthetic data (not timed): the cohort, this rank's shard of the config's fixed panel, and -- when
     #      that shard is shorter than a few batches -- a panel of its own for the weak-scaling steps
     t0 = time.time()
-    # phenotype, contexts, kinship factor (U sqrt(S) of the donor-block K as the reference's simulator forms it: a dense
-    # donor-expanded n x m factor; SURVEY.md 8d, cellregmap_amd/synth.py: kinship_factor)
-    cohort = make_cohort(donors, cells, k0, 16, seed=20, kinship="rotated")
+    # phenotype, contexts, kinship factor: the donor indicators (the sparse factor of the donor-block K; the data of rounds
+    # 1-3, kept so that the lines stay comparable) or, --kinship rotated, U sqrt(S) as the reference's simulator forms it --
+    # a dense donor-expanded n x m factor of the same K (cellregmap_amd/synth.py: kinship_factor)
+    cohort = make_cohort(donors, cells, k0, 16, seed=20, kinship=args.kinship)
     f_first, f_count = variant_shard(p_total, rank, world)
     G_full = None
     if args.full_panel:
@@ -272,8 +275,7 @@ def main():
         # (called by sharded_background while its collective is in flight: PCIe beside xGMI)
         t0_ = time.perf_counter()
         uploaded["panel"] = GenotypePanel(G_full, device=local_rank, groups=None)   # dense: general genotypes
-        _lib.check(lib.crm_ctx_synchronize(ctx))
-        uploaded["seconds"] = time.perf_counter() - t0_
+        uploaded["seconds"] = time.perf_counter() - t0_      # (the copy is complete when the call returns)
 
     if world > 1 or (dist is not None and os.environ.get("CRM_BENCH_FORCE_EXCHANGE")):
         bg = sharded_background(cohort.E, Ls if args.mode == "C" else cohort.hK, _engine._RHO_GRID, device=local_rank,
@@ -281,7 +283,18 @@ def main():
                                 overlap=upload_full_panel if G_full is not None else None, info=exchange)
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, background=bg, **bg_kw)
     else:
+        # one GPU: the panel goes to the device from a second thread while this one runs the constructor (the library copies
+        # on a stream of its own, outside the context's lock: PCIe beside the eleven decompositions)
+        import threading
+
+        up = None
+        if G_full is not None and not os.environ.get("CRM_BENCH_SERIAL_UPLOAD"):
+            up = threading.Thread(target=upload_full_panel)
+            up.start()
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)
+        if up is not None:
+            up.join()
+            uploaded["overlapped"] = True
     crm._bind_gene()
     _lib.check(lib.crm_ctx_synchronize(ctx))
     t_ctor = time.perf_counter() - t_start     # (N > 1: includes the panel upload that ran beside the exchange)
@@ -334,8 +347,10 @@ def main():
                                      "rows": [[round(v, 4) for v in row] for row in per_rank]},
                       "exchange": exchange.get("exchange"), "exchanged_bytes_rank0": exchange.get("exchanged_bytes"),
                       "gather": gather_note or ("ok" if world > 1 else None),
-                      "note": "the fixed panel of the config sharded over the ranks; end to end = constructor + "
-                              "panel upload (host float64) + scan + gather, max over ranks"}
+                      "upload": "beside the constructor (second thread, own stream)" if uploaded.get("overlapped") else
+                                ("beside the exchange of the background" if world > 1 else "after the constructor"),
+                      "note": "the fixed panel of the config sharded over the ranks; end to end = constructor with the "
+                              "panel upload (host float64) beside it + scan + gather, max over ranks"}
         if f_count >= weak_blocks * batch:
             panel = fpanel
             fpanel_kept = fpanel
@@ -414,7 +429,7 @@ def main():
                                                       None, None, None, None))
             _lib.check(lib.crm_ctx_synchronize(ctx))
 
-        run_multi(min(mb, 2048))   # warm-up: work buffers at the size of a full block, Q0 of the selected grid points
+        run_multi(min(mb, 4096))   # warm-up: work buffers at the size of a full block (4096 variants), Q0 of the selected grid points
         fence()
         t0 = time.perf_counter()
         run_multi(mb)
@@ -601,7 +616,7 @@ def main():
             "workload": f"{args.config}: {n} cells x {k0} contexts, mode {args.mode} background (ranks {min(ranks)}..{max(ranks)}), "
                         f"{steps} steps x {batch} variants per GPU of the {p_total}-variant panel, 1 gene",
             "batch_variants": batch, "cells": n, "contexts": k0, "rho_grid": len(ranks),
-            "null_fit": "brent-1e-6" + ("+polish" if args.polish else ""),
+            "null_fit": "brent-1e-6" + ("+polish" if args.polish else ""), "kinship_factor": args.kinship,
             "route": ("kinship structure of the background (%d donors): H'(g o E0) donor by donor, then Mix(rho*)'" % kin_groups)
                      if kin_groups else "direct contraction against Q0(rho*) over all cells",
         },

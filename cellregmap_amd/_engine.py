@@ -194,12 +194,22 @@ def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
     ctx = _context(device)
     E1c, us, hK, rho = _lib.f64(E1), halves.us, halves.hK, _lib.f64(rho)
     h = ctypes.c_void_p()
-    _lib.check(lib.crm_background_create_hadamard(ctx, E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(us),
-                                                  us.shape[1], _lib.ptr(hK), hK.shape[1], rho.shape[0],
-                                                  _lib.ptr(rho), float(rel_tol), ctypes.byref(h)))
+    finder = None
+    if cache:
+        # the donor structure of the kinship factor is looked for on the host (row hashes, then entry by entry) while the
+        # device decomposes: the call below releases the GIL for its 0.8 s
+        finder = threading.Thread(target=_kinship_groups, args=(hK,), daemon=True)
+        finder.start()
+    try:
+        _lib.check(lib.crm_background_create_hadamard(ctx, E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(us),
+                                                      us.shape[1], _lib.ptr(hK), hK.shape[1], rho.shape[0],
+                                                      _lib.ptr(rho), float(rel_tol), ctypes.byref(h)))
+    finally:
+        if finder is not None:
+            finder.join()
     bg = _Background(h, rho, device)
     if cache:   # (the per-SNP backgrounds of the effect-size path are never scanned: nothing to announce)
-        _announce_kinship_groups(bg, halves)
+        _announce_kinship_groups(bg, halves)        # (finds the structure in the cache the thread filled)
     if cache:
         _bg_cache[key] = bg
         while len(_bg_cache) > BACKGROUND_CACHE_SIZE:

@@ -211,6 +211,7 @@ int crm_ctx_create(int device, crm_ctx** out) {
     if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("CRM_TILE_BAND")) c->tune.band = atoi(e) > 1 ? atoi(e) : 0;   // (0 or 1: column tile of X first, the walk before round 3)
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRM_HIP(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
     CRM_HIP(hipEventCreate(&c->ev1));
     {
@@ -255,6 +256,7 @@ void crm_ctx_destroy(crm_ctx* c) {
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->sync_timeouts_host) (void)hipHostFree(c->sync_timeouts_host);
     delete c;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)

@@ -61,6 +61,8 @@ struct crm_ctx {
     std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t upload_stream = nullptr;   // crm_panel_create copies on it, outside the context's lock: a panel can be
+                                           // uploaded from one thread while another one runs the constructor
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int block_variants = 0;  // 0 = automatic
     bool fast_T = true;    // T(rho) through the mixing matrices when the background offers them

@@ -268,10 +268,32 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
 
     double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
     int nfev = 0;
+    // The logistic is clamped to [eps, 1 - eps]: every x beyond +-36.7 is the SAME delta, and the objective there the same
+    // number to the last bit -- a phenotype without a random effect (delta -> 1: half of the genes of an eQTL run) sends the
+    // reference's bracketing phase through 63, 127, 255, 511, 709 and Brent's iteration after it, dozens of evaluations of
+    // one value.  The two clamped points are evaluated once and remembered (bit-identical results, fewer spectrum passes).
+    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0};
+    bool memo_set[2] = {false, false};
     // f(x) = -lml at d = logistic(x), with beta and scale profiled out
     auto f = [&](double x) -> double {
         nfev++;
         const double delta = logistic_clamped(x);
+        const int clamp = delta == 1.0 - EPS_TINY ? 1 : (delta == EPS_TINY ? 0 : -1);
+        if (clamp >= 0 && memo_set[clamp]) {
+            cur_delta = delta;
+            cur_scale = memo_scale[clamp];
+            cur_lml = memo_lml[clamp];
+            return memo_f[clamp];
+        }
+        auto remember = [&](double value) -> double {
+            if (clamp >= 0) {
+                memo_set[clamp] = true;
+                memo_f[clamp] = value;
+                memo_scale[clamp] = cur_scale;
+                memo_lml[clamp] = cur_lml;
+            }
+            return value;
+        };
         double S[NP], lsum, unused[NP], unused2;
         spectrum_pass(delta, true, S, lsum, false, unused, unused2);
         const double inv_d = 1.0 / delta;
@@ -300,7 +322,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
             cur_delta = delta;
             cur_scale = NAN;
             cur_lml = NAN;
-            return INFINITY;
+            return remember(INFINITY);
         }
         cholesky_solve<P>(A, rhs);  // rhs <- beta
         double rss = K[pair_index(C + 1, C + 1, U)];
@@ -312,7 +334,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         cur_delta = delta;
         cur_scale = s;
         cur_lml = val;
-        return -val;
+        return remember(-val);
     };
 
     // g(x) = d(-lml)/dx with beta and scale profiled out (oracle/lmm.py: _neg_lml_grad_at)

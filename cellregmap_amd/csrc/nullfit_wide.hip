@@ -231,9 +231,23 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
 
     double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
     int nfev = 0;
+    // (the two clamped points delta = eps, 1 - eps are evaluated once and remembered: see nullfit.hip)
+    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0};
+    bool memo_set[2] = {false, false};
     auto f = [&](double x) -> double {
         nfev++;
         const double delta = logistic_clamped(x);
+        const int clamp = delta == 1.0 - EPS_TINY ? 1 : (delta == EPS_TINY ? 0 : -1);
+        if (clamp >= 0 && memo_set[clamp]) {
+            cur_delta = delta; cur_scale = memo_scale[clamp]; cur_lml = memo_lml[clamp];
+            return memo_f[clamp];
+        }
+        auto remember = [&](double value) -> double {
+            if (clamp >= 0) {
+                memo_set[clamp] = true; memo_f[clamp] = value; memo_scale[clamp] = cur_scale; memo_lml[clamp] = cur_lml;
+            }
+            return value;
+        };
         double lsum;
         gram_pass(delta, true, lsum);
         const double inv_d = 1.0 / delta;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
         if (!ok) {
             cur_delta = delta; cur_scale = NAN; cur_lml = NAN;
             __syncthreads();
-            return INFINITY;
+            return remember(INFINITY);
         }
         if (tid == 0) {
             // rss = y'Ky - b' H^-1 b
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
         if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log(s)));
         cur_delta = delta; cur_scale = s; cur_lml = val;
         __syncthreads();
-        return -val;
+        return remember(-val);
     };
 
     // ---- bracket + Brent, identical to nullfit.hip -------------------------------------------------

@@ -513,11 +513,15 @@ void crm_gene_destroy(crm_gene* g) {
 }
 
 // ---- panel ----------------------------------------------------------------------------------
+// (No lock of the context: the upload touches none of its work buffers and runs on a stream of its own, so that a panel
+// can go to the device from one thread while another thread's constructor holds the context -- 8 GB over PCIe beside
+// the eleven decompositions.  The copy is complete when the call returns.)
 int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, crm_panel** out) {
-    return crm::guarded_on("crm_panel_create", ctx, [&]() -> int {
+    return crm::guarded("crm_panel_create", [&]() -> int {
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     *out = nullptr;
     CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->upload_stream ? ctx->upload_stream : ctx->stream;
     crm_panel* P = new crm_panel();
     P->ctx = ctx;
     P->uid = next_panel_uid();
@@ -526,9 +530,9 @@ int crm_panel_create(crm_ctx* ctx, long n, const double* G, long ldg, long p, cr
     P->p = p;
     P->ld = round_up(p, 128);
     int rc = P->G.ensure(sizeof(double) * P->n_pad * P->ld);
-    if (rc == CRM_OK) rc = upload_padded(ctx->stream, P->G.as<double>(), P->ld, P->n_pad, G, ldg, n, p);
+    if (rc == CRM_OK) rc = upload_padded(st, P->G.as<double>(), P->ld, P->n_pad, G, ldg, n, p);
     if (rc != CRM_OK) { crm_panel_destroy(P); return rc; }
-    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    CRM_HIP(hipStreamSynchronize(st));
     *out = P;
     return CRM_OK;
     });
@@ -702,12 +706,12 @@ extern "C" {
 // verification of detect_groups (both O(n p) memory passes that dominated short scans).
 int crm_panel_create_auto(crm_ctx* ctx, long n, const double* G, long ldg, long p, const int* group_hint,
                           long m_hint, const long* rep_rows, crm_panel** out, int* out_grouped) {
-    return crm::guarded_on("crm_panel_create_auto", ctx, [&]() -> int {
+    return crm::guarded("crm_panel_create_auto", [&]() -> int {   // (no lock of the context, like crm_panel_create)
     if (!ctx || !G || !out || n <= 0 || p <= 0 || ldg < p) return CRM_ERR_ARG;
     if (out_grouped) *out_grouped = 0;
     crm_panel* P = nullptr;
     CRM_TRY(crm_panel_create(ctx, n, G, ldg, p, &P));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->upload_stream ? ctx->upload_stream : ctx->stream;
     auto fail = [&](int code) { crm_panel_destroy(P); return code; };
     ScopedBuf flags, dgroup, drep;
     int rc;
@@ -995,18 +999,20 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     long auto_blk = (long)(16.0 * (1ull << 30) / (sizeof(double) * (double)g0->k0 * (double)bg->ldq)) / 128 * 128;
     auto_blk = std::max<long>(256, std::min<long>(auto_blk, CRM_MAX_AUTO_BLOCK));
     int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
+    // Several phenotypes: the pair-ordered buffers (A~ and, on the routes through H, its gathered operand) grow with the
+    // number of distinct (variant, rho*) pairs, up to min(nrho, ng) per variant.  They are kept within 96 GB (a third of the
+    // device) by running the pair stage of a block -- steps 5 to 11 -- over sub-ranges of its variants, while the stages
+    // before it (block copies, rotations and, above all, the per-phenotype null fits, which run twice as fast per variant in
+    // launches of 4096 variants as in launches of 2048) keep the full block.
+    int pair_cap = BLK;
     if (ng > 1) {
-        // pair-ordered buffers (A~ and, on the shared-H route, its gathered operand) grow with
-        // min(nrho, ng) * BLK: halve the block while they would take more than 96 GB (a third of the device; 2048 variants
-        // for 64 phenotypes at config 3 -- the per-phenotype launches of a block, null fits above all, run 1.5 times
-        // faster per variant there than on 1024)
         const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
         const double cap_gb = cap_env && atof(cap_env) > 0 ? atof(cap_env) : 96.0;
-        while (BLK > 128 &&
-               2.0 * sizeof(double) * std::min(nrho, ng) * (double)BLK * g0->k0 * (double)bg->ldq > cap_gb * (1ull << 30))
-            BLK /= 2;
+        const double per_pair = 2.0 * sizeof(double) * g0->k0 * (double)bg->ldq;
+        const long most = (long)std::min(nrho, ng) * BLK, least = (long)std::min(nrho, ng) * std::min(BLK, 128);
+        pair_cap = (int)std::max<long>(least, std::min<long>(most, (long)(cap_gb * (1ull << 30) / per_pair)));
     }
-    const int max_pairs = ng > 1 ? std::min(nrho, ng) * BLK : BLK;
+    const int max_pairs = pair_cap;
     const long ldb = BLK + 128;              // slack columns for the Khatri-Rao tile over-read
     const long ldp = max_pairs + 128;        // pair-ordered copy of the block
     const long ldA = ldq, ldT = ldq;
@@ -1290,6 +1296,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     for (long done = 0; done < count; done += BLK) {
         const int nb = (int)std::min<long>(BLK, count - done);
         const long col0 = first + done;
+        const long done_blk = done;
         double* Gb = ctx->ws_Gb.as<double>();
         TraceRange range_block("crm scan block");
         // 1. aligned copy of the block (and its row-permuted twin for the test direction); in
@@ -1522,6 +1529,36 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     return CRM_ERR_NUMERIC;
                 }
             }
+        // ---- the pair stage, over sub-ranges [sb0, sb0 + nsb) of the block (one sub-range unless several phenotypes ask for
+        //      more (variant, rho*) pairs than the pair-ordered buffers hold).  Inside, the block-order names below stand for
+        //      the sub-range: the same code serves a whole block and a part of it.
+        const int nb_blk = nb;
+        auto& h_fit_blk = h_fit;
+        double* const Gt_blk = Gt; double* const Gx_blk = Gx; double* const Gb_blk = Gb;
+        double* const d_gg_blk = d_gg; double* const d_gy_blk = d_gy; double* const d_gW_blk = d_gW;
+        double* const d_coef_blk = d_coef; NullFitOut* const d_fit_blk = d_fit;
+        for (int sb0 = 0; sb0 < nb_blk;) {
+        int nsb = nb_blk - sb0;
+        if (ng > 1) {
+            long pairs = 0;
+            int take = 0;
+            for (; sb0 + take < nb_blk; take++) {
+                unsigned seen = 0;
+                for (int gi = 0; gi < ng; gi++) seen |= 1u << h_fit_blk[(size_t)gi * BLK + sb0 + take].rho_index;
+                const int here = __builtin_popcount(seen);
+                if (take > 0 && pairs + here > pair_cap) break;
+                pairs += here;
+            }
+            nsb = take;
+        }
+        const int nb = nsb;
+        const long done = done_blk + sb0;
+        struct FitView { const NullFitOut* p; const NullFitOut& operator[](size_t i) const { return p[i]; } } h_fit{h_fit_blk.data() + sb0};
+        double* const Gt = Gt_blk + sb0; double* const Gx = Gx_blk + sb0; double* const Gb = Gb_blk + sb0;
+        double* const d_gg = d_gg_blk + sb0; double* const d_gy = d_gy_blk + sb0;
+        double* const d_gW = d_gW_blk + (size_t)sb0 * ld_gW; double* const d_coef = d_coef_blk + sb0;
+        NullFitOut* const d_fit = d_fit_blk + sb0;
+        const int blk_cols = (int)(ldb - sb0);      // columns of the block buffers from the sub-range's first one on
         std::fill(pair_of.begin(), pair_of.end(), -1);
         for (int gi = 0; gi < ng; gi++)
             for (int b = 0; b < nb; b++) pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b] = 0;
@@ -1677,7 +1714,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             const double* Gsrc = in_pair_order ? Gs : Gt;
             const long ldg_k = in_pair_order ? ldp : ldb;
             const int ncol = in_pair_order ? npairs : nb;
-            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, (int)ldg_k, Gk, ldg_k));
+            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, in_pair_order ? (int)ldg_k : blk_cols, Gk, ldg_k));
             std::vector<GemmProblem> kp((size_t)groups + fold_split6);
             long maxlen = GEMM_BK;
             for (long d = 0; d < groups; d++) {
@@ -1749,7 +1786,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             const double* Gsrc = in_pair_order ? Gs : Gt;
             const long ldg_k = in_pair_order ? ldp : ldb;
             const int ncol = in_pair_order ? npairs : nb;
-            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, (int)ldg_k, Gk, ldg_k));
+            CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, in_pair_order ? (int)ldg_k : blk_cols, Gk, ldg_k));
             std::vector<GemmProblem> kp((size_t)groups + k2);
             long maxlen = GEMM_BK;
             for (long d = 0; d < groups; d++) {
@@ -1828,7 +1865,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         // 7. elementwise products for the side contractions
         double* G2 = ctx->ws_G2.as<double>();
         double* GG = !collapsed ? ctx->ws_GG.as<double>() : nullptr;   // (test direction) o (fixed-effect role)
-        CRM_TRY(launch_square_block(st, Gt, Gx, ldb, ldb, xrows, (int)ldb, G2, GG, ldb));
+        CRM_TRY(launch_square_block(st, Gt, Gx, ldb, ldb, xrows, blk_cols, G2, GG, ldb));
         if (!GG) GG = G2;
         // 8. y-free side contractions: Z2 = (Gt o G)' E, Z3 = (Gt o Gt)' (E (x) E)
         const int s1 = collapsed ? 1 : ks1, s2 = collapsed ? 1 : ks2, s3 = collapsed ? 1 : ks3;
@@ -1887,7 +1924,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 R.ty = g->rot.as<double>() + (long)i * slab;
                 R.tW = R.ty + ldq; R.ldW = ldq;
                 R.S0 = bg->S0[i].as<double>();
-                R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
+                R.T = ctx->ws_T.as<double>() + ((size_t)i * BLK + sb0) * ldT; R.ldT = ldT;
                 R.r = bg->r[i];
             }
             aa.fit = d_fit + (size_t)gi * BLK; aa.sorted_pos = d_pos + (size_t)gi * BLK;
@@ -1928,6 +1965,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // the per-gene device buffers (Z1, Q, F, pv) are reused by the next gene
             CRM_HIP(hipStreamSynchronize(st));
         }
+        sb0 += nsb;
+        }   // pair stage over the sub-ranges of the block
         ctx->report(done + nb, count);   // (the reference's tqdm, :340)
     }
     return CRM_OK;

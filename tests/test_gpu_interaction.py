@@ -235,6 +235,42 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
 
 
+@pytest.mark.parametrize("route", [2, 0])
+def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
+    """Several phenotypes can ask for more (variant, rho*) pairs than the pair-ordered buffers hold (min(11, genes) per
+    variant in the worst case): the block keeps its size for the stages before -- the per-phenotype null fits above all --
+    and the pair stage runs over sub-ranges of its variants (scan.hip: pair_cap).  With the buffers cut down to the
+    smallest size the library accepts (CRM_PAIR_BUFFER_GB), 700 variants x 5 phenotypes take several sub-ranges and must
+    give exactly what the unrestricted pass gives, on the kinship-structure route and on the direct one, with and without
+    the permutation hooks."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 30, 4, 700, seed=43)
+    rng = np.random.default_rng(9)
+    n = c.y.size
+    ys = [c.y, c.y[rng.permutation(n)], rng.normal(size=n), c.y + rng.normal(size=n), c.y[::-1].copy()]
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(ys[0], c.E, W=c.W, Ls=Ls)
+    crms = [first] + [CellRegMap(y, c.E, W=c.W, Ls=Ls, background=first._bg) for y in ys[1:]]
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes
+    panel = GenotypePanel(G, groups=None)
+    lib, ctx = _lib.load(), _engine._context(0)
+    _lib.check(lib.crm_test_set_kinship_route(ctx, route))
+    try:
+        for kw in ({}, {"idx_G": rng.permutation(n)}):
+            monkeypatch.delenv("CRM_PAIR_BUFFER_GB", raising=False)
+            pv, info = scan_interaction_many(crms, panel, **kw)
+            assert np.mean([len(set(info["rho1"][:, j])) for j in range(700)]) > 1.5     # several rho* per variant
+            monkeypatch.setenv("CRM_PAIR_BUFFER_GB", "1e-9")
+            pv2, info2 = scan_interaction_many(crms, panel, **kw)
+            assert np.array_equal(pv, pv2)
+            for k in info:
+                assert np.array_equal(info[k], info2[k])
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+
+
 def test_shared_h_route_of_the_multi_gene_scan():
     """With Q0(rho) = H Mix(rho) the n-length Khatri-Rao contraction can be done once per variant
     against H and finished per (variant, rho*) pair with Mix(rho*): same null fits (bit-identical
