@@ -45,14 +45,18 @@ def algorithmic_flops(n, r_list, r_star, k0, c):
 
 def executed_flops(n, cols, r_list, r_star, k0, c, fast_rotation, kin=None):
     """What the engine executes per variant-test.  fast_rotation: the rotations go through the mixing matrices,
-    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones.  kin = (k1, k2, donors_padded, m): the
+    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones.  kin = (k1, k2, donors_padded, m, folded): the
     background knows the donor structure of its kinship factor, so H'g and H'(g o E0) are formed donor by donor
     (2 n (k1 + k2) flops per product column plus the contraction over the donors with the donor-level factor) and
     Q0(rho*)'(g o E0) is taken as Mix(rho*)'[H'(g o E0)]: 2 cols r* k0 instead of 2 n r* k0."""
     R = float(sum(r_list))
     if kin is not None:
-        k1, k2, dpad, m = kin
-        per_column = 2.0 * n * (k1 + k2) + 2.0 * dpad * m * k2        # donor sums + contraction over the donors
+        k1, k2, dpad, m, folded = kin
+        if folded:   # the contraction over the donors sits in the mixing matrices: their products are k1 + donors k2 long
+            per_column = 2.0 * n * (k1 + k2)
+            cols = folded
+        else:
+            per_column = 2.0 * n * (k1 + k2) + 2.0 * dpad * m * k2    # donor sums + contraction over the donors
         rot = per_column + 2.0 * cols * R
         contraction = per_column * k0 + 2.0 * cols * r_star * k0
     else:
@@ -461,11 +465,11 @@ def main():
     achieved = kr_fl.value / kr_s * 1e-12 if kr_s > 0 else 0.0
     kin_groups = lib.crm_background_kinship_groups(crm._bg.handle) if os.environ.get("CRM_KIN_ROUTE", "1") != "0" else 0
     if kin_groups:
-        kernel = ("gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>: A~ = Mix(rho*)' [H'(g o E0)] for every variant of a block, one "
-                  "launch per block (a plain cols x (variants k0) x r product over the cols = k1 + k2 m columns of the half "
-                  "factor, LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route, which "
-                  "forms H'(g o E0) donor by donor first (DESIGN.md 6c); achieved = its executed flops 2 cols r* k0 per "
-                  "variant / its duration by HIP events on the library's stream")
+        kernel = ("gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>: A~ = MixK(rho*)' S for every variant of a block, one launch per "
+                  "block (a plain K x (variants k0) x r product, K = k1 + donors k2 rows of per-donor sums S = [E1'(g o E0) over all "
+                  "cells ; us'(g o E0) donor by donor] against the mixing matrix with the donor-level kinship factor folded in; "
+                  "LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route (DESIGN.md 6c); "
+                  "achieved = its executed flops 2 K r* k0 per variant / its duration by HIP events on the library's stream")
     else:
         kernel = ("gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
                   "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
@@ -492,7 +496,7 @@ def main():
             "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
             "kinship_route": bool(kin_groups), "tile_band": int(os.environ.get("CRM_TILE_BAND", "8") or 0)}
     roofline["kernel_form"] = form
-    for name in ("r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             shape = pmc["launch_shape"]
@@ -515,7 +519,8 @@ def main():
     kin = None
     if kin_groups:
         k2_, m_ = (Ls.us.shape[1], Ls.hK.shape[1]) if args.mode == "C" else (0, 0)
-        kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_)
+        folded = lib.crm_background_kinship_folded(crm._bg.handle)
+        kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_, (cohort.E.shape[1] + kin_groups * k2_) if folded else 0)
     f_exe = executed_flops(n, cols, ranks, rstar, k0, c_cov, fast_rotation=True, kin=kin)
     per_rank_rate = value / world
 

@@ -33,6 +33,7 @@ SIGNATURES = {
                                                       ctypes.POINTER(vp)]),
     "crm_background_set_kinship_groups": (ctypes.c_int, [vp, vp, ctypes.c_long, vp, ctypes.c_long, vp, ctypes.c_int]),
     "crm_background_kinship_groups": (ctypes.c_int, [vp]),
+    "crm_background_kinship_folded": (ctypes.c_long, [vp]),
     "crm_background_begin": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_int, vp, ctypes.c_long, vp, ctypes.c_int, vp,
                                             ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.POINTER(vp)]),
     "crm_background_complete": (ctypes.c_int, [vp, vp]),

@@ -265,6 +265,16 @@ int crm_background_kinship_groups(const crm_background* bg) {
     }
 }
 
+long crm_background_kinship_folded(const crm_background* bg) {
+    if (!bg) return 0;
+    try {
+        std::lock_guard<std::recursive_mutex> lock(bg->ctx->mu);
+        return bg->kin && bg->kin_fold ? bg->kin_kdim : 0;
+    } catch (...) {
+        return 0;
+    }
+}
+
 int crm_background_rank(const crm_background* bg, int i) {
     return crm::guarded_on("crm_background_rank", bg ? bg->ctx : nullptr, [&]() -> int {
     if (!bg || i < 0 || i >= bg->nrho) return -1;

@@ -86,6 +86,12 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
                                       const double* U, int k2);
 /* Number of donors of the kinship structure in use by this background (0: none announced, or not usable). */
 int crm_background_kinship_groups(const crm_background* bg);
+/* > 0 when the donor-level factor has been folded into the mixing matrices (MixK(rho)[k1 + d' k2 + j, :] =
+ * sum_d hKd[d', d] Mix(rho)[k1 + j m + d, :], formed once when the structure is announced): the per-donor sums are then
+ * the operand of the product with the mixing matrix as they stand and no contraction over the donors runs per block of
+ * variants.  The value is the length of that product's contraction, k1 + donors k2 padded to whole stages.  Taken when it
+ * is at most a quarter longer than cols = k1 + m k2 (donor-level factors of full rank). */
+long crm_background_kinship_folded(const crm_background* bg);
 /* The same constructor split over several processes, one per GPU (the grid points are decomposed
  * by different ranks, the results exchanged over RCCL; cellregmap_amd/distributed.py drives it):
  *   begin    -- H = [E1, B] (B explicit, or U / hK as in crm_background_create_hadamard when B == NULL), Gram

@@ -1,11 +1,11 @@
-"""Turn the CSVs of tools/pmc_bench.sh into profiles/r03_pmc_summary.json.
+"""Turn the CSVs of tools/pmc_bench.sh into profiles/r04_pmc_summary.json.
 
 A block of 4096 variants is one large Khatri-Rao launch (gemm_tn_glds_sync_kernel) plus, when the spectrum is a little
 longer than a multiple of the 128-column tile, a second launch of 160-column tiles for the last columns; the counters of
 both are added per block.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 bytes; FETCH_SIZE is doubled for
 16-byte-per-lane streams (the gfx950 correction of MI355X_MICROARCH.md's HBM section).
 
-    python tools/pmc_summary.py gpurun_out/pmc_r03 [gpurun_out/pmc_r03_sync0] > profiles/r03_pmc_summary.json"""
+    python tools/pmc_summary.py gpurun_out/pmc_r04 [gpurun_out/pmc_r04_sync0] > profiles/r04_pmc_summary.json"""
 import csv
 import json
 import os
@@ -61,16 +61,16 @@ def main():
     variants = {names[i]: variant(d) for i, d in enumerate(dirs)}
     first = variants[names[0]]
     if kin:
-        # operands of one launch at config 3: H'(g o E0) 5050 x 204 800 doubles read once, Mix(rho*) 5050 x 5000 per
-        # selected grid point, A~ 204 800 x 5000 written
+        # operands of one launch at config 3: the per-donor sums S (5050 = k1 + donors k2 rows x 204 800 doubles) read once,
+        # MixK(rho*) 5050 x 5000 per selected grid point, A~ 204 800 x 5000 written
         alg = 8.0 * (5050 * 204800 + 5050 * 5000 + 204800 * 5000)
         shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096,
                  "flops_per_launch": 2.0 * 5050 * 5000 * 50 * 4096}
         what = ("rocprofv3 --pmc over bench.py's own launches (tools/pmc_bench.sh; bench.py --steps 2 --warmup 1, cfg3): the "
                 "dominant launch of the kinship-structure route, gemm_tn_glds_kernel<false, 1, 0, false, 128, 1> = "
-                "Mix(rho*)' [H'(g o E0)] for the 4096 variants of a block, one pass per counter group; summary by "
-                "tools/pmc_summary.py")
-        note = "H'(g o E0) 8.27 GB + Mix(rho*) 0.2 GB read once, A~ 8.19 GB written"
+                "MixK(rho*)' S for the 4096 variants of a block (the donor-level kinship factor folded into the mixing matrix), "
+                "one pass per counter group; summary by tools/pmc_summary.py")
+        note = "S 8.27 GB + MixK(rho*) 0.2 GB read once, A~ 8.19 GB written"
     else:
         alg = 9.75e9
         shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13}
@@ -81,7 +81,7 @@ def main():
         note = ("Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
                 "(SURVEY 8d per-unit figure x 4096)")
     # the kernel form of the profiled build: from the plain bench.py run that tools/pmc_bench.sh makes beside the passes
-    form = {"contraction_sync": True, "tail_launch": True, "library": "0.3.1", "kinship_route": kin, "tile_band": 8}
+    form = {"contraction_sync": True, "tail_launch": True, "library": "0.4.0", "kinship_route": kin, "tile_band": 8}
     try:
         line = open(os.path.join(dirs[0], "bench_plain.json")).read().strip().splitlines()[-1]
         form = json.loads(line)["roofline"]["kernel_form"]
