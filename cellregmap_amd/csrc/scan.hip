@@ -218,7 +218,11 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     bg->kin_fold = false;
     const long kfold = k1 + groups * (long)k2, m_pad = round_up(m, GEMM_BK);
     const char* fold_env = getenv("CRM_KIN_FOLD");
-    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && !(fold_env && atoi(fold_env) == 0)) {
+    // (k2 >= 32: the folded form launches the per-donor sums for the us columns alone, 64 columns wide -- with few of them,
+    // mode B's single column of ones or config 2's 20, one launch over [us | E1] together and the small contraction over
+    // the donors per block is the better form: cfg3 mode B 205 000 against 168 000 variant-tests/s, config 2 463 000 / 451 000)
+    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && (k2 >= 32 || (fold_env && atoi(fold_env) > 1)) &&
+        !(fold_env && atoi(fold_env) == 0)) {
         const long kdim = round_up(kfold, GEMM_BK), ldq = bg->ldq, ld_t = round_up(groups, 128);
         ScopedBuf hKdT, probs_dev;
         CRM_TRY(hKdT.ensure(sizeof(double) * m_pad * ld_t));

@@ -687,7 +687,7 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
 
 @pytest.mark.parametrize("hook,shape", [("none", "small"), ("E", "small"), ("G", "small"), ("none", "wide"),
                                         ("none", "full"), ("G", "full")])
-def test_kinship_structure_route_equals_the_direct_route(hook, shape):
+def test_kinship_structure_route_equals_the_direct_route(hook, shape, monkeypatch):
     """Mode C through get_L_values with an "expanded" kinship factor (rows of a donor-level factor repeated for the cells
     of each donor, ragged donors, a DENSE donor-level factor): the dense scan of general genotypes forms
     Q0(rho*)'(g o E0) = Mix(rho*)' [H'(g o E0)] with H'(g o E0) built donor by donor (crm_background_set_kinship_groups)
@@ -713,10 +713,13 @@ def test_kinship_structure_route_equals_the_direct_route(hook, shape):
     y = 0.5 * G[:, 3] * E[:, 0] + E @ rng.normal(size=k0) * 0.3 + hK @ rng.normal(size=mcols) * 0.2 + rng.normal(size=n)
     idx = rng.permutation(n)
     hooks = {} if hook == "none" else ({"idx_E": idx} if hook == "E" else {"idx_G": idx})
+    if shape == "full":   # (the library folds by itself from 32 columns of us on: few columns do better unfolded)
+        monkeypatch.setenv("CRM_KIN_FOLD", "2")
     crm = CellRegMap(y, E, W=W, Ls=get_L_values(hK, E))
     lib, ctx = _lib.load(), _engine._context(0)
     panel = GenotypePanel(G, groups=None)
     assert lib.crm_background_kinship_groups(crm._bg.handle) == donors      # the structure was found and is in use
+    assert (lib.crm_background_kinship_folded(crm._bg.handle) > 0) == (shape == "full")
     # the two routes with the null-fit optimum pinned (polish), so that the comparison is not about where Brent stops
     try:
         _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
