@@ -16,7 +16,7 @@ constexpr double LOG2PI = 1.8378770664093453;
 constexpr double EPS_SMALL = 1.4901161193847656e-08;
 constexpr double DBL_TINY = 2.2250738585072014e-308;   // numpy_sugar.epsilon.super_tiny
 constexpr double DBL_EPS = 2.220446049250313e-16;      // numpy_sugar.epsilon.tiny
-constexpr int CMAX = 62;
+constexpr int CMAX = CRM_MAX_COV_XWIDE;   // layout constant of the prep record (effects.hip reads it too)
 
 __device__ inline double block_sum(double v, double* red) {
     const int tid = threadIdx.x;
@@ -37,8 +37,9 @@ __device__ inline double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void fastscan_prep_kernel(AssocArgs a, double* __restrict__ prep,
                                                              double* __restrict__ wts) {
     __shared__ double red[256];
-    __shared__ double H[CMAX * CMAX];
     __shared__ double hy[CMAX];
+    double* const H = prep + 8 + CMAX;   // (c x c, ld CMAX: in the record itself -- 128 x 128 doubles do not fit static LDS;
+                                         // one workgroup, its own writes read back past the L1 by thread 0 only)
     const int tid = threadIdx.x;
     const int c = a.c, r = a.r;
     const double delta = a.delta0, inv_d = 1.0 / delta, omd = 1.0 - delta;
@@ -103,8 +104,6 @@ __global__ __launch_bounds__(256) void fastscan_prep_kernel(AssocArgs a, double*
         prep[1] = logdetK;
         prep[2] = delta;
         prep[3] = ok ? 1.0 : 0.0;
-        for (int i = 0; i < c; i++)
-            for (int k = 0; k <= i; k++) prep[8 + CMAX + i * CMAX + k] = H[i * CMAX + k];
     }
 }
 

@@ -89,6 +89,11 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     fa.WW = gene->WW.as<double>(); fa.Wy = gene->Wy.as<double>(); fa.yy = gene->yy;
     fa.gg = d_gg; fa.gy = d_gy; fa.gW = d_gW; fa.ld_gW = ld_gW;
     fa.trial = d_trial; fa.out = d_fit;
+    ScopedBuf xwide;
+    if (c > CRM_MAX_COV_WIDE) {   // 63 .. 128 columns (run_association binds the contexts here): nullfit_xwide.hip
+        CRM_TRY(xwide.ensure(sizeof(double) * nullfit_xwide_scratch_doubles(std::max(BLK, 1), nrho, c)));
+        fa.xwide = xwide.as<double>();
+    }
     CRM_TRY(launch_nullfit(st, fa, 1));
     NullFitOut null{};
     CRM_HIP(hipMemcpyAsync(&null, d_fit, sizeof null, hipMemcpyDeviceToHost, st));

@@ -16,7 +16,7 @@ using namespace crm;
 
 namespace {
 
-constexpr int CMAX = 62;  // layout constant of the fastscan_prep record (assoc.hip)
+constexpr int CMAX = CRM_MAX_COV_XWIDE;  // layout constant of the fastscan_prep record (assoc.hip)
 
 // w_j = d_j t_j,  d_j = v0 S0_j / (v0 S0_j + v1), for m right-hand sides (rows of T)
 __global__ void shrink_rotation_kernel(double* __restrict__ T, long ldT, int m, const double* __restrict__ S0,
@@ -89,6 +89,11 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
     fa.gg = d_g3; fa.gy = d_g3 + 1; fa.gW = d_g3 + 2; fa.ld_gW = ld_gW;
     fa.trial = (NullFitTrial*)(sm + o_trial);
     fa.out = (NullFitOut*)(sm + o_fit);
+    ScopedBuf xwide;
+    if (c > CRM_MAX_COV_WIDE) {   // 63 .. 128 columns: the slower kernel with its scratch in global memory
+        CRM_TRY(xwide.ensure(sizeof(double) * nullfit_xwide_scratch_doubles(1, nrho, c)));
+        fa.xwide = xwide.as<double>();
+    }
     CRM_TRY(launch_nullfit(st, fa, 1));
     NullFitOut fit{};
     CRM_HIP(hipMemcpyAsync(&fit, fa.out, sizeof fit, hipMemcpyDeviceToHost, st));

@@ -43,6 +43,7 @@ struct NullFitArgs {
     long ld_gW;
     const int* g_drop; // [variants] 1: the variant's direction falls under the reference's rank rule (launch_ortho_rank);
                        // null: decided here from the last pivot of the Cholesky factor of X'X (relative 1e-12)
+    double* xwide;        // scratch of the 63..128-column kernel: nullfit_xwide_scratch_doubles(variants, nrho, c) doubles
     NullFitTrial* trial;  // [variants x nrho]
     NullFitOut* out;      // [variants]
 };
@@ -52,6 +53,9 @@ struct NullFitArgs {
 // queue: CRM_MAX_RHO unsigned counters in device memory (optional; enables the LDS-shared form for c == 1)
 int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide = false, unsigned* queue = nullptr);
 int launch_nullfit_wide(hipStream_t st, const NullFitArgs& a, int variants);
+// 63 .. 128 covariate columns (nullfit_xwide.hip): needs NullFitArgs::xwide
+int launch_nullfit_xwide(hipStream_t st, const NullFitArgs& a, int variants);
+size_t nullfit_xwide_scratch_doubles(int variants, int nrho, int c);
 
 // ---- association paths (assoc.hip) ---------------------------------------------------------------
 struct AssocArgs {

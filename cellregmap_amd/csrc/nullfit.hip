@@ -667,6 +667,8 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         else
             hipLaunchKernelGGL((nullfit_shared_kernel<1, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
                                variants, sld, queue);
+    } else if (a.c > CRM_MAX_COV_WIDE) {
+        CRM_TRY(launch_nullfit_xwide(st, a, variants));
     } else if (force_wide || a.c > CRM_MAX_COV) {
         CRM_TRY(launch_nullfit_wide(st, a, variants));
     } else

@@ -1,0 +1,416 @@
+// Null fits with 63 .. 128 fixed-effect columns: the slower, correct path behind nullfit_wide.hip's 62-column limit.
+//
+// Who needs it: the association wrappers bind the cellular contexts to the fixed-effect slot
+// (cellregmap/_cellregmap.py:498, :529: run_association(y, W, E, G) calls CellRegMap(y, W, E, ...) positionally), so a
+// cohort with 100 contexts fits LMMs with 100 covariate columns there; the effect-size estimators fit [W, g, E0]
+// (:175, :223).  The reference accepts any width.
+//
+// Same model, same search (bracket + Brent, rtol = atol = 1e-6, statement for statement as nullfit.hip / oracle/brent.py),
+// same weighted-Gram evaluation as nullfit_wide.hip -- one 256-thread workgroup per (variant, rho), 16 x 16 threads with
+// TS x TS register tiles over sqrt(w)-scaled rows staged in LDS -- but with what no longer fits LDS kept elsewhere:
+//   * the (c+1) x (c+1) system / Cholesky factor in PACKED lower-triangular storage (129 * 130 / 2 doubles = 67 KB),
+//   * the complement numerators u'v - t_u't_v (KT x KT, constant over the search) in global memory (NullFitArgs::xwide,
+//     KT * KT doubles per workgroup; they stay in L2),
+//   * the weighted Gram itself nowhere: every thread adds its tile to the packed system (and to the right-hand side /
+//     y'K^-1y) straight from its accumulators,
+//   * 32 spectrum entries per staging step instead of 64.
+#include "nullfit.h"
+
+namespace crm {
+
+namespace {
+
+constexpr double LOG2PI = 1.8378770664093453;
+constexpr double EPS_TINY = 2.220446049250313e-16;
+constexpr double EPS_SMALL = 1.4901161193847656e-08;
+constexpr double LOGMAX = 709.782712893384;
+constexpr double GOLDEN = 0.381966011250105097;
+constexpr int MAXITER = 500;
+constexpr int CHX = 32;         // spectrum entries per staging step
+constexpr int XKT_MAX = 130;    // c + 2 <= 130
+
+__device__ inline double logistic_clamped_x(double x) {
+    double v;
+    if (x > 0.0) {
+        v = 1.0 / (1.0 + exp(-x));
+    } else {
+        v = exp(x);
+        v = v / (v + 1.0);
+    }
+    return fmin(fmax(v, EPS_TINY), 1.0 - EPS_TINY);
+}
+
+__device__ inline int tri(int i, int k) { return i * (i + 1) / 2 + k; }   // k <= i
+
+// In-place Cholesky of the leading P x P block in packed lower storage, all threads.  false on a non-positive pivot.
+__device__ bool packed_cholesky(double* H, int P, double* scal, double& logdet) {
+    const int tid = threadIdx.x;
+    logdet = 0.0;
+    for (int j = 0; j < P; j++) {
+        __syncthreads();
+        if (tid == 0) {
+            double d = H[tri(j, j)];
+            for (int k = 0; k < j; k++) d -= H[tri(j, k)] * H[tri(j, k)];
+            scal[0] = d;
+        }
+        __syncthreads();
+        const double d = scal[0];
+        if (!(d > 0.0)) return false;
+        const double l = sqrt(d);
+        logdet += 2.0 * log(l);
+        for (int i = j + 1 + tid; i < P; i += blockDim.x) {
+            double s = H[tri(i, j)];
+            for (int k = 0; k < j; k++) s -= H[tri(i, k)] * H[tri(j, k)];
+            H[tri(i, j)] = s / l;
+        }
+        if (tid == 0) H[tri(j, j)] = l;
+        __syncthreads();
+    }
+    return true;
+}
+
+template <int TS>
+__global__ __launch_bounds__(256) void nullfit_xwide_kernel(NullFitArgs a) {
+    extern __shared__ __align__(16) double xsm[];
+    const int b = blockIdx.x;
+    const int w = blockIdx.y;
+    const NullFitRho R = a.rho[w];
+    const int c = a.c;
+    const int P = c + 1, KT = c + 2;
+    const int r = R.r;
+    const double n = (double)a.n;
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const double* __restrict__ tg = R.T + (long)b * R.ldT;
+    // LDS: S [16 TS][CHX + 1], sd [CHX], Hp [P (P + 1) / 2], rhs [KT], red [256], scal [8]
+    double* const S = xsm;
+    double* const sd = S + 16 * TS * (CHX + 1);
+    double* const Hp = sd + CHX;
+    double* const rhs = Hp + (size_t)P * (P + 1) / 2;
+    double* const red = rhs + KT;
+    double* const scal = red + 256;
+    double* const Cp = a.xwide + ((size_t)b * a.nrho + w) * (size_t)KT * KT;   // [KT x KT] complement numerators
+
+    auto row_value = [&](int row, int j) -> double {
+        if (row < c) return R.tW[(long)row * R.ldW + j];
+        if (row == c) return tg[j];
+        return R.ty[j];
+    };
+    // weighted Gram over the spectrum in register tiles; `sink(row, col, value)` receives every entry of the KT x KT
+    // result (row, col < KT) from the thread that holds it; returns sum_j log D_j in lsum
+    auto gram_pass = [&](double delta, bool weighted, double& lsum, auto&& sink) {
+        double acc[TS][TS];
+#pragma unroll
+        for (int i = 0; i < TS; i++)
+#pragma unroll
+            for (int j = 0; j < TS; j++) acc[i][j] = 0.0;
+        double lpart = 0.0;
+        const double omd = 1.0 - delta;
+        for (int c0 = 0; c0 < r; c0 += CHX) {
+            if (tid < CHX) {
+                const int j = c0 + tid;
+                double v = 0.0;
+                if (j < r) {
+                    if (weighted) {
+                        const double D = omd * R.S0[j] + delta;
+                        lpart += log(D);
+                        v = sqrt(1.0 / D);
+                    } else {
+                        v = 1.0;
+                    }
+                }
+                sd[tid] = v;
+            }
+            __syncthreads();
+            for (int e = tid; e < 16 * TS * CHX; e += 256) {
+                const int row = e / CHX, cc = e - row * CHX;
+                const int j = c0 + cc;
+                double v = 0.0;
+                if (row < KT && j < r) v = row_value(row, j) * sd[cc];
+                S[row * (CHX + 1) + cc] = v;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int cc = 0; cc < CHX; cc++) {
+                double x[TS], y[TS];
+#pragma unroll
+                for (int i = 0; i < TS; i++) {
+                    x[i] = S[(ti + 16 * i) * (CHX + 1) + cc];
+                    y[i] = S[(tj + 16 * i) * (CHX + 1) + cc];
+                }
+#pragma unroll
+                for (int i = 0; i < TS; i++)
+#pragma unroll
+                    for (int j = 0; j < TS; j++) acc[i][j] += x[i] * y[j];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TS; i++) {
+            const int row = ti + 16 * i;
+#pragma unroll
+            for (int j = 0; j < TS; j++) {
+                const int col = tj + 16 * j;
+                if (row < KT && col < KT) sink(row, col, acc[i][j]);
+            }
+        }
+        red[tid] = lpart;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < CHX; i++) s += red[i];
+            scal[1] = s;
+        }
+        __syncthreads();
+        lsum = scal[1];
+    };
+    // (written by this workgroup's threads, read by others of it: past the CU's vector L1)
+    auto cp_at = [&](size_t e) -> double { return __hip_atomic_load(Cp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto plain = [&](int i, int j) -> double {   // u'v for u, v in {W.., g, y}
+        if (i > j) { const int t = i; i = j; j = t; }
+        if (j < c) return a.WW[i * c + j];
+        if (j == c) return i < c ? a.gW[(long)b * a.ld_gW + i] : a.gg[b];
+        return i < c ? a.Wy[i] : (i == c ? a.gy[b] : a.yy);
+    };
+
+    // rank of [W, g] and log|X'X| from the Cholesky of the plain Gram
+    for (int e = tid; e < P * (P + 1) / 2; e += 256) {
+        int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (tri(i + 1, 0) <= e) i++;
+        while (tri(i, 0) > e) i--;
+        Hp[e] = plain(i, e - tri(i, 0));
+    }
+    __syncthreads();
+    bool use_g = true;
+    double logdetXX = 0.0;
+    {
+        const bool flagged = a.g_drop && a.g_drop[b] != 0;
+        bool ok = packed_cholesky(Hp, c, scal, logdetXX);   // the covariates' block
+        if (ok && !flagged) {
+            // the variant's row by hand: relative floor on its pivot when no flag came with the block (legacy rule)
+            if (tid == 0) {
+                for (int k = 0; k < c; k++) {
+                    double s = Hp[tri(c, k)];
+                    for (int q = 0; q < k; q++) s -= Hp[tri(c, q)] * Hp[tri(k, q)];
+                    Hp[tri(c, k)] = s / Hp[tri(k, k)];
+                }
+                double d = Hp[tri(c, c)];
+                const double d0 = d;
+                for (int k = 0; k < c; k++) d -= Hp[tri(c, k)] * Hp[tri(c, k)];
+                scal[3] = d;
+                scal[4] = d0;
+            }
+            __syncthreads();
+            const double d = scal[3];
+            if (a.g_drop ? !(d > 0.0) : !(d > 1e-12 * scal[4])) {
+                if (a.g_drop) ok = false;
+                else use_g = false;
+            } else {
+                logdetXX += log(d);
+            }
+        } else if (flagged) {
+            use_g = false;
+        }
+        if (!ok) logdetXX = NAN;
+        __syncthreads();
+    }
+    // complement numerators: plain inner products minus the unweighted Gram, into global memory
+    {
+        double dummy;
+        gram_pass(1.0, false, dummy, [&](int row, int col, double v) { Cp[(size_t)row * KT + col] = plain(row, col) - v; });
+        __threadfence();
+        __syncthreads();
+    }
+    const double p_eff = use_g ? (double)P : (double)c;
+    const double df = a.restricted ? n - p_eff : n;
+
+    double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
+    int nfev = 0;
+    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0};
+    bool memo_set[2] = {false, false};
+    auto f = [&](double x) -> double {
+        nfev++;
+        const double delta = logistic_clamped_x(x);
+        const int clamp = delta == 1.0 - EPS_TINY ? 1 : (delta == EPS_TINY ? 0 : -1);
+        if (clamp >= 0 && memo_set[clamp]) {
+            cur_delta = delta; cur_scale = memo_scale[clamp]; cur_lml = memo_lml[clamp];
+            return memo_f[clamp];
+        }
+        auto remember = [&](double value) -> double {
+            if (clamp >= 0) {
+                memo_set[clamp] = true; memo_f[clamp] = value; memo_scale[clamp] = cur_scale; memo_lml[clamp] = cur_lml;
+            }
+            return value;
+        };
+        const double inv_d = 1.0 / delta;
+        double lsum;
+        gram_pass(delta, true, lsum, [&](int row, int col, double v) {
+            const double k = v + cp_at((size_t)row * KT + col) * inv_d;   // u' Kt^-1 v
+            if (row < P && col <= row) {
+                double h = k;
+                if (!use_g && (row == c || col == c)) h = (row == col) ? 1.0 : 0.0;
+                Hp[tri(row, col)] = h;
+            }
+            if (col == c + 1 && row < P) rhs[row] = (!use_g && row == c) ? 0.0 : k;
+            if (row == c + 1 && col == c + 1) scal[5] = k;                // y' Kt^-1 y
+        });
+        __syncthreads();
+        const double logdetK = lsum + (n - (double)r) * log(delta);
+        double logdetH;
+        const bool ok = packed_cholesky(Hp, P, scal, logdetH);
+        if (!ok) {
+            cur_delta = delta; cur_scale = NAN; cur_lml = NAN;
+            __syncthreads();
+            return remember(INFINITY);
+        }
+        if (tid == 0) {
+            // rss = y'Ky - z'z with L z = b  (one forward substitution)
+            double rss = scal[5];
+            for (int i = 0; i < P; i++) {
+                double s = rhs[i];
+                for (int k = 0; k < i; k++) s -= Hp[tri(i, k)] * red[k];
+                s /= Hp[tri(i, i)];
+                red[i] = s;
+                rss -= s * s;
+            }
+            scal[2] = rss;
+        }
+        __syncthreads();
+        const double rss = scal[2];
+        const double s = fmax(rss / df, EPS_SMALL);
+        double val = -0.5 * (df * LOG2PI + df + n * log(s) + logdetK);
+        if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log(s)));
+        cur_delta = delta; cur_scale = s; cur_lml = val;
+        __syncthreads();
+        return remember(-val);
+    };
+
+    // ---- bracket + Brent, identical to nullfit.hip -------------------------------------------------
+    double lo = -LOGMAX, hi = LOGMAX;
+    double x0 = 0.0, x1 = 1.0;
+    double f0 = f(x0), f1 = f(x1);
+    if (f1 > f0) {
+        double t = x0; x0 = x1; x1 = t;
+        t = f0; f0 = f1; f1 = t;
+    }
+    double bl, bm, bh, fm;
+    bool bracketed = false;
+    for (int it = 0; it < MAXITER; it++) {
+        double x2 = x1 + 2.0 * (x1 - x0);
+        x2 = fmin(fmax(x2, lo), hi);
+        if (x2 == x1) break;
+        const double f2 = f(x2);
+        if (f2 > f1) {
+            bl = x0 < x2 ? x0 : x2;
+            bh = x0 < x2 ? x2 : x0;
+            bm = x1; fm = f1;
+            bracketed = true;
+            break;
+        }
+        x0 = x1; f0 = f1;
+        x1 = x2; f1 = f2;
+    }
+    if (!bracketed) {
+        bl = x0 < x1 ? x0 : x1;
+        bh = x0 < x1 ? x1 : x0;
+        bm = x1; fm = f1;
+    }
+    const double rtol = 1e-6, atol = 1e-6;
+    double A_ = bl, B_ = bh;
+    double bx0 = bm, bf0 = fm;
+    double bx1 = bx0, bx2 = bx0, bf1 = bf0, bf2 = bf0;
+    double d = 0.0, e = 0.0;
+    for (int it = 0; it < MAXITER; it++) {
+        const double m = 0.5 * (A_ + B_);
+        const double tol = rtol * fabs(bx0) + atol;
+        const double tol2 = 2.0 * tol;
+        if (fabs(bx0 - m) <= tol2 - 0.5 * (B_ - A_)) break;
+        double p = 0.0, q = 0.0, rr = 0.0;
+        if (tol < fabs(e)) {
+            rr = (bx0 - bx1) * (bf0 - bf2);
+            q = (bx0 - bx2) * (bf0 - bf1);
+            p = (bx0 - bx2) * q - (bx0 - bx1) * rr;
+            q = 2.0 * (q - rr);
+            if (0.0 < q) p = -p;
+            q = fabs(q);
+            rr = e;
+            e = d;
+        }
+        double u;
+        if (fabs(p) < fabs(0.5 * q * rr) && q * (A_ - bx0) < p && p < q * (B_ - bx0)) {
+            d = p / q;
+            u = bx0 + d;
+            if ((u - A_) < tol2 || (B_ - u) < tol2) d = bx0 < m ? tol : -tol;
+        } else {
+            e = bx0 < m ? B_ - bx0 : A_ - bx0;
+            d = GOLDEN * e;
+        }
+        if (tol <= fabs(d)) u = bx0 + d;
+        else if (0.0 < d) u = bx0 + tol;
+        else u = bx0 - tol;
+        const double fu = f(u);
+        if (fu <= bf0) {
+            if (u < bx0) B_ = bx0; else A_ = bx0;
+            bx2 = bx1; bf2 = bf1;
+            bx1 = bx0; bf1 = bf0;
+            bx0 = u; bf0 = fu;
+        } else {
+            if (u < bx0) A_ = u; else B_ = u;
+            if (fu <= bf1 || bx1 == bx0) {
+                bx2 = bx1; bf2 = bf1;
+                bx1 = u; bf1 = fu;
+            } else if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
+                bx2 = u; bf2 = fu;
+            }
+        }
+    }
+    (void)f(bx0);
+    if (tid == 0) {
+        NullFitTrial t;
+        t.lml = cur_lml;
+        t.delta = cur_delta;
+        t.scale = cur_scale;
+        t.use_g = use_g ? 1 : 0;
+        t.nfev = nfev;
+        a.trial[(long)b * a.nrho + w] = t;
+    }
+}
+
+}  // namespace
+
+size_t nullfit_xwide_scratch_doubles(int variants, int nrho, int c) { return (size_t)variants * nrho * (c + 2) * (c + 2); }
+
+int launch_nullfit_xwide(hipStream_t st, const NullFitArgs& a, int variants) {
+    const int KT = a.c + 2, P = a.c + 1;
+    if (KT > XKT_MAX) {
+        set_error("null fit: %d covariate columns (supported up to %d)", a.c, XKT_MAX - 2);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    if (a.polish) {
+        set_error("null fit: the derivative polish is only built for up to %d covariate columns", CRM_MAX_COV);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    if (!a.xwide) {
+        set_error("null fit: %d covariate columns need the wide scratch buffer (NullFitArgs::xwide)", a.c);
+        return CRM_ERR_INTERNAL;
+    }
+    const int ts = (KT + 15) / 16;
+    const size_t lds = sizeof(double) * ((size_t)16 * ts * (CHX + 1) + CHX + (size_t)P * (P + 1) / 2 + KT + 256 + 8);
+    dim3 grid(variants, a.nrho);
+#define CRM_XWIDE(T)                                                                                 \
+    do {                                                                                             \
+        CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nullfit_xwide_kernel<T>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL(nullfit_xwide_kernel<T>, grid, dim3(256), lds, st, a);                    \
+    } while (0)
+    if (ts <= 5) CRM_XWIDE(5);
+    else if (ts == 6) CRM_XWIDE(6);
+    else if (ts == 7) CRM_XWIDE(7);
+    else if (ts == 8) CRM_XWIDE(8);
+    else CRM_XWIDE(9);
+#undef CRM_XWIDE
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+}  // namespace crm

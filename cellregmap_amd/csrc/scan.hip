@@ -310,8 +310,8 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
         set_error("gene: the background is still under construction (crm_background_seal not called)");
         return CRM_ERR_ARG;
     }
-    if (c < 1 || c > CRM_MAX_COV_WIDE) {
-        set_error("gene: %d covariate columns (supported 1..%d)", c, CRM_MAX_COV_WIDE);
+    if (c < 1 || c > CRM_MAX_COV_XWIDE) {
+        set_error("gene: %d covariate columns (supported 1..%d; the interaction scan up to %d)", c, CRM_MAX_COV_XWIDE, CRM_MAX_COV_WIDE);
         return CRM_ERR_UNSUPPORTED;
     }
     if (k0 < 1 || k0 > CRM_MAX_K0) {
@@ -992,6 +992,11 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         return CRM_ERR_UNSUPPORTED;
     }
     struct InScan { crm_ctx* c; explicit InScan(crm_ctx* c_) : c(c_) { c->in_scan = true; } ~InScan() { c->in_scan = false; } } in_scan(ctx);
+    if (g0->c > CRM_MAX_COV_WIDE) {
+        set_error("interaction scan: %d covariate columns (supported up to %d; the association scans and LMM fits take up to %d)",
+                  g0->c, CRM_MAX_COV_WIDE, CRM_MAX_COV_XWIDE);
+        return CRM_ERR_UNSUPPORTED;
+    }
     if (ctx->polish && g0->c > CRM_MAX_COV) {
         set_error("interaction scan: the null-fit polish is only built for up to %d covariate columns", CRM_MAX_COV);
         return CRM_ERR_UNSUPPORTED;

@@ -76,8 +76,9 @@ def test_sizes_out_of_range(world):
     many = _lib.f64(np.linspace(0, 1, 17))
     assert lib.crm_background_create(world["ctx"], n, _lib.ptr(world["E"]), 3, None, 0, 17, _lib.ptr(many), 0.0,
                                      ctypes.byref(out)) == ERR_UNSUPPORTED and b"grid points" in lib.crm_last_error()
-    Wwide = _lib.f64(np.random.default_rng(0).normal(size=(n, 63)))
-    assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(Wwide), 63, _lib.ptr(world["E"]), 3,
+    # up to 128 covariate columns bind (the association scans and LMM fits take them: nullfit_xwide.hip); 129 do not
+    Wwide = _lib.f64(np.random.default_rng(0).normal(size=(n, 129)))
+    assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(Wwide), 129, _lib.ptr(world["E"]), 3,
                                ctypes.byref(out)) == ERR_UNSUPPORTED
     Ewide = _lib.f64(np.random.default_rng(1).normal(size=(n, 129)))
     assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(world["W"]), 1, _lib.ptr(Ewide), 129,

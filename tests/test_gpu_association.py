@@ -104,3 +104,23 @@ def test_association_sweep_against_the_oracle(i, donors, cells, k, p, c, mode, f
     for key in ("e2", "g2", "eps2"):
         assert_allclose(info[key], oinfo[key], rtol=1e-5, atol=1e-12)
     assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("contexts", [70, 100, 126])
+def test_run_association_with_many_contexts(contexts, fast):
+    """run_association(y, W, E, G, hK) binds the contexts to the fixed-effect slot (_cellregmap.py:498, :529), so a cohort
+    with 100 contexts fits LMMs with 100 covariate columns; round 3 refused more than 61.  Now 63 .. 128 columns go through
+    the slower null-fit kernel whose scratch lives in global memory (nullfit_xwide.hip): null model and every p-value
+    against the oracle."""
+    from cellregmap_amd import run_association, run_association_fast
+    from oracle import crm as ocrm
+
+    c = _cohort(10, 40, contexts, 12, seed=24)                # 400 cells
+    f, of = (run_association_fast, ocrm.run_association_fast) if fast else (run_association, ocrm.run_association)
+    pv, info = f(c.y, c.W, c.E, c.G, hK=c.hK)
+    opv, oinfo = of(c.y, c.W, c.E, c.G, hK=c.hK)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    for key in ("e2", "g2", "eps2"):
+        assert_allclose(info[key], oinfo[key], rtol=1e-5, atol=1e-10)
+    assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]

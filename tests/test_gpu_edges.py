@@ -205,8 +205,14 @@ def test_unsupported_sizes_fail_loudly():
     c = _cohort(8, 20, 3, 4, seed=35)
     rng = np.random.default_rng(1)
     W = np.concatenate([c.W, rng.normal(size=(c.y.size, 69))], axis=1)  # 70 independent covariates > 62
-    with pytest.raises(_lib.CrmError):
-        CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
+    crm = CellRegMap(c.y, c.E, W=W)
+    with pytest.raises(_lib.CrmError, match="interaction scan: 70 covariate columns"):
+        crm.scan_interaction(c.G)
+    pv, info = crm.scan_association(c.G, progress=False)      # ... which the association scans take (up to 128)
+    assert np.all(np.isfinite(pv))
+    E = rng.normal(size=(c.y.size, 129))                               # 129 contexts > 128
+    with pytest.raises(_lib.CrmError, match="contexts"):
+        CellRegMap(c.y, E, W=c.W).scan_interaction(c.G)
 
 
 def test_device_side_group_verification():
