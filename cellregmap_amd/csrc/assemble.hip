@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     constexpr int ROWS = 16 * NTL, NTILES = NTL * (NTL + 1) / 2, MAXT = (NTILES + 3) / 4, RPT = ROWS / 4;
     extern __shared__ double Ss[];  // [ROWS][SLD]
     __shared__ int tile_ij[NTILES];
-    __shared__ const double* tail_ptr[CRM_MAX_COV_WIDE + 2];
+    __shared__ const double* tail_ptr[CRM_MAX_COV_XWIDE + 2];
     const int b = blockIdx.x;
     const NullFitOut fit = a.fit[b];
     const AssembleRho R = a.rho[fit.rho_index];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void gram_ext_dma_kernel(AssembleArgs a, doubl
     }
 }
 
-constexpr int PMAX = CRM_MAX_COV_WIDE + 1;
+constexpr int PMAX = CRM_MAX_COV_XWIDE + 1;
 
 __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const double* __restrict__ Gext,
                                                         int KT) {
@@ -560,9 +560,9 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
     const int KT = a.k0 + a.c + 2;
     const int P = a.c + 1;
     const size_t fin_lds = sizeof(double) * ((size_t)P * P + P + 2 * (size_t)a.k0 * P + a.k0);
-    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV_WIDE || KT > 144 || fin_lds > 150 * 1024) {
+    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV_XWIDE || KT > 144 || fin_lds > 150 * 1024) {
         set_error("assemble: k0=%d, c=%d outside the supported range (k0 <= %d, c <= %d, k0 + c + 2 <= 144, "
-                  "(c+1)(2 k0 + c + 2) <= 19000)", a.k0, a.c, CRM_MAX_K0, CRM_MAX_COV_WIDE);
+                  "(c+1)(2 k0 + c + 2) <= 19000)", a.k0, a.c, CRM_MAX_K0, CRM_MAX_COV_XWIDE);
         return CRM_ERR_UNSUPPORTED;
     }
     const int ts = (KT + 15) / 16;

@@ -106,10 +106,11 @@ struct crm_ctx {
     double kr_flops = 0.0;
     // scan workspace (grown on demand, reused across calls)
     crm::DevBuf ws_T, ws_A, ws_Gb, ws_Gx, ws_Gs, ws_G2, ws_GG, ws_Gt, ws_Z, ws_small, ws_probs, ws_F, ws_Gext, ws_TH, ws_AH, ws_XG;
+    crm::DevBuf ws_xwide;  // scratch of the 63..128-column null-fit kernel (nullfit_xwide.hip)
     crm::DevBuf ws_Tcut;   // rotations: the few small products taken out of the batched launch (cut along the contraction axis)
     crm::DevBuf ws_Gk, ws_S, ws_S2;   // kinship-structure route: the block in donor order, the per-donor sums (step 6 / step 3)
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&sync_counters, &ws_Tcut, &ws_S, &ws_S2, &ws_Gk, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gx, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&sync_counters, &ws_xwide, &ws_Tcut, &ws_S, &ws_S2, &ws_Gk, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gx, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };
 

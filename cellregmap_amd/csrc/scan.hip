@@ -992,10 +992,16 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         return CRM_ERR_UNSUPPORTED;
     }
     struct InScan { crm_ctx* c; explicit InScan(crm_ctx* c_) : c(c_) { c->in_scan = true; } ~InScan() { c->in_scan = false; } } in_scan(ctx);
-    if (g0->c > CRM_MAX_COV_WIDE) {
-        set_error("interaction scan: %d covariate columns (supported up to %d; the association scans and LMM fits take up to %d)",
-                  g0->c, CRM_MAX_COV_WIDE, CRM_MAX_COV_XWIDE);
-        return CRM_ERR_UNSUPPORTED;
+    {
+        // (the Gram kernel's register tiles reach 144 rows, the finalisation keeps (c + 1)(2 k0 + c + 2) doubles in LDS:
+        // refused here, before anything is launched, with the limit named)
+        const long Pq = g0->c + 1;
+        if (g0->k0 + g0->c + 2 > 144 || sizeof(double) * (Pq * Pq + Pq + 2 * g0->k0 * Pq + g0->k0) > 150 * 1024) {
+            set_error("interaction scan: %d contexts with %d covariate columns (supported: contexts + covariates + 2 <= 144 and "
+                      "(c + 1)(2 k0 + c + 2) <= 19000; the association scans take up to %d covariate columns)",
+                      g0->k0, g0->c, CRM_MAX_COV_XWIDE);
+            return CRM_ERR_UNSUPPORTED;
+        }
     }
     if (ctx->polish && g0->c > CRM_MAX_COV) {
         set_error("interaction scan: the null-fit polish is only built for up to %d covariate columns", CRM_MAX_COV);
@@ -1023,6 +1029,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // device) by running the pair stage of a block -- steps 5 to 11 -- over sub-ranges of its variants, while the stages
     // before it (block copies, rotations and, above all, the per-phenotype null fits, which run twice as fast per variant in
     // launches of 4096 variants as in launches of 2048) keep the full block.
+    if (g0->c > CRM_MAX_COV_WIDE) BLK = std::min(BLK, 512);   // (63 .. 128 covariate columns: the slow null-fit kernel's scratch)
     int pair_cap = BLK;
     if (ng > 1) {
         const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
@@ -1517,6 +1524,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             fa.WW = g->WW.as<double>(); fa.Wy = g->Wy.as<double>(); fa.yy = g->yy;
             fa.gg = d_gg; fa.gy = d_gy + (size_t)gi * BLK; fa.gW = d_gW; fa.ld_gW = ld_gW;
             fa.g_drop = collapsed ? nullptr : d_drop;
+            if (c > CRM_MAX_COV_WIDE) {
+                CRM_TRY(ctx->ws_xwide.ensure(sizeof(double) * nullfit_xwide_scratch_doubles(BLK, nrho, c)));
+                fa.xwide = ctx->ws_xwide.as<double>();
+            }
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             fa.probe = ctx->probe_on ? 1 : 0; fa.probe_x = ctx->probe_x;
             CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));

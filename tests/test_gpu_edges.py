@@ -199,16 +199,37 @@ def test_many_covariates_in_the_interaction_scan():
         assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
 
 
+def test_interaction_scan_with_seventy_covariate_columns():
+    """63 .. 128 fixed-effect columns (as long as contexts + covariates + 2 <= 144): the slower null-fit kernel
+    (nullfit_xwide.hip) under the interaction scan, against the oracle."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    c = _cohort(10, 40, 4, 6, seed=39)                                   # 400 cells
+    rng = np.random.default_rng(3)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 69))], axis=1)   # 70 columns
+    crm = CellRegMap(c.y, c.E, W=W, hK=c.hK)
+    opv, oinfo, ost = OracleCellRegMap(c.y, c.E, W=W, hK=c.hK).scan_interaction(c.G, return_stats=True)
+    pv, info, st = crm.scan_interaction(GenotypePanel(c.G, groups=None), return_stats=True)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert_allclose(st["Q"], ost["Q"], rtol=2e-5)          # (verbatim procedure: the oracle-vs-oracle envelope)
+    assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL), np.c_[pv, opv]
+
+
 def test_unsupported_sizes_fail_loudly():
     from cellregmap_amd import CellRegMap, _lib
 
     c = _cohort(8, 20, 3, 4, seed=35)
     rng = np.random.default_rng(1)
-    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 69))], axis=1)  # 70 independent covariates > 62
-    crm = CellRegMap(c.y, c.E, W=W)
-    with pytest.raises(_lib.CrmError, match="interaction scan: 70 covariate columns"):
-        crm.scan_interaction(c.G)
-    pv, info = crm.scan_association(c.G, progress=False)      # ... which the association scans take (up to 128)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 128))], axis=1)  # 129 covariate columns > 128
+    with pytest.raises(_lib.CrmError, match="covariate columns"):
+        CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
+    c2 = _cohort(8, 20, 60, 4, seed=35)
+    W = np.concatenate([c2.W, rng.normal(size=(c2.y.size, 89))], axis=1)  # 60 contexts + 90 covariates + 2 > 144
+    crm = CellRegMap(c2.y, c2.E, W=W)
+    with pytest.raises(_lib.CrmError, match="contexts \\+ covariates \\+ 2 <= 144"):
+        crm.scan_interaction(c2.G)
+    pv, info = crm.scan_association(c2.G, progress=False)      # ... which the association scans take (up to 128 columns)
     assert np.all(np.isfinite(pv))
     E = rng.normal(size=(c.y.size, 129))                               # 129 contexts > 128
     with pytest.raises(_lib.CrmError, match="contexts"):
