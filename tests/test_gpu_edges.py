@@ -199,6 +199,41 @@ def test_many_covariates_in_the_interaction_scan():
         assert np.all(np.abs(pv - opv) <= P_RTOL * opv + P_ATOL), np.c_[pv, opv]
 
 
+def test_covariates_as_given_through_the_c_abi(monkeypatch):
+    """The Python host hands W to the library as U diag(s) of its thin SVD (mutually orthogonal columns).  A C caller may
+    pass W as it is: crm_gene_create then works through (W'W)^-1 and the eigen-decomposition of W'W (cyclic Jacobi on the
+    c x c Gram matrix) for the projection of the variants and the reference's rank rule.  Same span, same statistics --
+    with the optimum pinned, to 1e-9; a rank-deficient W passed raw is refused with the remedy in the message."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
+
+    c = _cohort(9, 25, 4, 30, seed=40)
+    rng = np.random.default_rng(6)
+    W = np.concatenate([c.W, rng.normal(size=(c.y.size, 3)) + 0.5], axis=1)     # four correlated, non-orthogonal columns
+    G = c.G + 0.1 * rng.normal(size=c.G.shape)
+    G[:, 5] = W @ np.array([1.0, -0.5, 0.25, 2.0])                              # one variant inside span(W)
+    panel = GenotypePanel(G, groups=None)
+    lib, ctx = _lib.load(), _engine._context(0)
+    _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+    try:
+        pv, info, st = CellRegMap(c.y, c.E, W=W, hK=c.hK).scan_interaction(panel, return_stats=True)
+        pvi, infoi = CellRegMap(c.y, c.E, W=W, hK=c.hK).scan_interaction_info(panel)
+        monkeypatch.setattr(CellRegMap, "_fixed_effect_basis", lambda self: self._W)
+        raw = CellRegMap(c.y, c.E, W=W, hK=c.hK)
+        pv2, info2, st2 = raw.scan_interaction(panel, return_stats=True)
+        pvi2, infoi2 = raw.scan_interaction_info(panel)
+    finally:
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+    assert np.array_equal(info["rho1"], info2["rho1"])
+    assert np.array_equal(infoi["model_flags"], infoi2["model_flags"]) and infoi["model_flags"][5] & 4
+    assert_allclose(st2["lml"] - st["lml"], (st2["lml"] - st["lml"])[0], atol=1e-8)   # (log|X'X| differs by the basis: a constant)
+    assert_allclose(st2["Q"], st["Q"], rtol=1e-9)
+    assert np.all(np.abs(pv2 - pv) <= 2e-6 * pv + P_ATOL)
+    Wdef = np.concatenate([W, W[:, [1]] - W[:, [2]]], axis=1)                           # rank 4, five columns, passed raw
+    monkeypatch.setattr(CellRegMap, "_fixed_effect_basis", lambda self: self._W)
+    with pytest.raises(_lib.CrmError, match="orthogonal basis of span"):
+        CellRegMap(c.y, c.E, W=Wdef, hK=c.hK).scan_interaction(panel)
+
+
 def test_interaction_scan_with_seventy_covariate_columns():
     """63 .. 128 fixed-effect columns (as long as contexts + covariates + 2 <= 144): the slower null-fit kernel
     (nullfit_xwide.hip) under the interaction scan, against the oracle."""
