@@ -39,6 +39,14 @@ def _logistic(x):
 
 
 def _rsolve(A, b):
+    """The fixed effects' solve.  glimix-core routes it through numpy_sugar.linalg.rsolve, a truncated ``lstsq``; which
+    ``rcond`` that wrapper passes is NOT recoverable here (recalled as sqrt(eps), i.e. singular values of X'K^-1X below
+    1.5e-8 of the largest are cut; the reference's own in-tree twin, cellregmap/_math.py:33-37, uses ``rcond=None`` = eps
+    times the dimension).  The two only differ for a direction of [W, g] whose singular value is below ~1e-4 of the largest
+    -- covariates on wildly different scales, or a variant collinear with W to seven digits -- and nothing in the
+    reference's tests reaches there; this restatement takes ``rcond=None`` like the in-tree twin.  Consequence worth
+    knowing: a direction between sqrt(eps) (economic_svd's absolute rule, which decides the rank and
+    the degrees of freedom) and that relative cut-off is counted in df while its beta is zeroed."""
     return np.linalg.lstsq(A, b, rcond=None)[0]
 
 
