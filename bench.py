@@ -85,6 +85,130 @@ def _launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_record(lib, ctx, crm, config, kr_ms, kr_n, kr_fl, elapsed):
+    """The `roofline` object of the line: the dominant kernel's executed flops over its duration by HIP events on the
+    library's stream (crm_kernel_timer_*), against the FP64-MFMA peak; its L2-fabric traffic from the committed PMC profile of
+    the same launch shape and kernel form, else null.  Returns (roofline, donors of the kinship structure in use)."""
+    # ---- roofline of the dominant kernel (Khatri-Rao contraction, FP64 MFMA bound) ----------
+    kr_s = kr_ms * 1e-3
+    achieved = kr_fl / kr_s * 1e-12 if kr_s > 0 else 0.0
+    kin_groups = lib.crm_background_kinship_groups(crm._bg.handle) if os.environ.get("CRM_KIN_ROUTE", "1") != "0" else 0
+    if kin_groups:
+        kernel = ("gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>: A~ = MixK(rho*)' S for every variant of a block, one launch per "
+                  "block (a plain K x (variants k0) x r product, K = k1 + donors k2 rows of per-donor sums S = [E1'(g o E0) over all "
+                  "cells ; us'(g o E0) donor by donor] against the mixing matrix with the donor-level kinship factor folded in; "
+                  "LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route (DESIGN.md 6c); "
+                  "achieved = its executed flops 2 K r* k0 per variant / its duration by HIP events on the library's stream")
+    else:
+        kernel = ("gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
+                  "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
+                  "+ gemm_tn_glds_kernel<true, KRQ, ECQ, false, 160> over the last 128 + r mod 128 columns when r mod 128 <= 32 "
+                  "(cfg3: 38 x 128 + 136 of r = 5000); achieved / avg_launch_ms cover both launches of a block")
+    roofline = {
+        "bound": "mfma", "kernel": kernel,
+        "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+        "launches": int(kr_n), "avg_launch_ms": round(kr_ms / max(kr_n, 1), 3),
+        "flops_per_launch": kr_fl / max(kr_n, 1),
+        "share_of_step_time": round(kr_s / elapsed, 4),
+    }
+    if roofline["share_of_step_time"] < 0.5:
+        # (side records only -- cfg2, mode B: short spectra leave the step spread over several kernels; the default cfg3
+        # line has this kernel at two thirds of the step)
+        roofline["dominant"] = False
+        roofline["note"] = ("the timed kernel is the route's largest single product but takes less than half of the step at "
+                            "this configuration; the kernel-stats profile of the same configuration shows the spread")
+    # L2-fabric traffic of that kernel is NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes,
+    # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
+    # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
+    form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
+            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
+            "kinship_route": bool(kin_groups), "tile_band": int(os.environ.get("CRM_TILE_BAND", "8") or 0)}
+    roofline["kernel_form"] = form
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            shape = pmc["launch_shape"]
+            same_form = {"kinship_route": False, **pmc.get("kernel_form", {"contraction_sync": True, "tail_launch": True,
+                                                                           "library": "0.1.0"})} == form
+            if (config == shape["config"] and roofline["launches"] > 0 and same_form
+                    and abs(roofline["flops_per_launch"] / shape["flops_per_launch"] - 1.0) < 0.05):
+                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, fabric side incl. Infinity Cache)"
+                roofline["traffic_source"] = (f"EARLIER PROFILE, not this run: profiles/{name} "
+                                              f"({pmc.get('collected_on', 'rocprofv3 --pmc')})")
+                roofline["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_launch"]
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    if roofline["traffic"] is None:
+        roofline["traffic_note"] = "no committed PMC profile matches this launch shape and kernel form"
+    return roofline, kin_groups
+
+
+def cpu_baseline_leg(crm, cohort, Ls, n, sample_of, G_weak, G_full, pv_dense, cpu_variants, cpu_repeats, multi_keep, config4):
+    """`cpu_baseline`: the oracle (the reference-shaped per-variant loop: 11 LMM fits redoing the rotations, QSCov / PMat /
+    ScoreStatistic, eigvalsh, Davies) timed on this host on a seeded random sample of the variants the GPU scanned, median
+    of a few repeats; bound to the decompositions the device built.  Also checks (gene, variant) pairs of the
+    config-4 leg against the oracle (into config4["oracle_check"]).  The only place of this script that touches oracle/."""
+    from oracle.crm import OracleCellRegMap
+
+    qs = {}
+    for i, rho in enumerate(crm._rho1):
+        Q0, S0 = crm._bg.read(i, n)
+        qs[rho] = ((Q0,), S0)
+    ocrm = OracleCellRegMap.__new__(OracleCellRegMap)
+    ocrm._polish = False
+    ocrm._y, ocrm._E0, ocrm._W, ocrm._E1 = cohort.y, cohort.E, cohort.W, cohort.E
+    ocrm._Ls, ocrm._rho, ocrm._half, ocrm._qs = Ls, list(crm._rho1), {}, qs
+    m = cpu_variants
+    pick = np.sort(np.random.default_rng(2024).choice(sample_of, size=m, replace=False))
+    Gs = np.ascontiguousarray(G_weak[:, pick])
+    ocrm.scan_interaction(Gs[:, :1])  # warm-up variant, discarded
+    times = []
+    for _ in range(max(1, cpu_repeats)):
+        t0 = time.time()
+        opv, _ = ocrm.scan_interaction(Gs)
+        times.append(time.time() - t0)
+    t_cpu = float(np.median(times))
+    import threadpoolctl
+
+    blas = threadpoolctl.threadpool_info()
+    nthreads = max([b.get("num_threads", 1) for b in blas] or [1])
+    dev = np.abs(opv - pv_dense[pick]) / np.maximum(opv, 1e-300)
+    # (gene, variant) pairs of the config-4 leg against the oracle (other phenotypes, same decomposition)
+    c4_check = None
+    if multi_keep is not None:
+        import copy
+
+        mpv_, mrho_, ys, whole_ = multi_keep
+        Gsrc = G_full if whole_ else G_weak
+        prng = np.random.default_rng(4)
+        worst, pairs, same_rho = 0.0, 0, True
+        for gi in sorted({1, len(ys) // 2, len(ys) - 1}):
+            cols_ = np.sort(prng.choice(mpv_.shape[1], size=3, replace=False))
+            og = copy.copy(ocrm)
+            og._y = ys[gi]
+            gp, ginfo = og.scan_interaction(np.ascontiguousarray(Gsrc[:, cols_]))
+            worst = max(worst, float(np.max(np.abs(gp - mpv_[gi, cols_]) / np.maximum(gp, 1e-300))))
+            same_rho = same_rho and bool(np.array_equal(ginfo["rho1"], mrho_[gi, cols_]))
+            pairs += len(cols_)
+        c4_check = {"pairs": pairs, "max_rel_dp_vs_oracle": worst, "rho_star_identical": same_rho}
+        if config4 is not None:
+            config4["oracle_check"] = c4_check
+    cpu = {
+        "value": round(m / t_cpu, 4), "unit": "variant-tests/s", "cores": int(nthreads), "kind": "port",
+        "cores_note": ("threads of the host BLAS as this run used them: OpenBLAS caps its pool (64 in this image) below "
+                       "the host's %d logical cpus" % (os.cpu_count() or 0)),
+        "sample": f"{m} variants drawn at random (seed 2024) from the {sample_of} this run scanned, "
+                  f"median of {len(times)} repeats ({', '.join('%.1f s' % t for t in times)}); scan only (decomposition "
+                  f"shared with the GPU run); host has {os.cpu_count()} logical cpus",
+        "threadpools": [{k: b.get(k) for k in ("user_api", "internal_api", "num_threads", "version")} for b in blas],
+        "max_rel_dp_vs_gpu": float(dev.max()),
+    }
+    return cpu
+
+
 class Comm:
     """The process group the bench talks through.  ``nccl`` (= RCCL over xGMI) is the one the contract asks for; a ``gloo``
     group over the same ranks is created beside it and takes over -- for every later collective -- if the first RCCL
@@ -460,60 +584,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (Khatri-Rao contraction, FP64 MFMA bound) ----------
-    kr_s = kr_ms.value * 1e-3
-    achieved = kr_fl.value / kr_s * 1e-12 if kr_s > 0 else 0.0
-    kin_groups = lib.crm_background_kinship_groups(crm._bg.handle) if os.environ.get("CRM_KIN_ROUTE", "1") != "0" else 0
-    if kin_groups:
-        kernel = ("gemm_tn_glds_kernel<false, 1, 0, false, 128, 1>: A~ = MixK(rho*)' S for every variant of a block, one launch per "
-                  "block (a plain K x (variants k0) x r product, K = k1 + donors k2 rows of per-donor sums S = [E1'(g o E0) over all "
-                  "cells ; us'(g o E0) donor by donor] against the mixing matrix with the donor-level kinship factor folded in; "
-                  "LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route (DESIGN.md 6c); "
-                  "achieved = its executed flops 2 K r* k0 per variant / its duration by HIP events on the library's stream")
-    else:
-        kernel = ("gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
-                  "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
-                  "+ gemm_tn_glds_kernel<true, KRQ, ECQ, false, 160> over the last 128 + r mod 128 columns when r mod 128 <= 32 "
-                  "(cfg3: 38 x 128 + 136 of r = 5000); achieved / avg_launch_ms cover both launches of a block")
-    roofline = {
-        "bound": "mfma", "kernel": kernel,
-        "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
-        "launches": int(kr_n.value), "avg_launch_ms": round(kr_ms.value / max(kr_n.value, 1), 3),
-        "flops_per_launch": kr_fl.value / max(kr_n.value, 1),
-        "share_of_step_time": round(kr_s / elapsed, 4),
-    }
-    if roofline["share_of_step_time"] < 0.5:
-        # (side records only -- cfg2, mode B: short spectra leave the step spread over several kernels; the default cfg3
-        # line has this kernel at two thirds of the step)
-        roofline["dominant"] = False
-        roofline["note"] = ("the timed kernel is the route's largest single product but takes less than half of the step at "
-                            "this configuration; the kernel-stats profile of the same configuration shows the spread")
-    # L2-fabric traffic of that kernel is NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes,
-    # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
-    # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
-    form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
-            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
-            "kinship_route": bool(kin_groups), "tile_band": int(os.environ.get("CRM_TILE_BAND", "8") or 0)}
-    roofline["kernel_form"] = form
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            shape = pmc["launch_shape"]
-            same_form = {"kinship_route": False, **pmc.get("kernel_form", {"contraction_sync": True, "tail_launch": True,
-                                                                           "library": "0.1.0"})} == form
-            if (args.config == shape["config"] and roofline["launches"] > 0 and same_form
-                    and abs(roofline["flops_per_launch"] / shape["flops_per_launch"] - 1.0) < 0.05):
-                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, fabric side incl. Infinity Cache)"
-                roofline["traffic_source"] = (f"EARLIER PROFILE, not this run: profiles/{name} "
-                                              f"({pmc.get('collected_on', 'rocprofv3 --pmc')})")
-                roofline["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_launch"]
-                break
-        except (OSError, KeyError, ValueError):
-            pass
-    if roofline["traffic"] is None:
-        roofline["traffic_note"] = "no committed PMC profile matches this launch shape and kernel form"
+    roofline, kin_groups = roofline_record(lib, ctx, crm, args.config, kr_ms.value, kr_n.value, kr_fl.value, elapsed)
     rstar = float(np.mean([ranks[int(round(x * 10))] if len(ranks) > 1 else ranks[0] for x in rho1[: min(steps, weak_blocks) * batch]]))
     f_alg = algorithmic_flops(n, ranks, rstar, k0, c_cov)
     kin = None
@@ -553,65 +624,11 @@ def main():
                      "note": "exact rearrangement onto per-donor tables; general G uses the dense path"}
         pv[:] = pv_dense
 
-    # ---- CPU baseline: the oracle (reference-shaped per-variant loop) on this host: a seeded random sample of the
-    #      variants this run scanned, median of a few repeats -------------
+    # ---- CPU baseline: the oracle on this host's cores, a bounded sample (rank 0, N = 1 only) ------------------------
     cpu = None
     if args.cpu_variants > 0 and world == 1:
-        from oracle.crm import OracleCellRegMap
-
-        qs = {}
-        for i, rho in enumerate(crm._rho1):
-            Q0, S0 = crm._bg.read(i, n)
-            qs[rho] = ((Q0,), S0)
-        ocrm = OracleCellRegMap.__new__(OracleCellRegMap)
-        ocrm._polish = False
-        ocrm._y, ocrm._E0, ocrm._W, ocrm._E1 = cohort.y, cohort.E, cohort.W, cohort.E
-        ocrm._Ls, ocrm._rho, ocrm._half, ocrm._qs = Ls, list(crm._rho1), {}, qs
-        m = args.cpu_variants
-        pick = np.sort(np.random.default_rng(2024).choice(min(steps, weak_blocks) * batch, size=m, replace=False))
-        Gs = np.ascontiguousarray(G_weak[:, pick])
-        ocrm.scan_interaction(Gs[:, :1])  # warm-up variant, discarded
-        times = []
-        for _ in range(max(1, args.cpu_repeats)):
-            t0 = time.time()
-            opv, _ = ocrm.scan_interaction(Gs)
-            times.append(time.time() - t0)
-        t_cpu = float(np.median(times))
-        import threadpoolctl
-
-        blas = threadpoolctl.threadpool_info()
-        nthreads = max([b.get("num_threads", 1) for b in blas] or [1])
-        dev = np.abs(opv - pv_dense[pick]) / np.maximum(opv, 1e-300)
-        # (gene, variant) pairs of the config-4 leg against the oracle (other phenotypes, same decomposition)
-        c4_check = None
-        if multi_keep is not None:
-            import copy
-
-            mpv_, mrho_, ys, whole_ = multi_keep
-            Gsrc = G_full if whole_ else G_weak
-            prng = np.random.default_rng(4)
-            worst, pairs, same_rho = 0.0, 0, True
-            for gi in sorted({1, len(ys) // 2, len(ys) - 1}):
-                cols_ = np.sort(prng.choice(mpv_.shape[1], size=3, replace=False))
-                og = copy.copy(ocrm)
-                og._y = ys[gi]
-                gp, ginfo = og.scan_interaction(np.ascontiguousarray(Gsrc[:, cols_]))
-                worst = max(worst, float(np.max(np.abs(gp - mpv_[gi, cols_]) / np.maximum(gp, 1e-300))))
-                same_rho = same_rho and bool(np.array_equal(ginfo["rho1"], mrho_[gi, cols_]))
-                pairs += len(cols_)
-            c4_check = {"pairs": pairs, "max_rel_dp_vs_oracle": worst, "rho_star_identical": same_rho}
-            if config4 is not None:
-                config4["oracle_check"] = c4_check
-        cpu = {
-            "value": round(m / t_cpu, 4), "unit": "variant-tests/s", "cores": int(nthreads), "kind": "port",
-            "cores_note": ("threads of the host BLAS as this run used them: OpenBLAS caps its pool (64 in this image) below "
-                           "the host's %d logical cpus" % (os.cpu_count() or 0)),
-            "sample": f"{m} variants drawn at random (seed 2024) from the {min(steps, weak_blocks) * batch} this run scanned, "
-                      f"median of {len(times)} repeats ({', '.join('%.1f s' % t for t in times)}); scan only (decomposition "
-                      f"shared with the GPU run); host has {os.cpu_count()} logical cpus",
-            "threadpools": [{k: b.get(k) for k in ("user_api", "internal_api", "num_threads", "version")} for b in blas],
-            "max_rel_dp_vs_gpu": float(dev.max()),
-        }
+        cpu = cpu_baseline_leg(crm, cohort, Ls, n, min(steps, weak_blocks) * batch, G_weak, G_full, pv_dense, args.cpu_variants,
+                               args.cpu_repeats, multi_keep, config4)
     out = {
         "metric": "variant-tests/sec (interaction test)",
         "value": round(value, 2), "unit": "variant-tests/s", "n_gpus": world, "steps": steps, "warmup": warmup,
