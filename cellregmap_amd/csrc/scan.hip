@@ -2017,10 +2017,17 @@ static int scan_core(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         ~Quiet() { c->progress_muted = false; }
     } quiet(ctx);
     ctx->dense_repeats += (long)near.size();
+    // runs of marked variants, neighbours closer than 32 variants merged (a dense pass has a fixed cost of a few
+    // milliseconds whatever its length); a panel that is marked on more than a quarter of its variants is simply scanned
+    // again as a whole
+    if ((long)near.size() * 4 > count) {
+        near.resize((size_t)count);
+        for (long v = 0; v < count; v++) near[(size_t)v] = v;
+    }
     for (size_t i = 0; i < near.size();) {
         size_t j = i + 1;
-        while (j < near.size() && near[j] == near[j - 1] + 1) j++;
-        const long off = near[i], len = (long)(j - i);
+        while (j < near.size() && near[j] <= near[j - 1] + 32) j++;
+        const long off = near[i], len = near[j - 1] - near[i] + 1;
         std::vector<ScanOut> shifted(outs);
         for (ScanOut& o : shifted) {
             auto at = [&](double* p, long stride) { return p ? p + off * stride : nullptr; };
