@@ -382,15 +382,24 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_glds_kernel(c
                                                                long split_stride, int k0) {
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
-    const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
-    int tm = tile % mtiles_max, tn = tile / mtiles_max;
+    // The grid is sized for the largest problem of the launch; every problem numbers ITS OWN tiles 0 .. mt_p * nt_p - 1 and
+    // spreads them over the 8 XCDs by itself (workgroup b runs on XCD b & 7 whatever the problem).  Numbered against the
+    // largest problem's tile count instead, the real tiles of a small problem sit at the start of each band and whole XCDs
+    // get none of them: a multi-phenotype pass, whose (variant, rho*) groups differ in size by an order of magnitude, ran its
+    // MixK products at 57 TFLOP/s against 73 for one phenotype.
+    const int mt_p = (P.M + GEMM_BM - 1) / GEMM_BM, nt_p = (P.N + BN - 1) / BN;
+    const int nwg_p = mt_p * nt_p;
+    (void)mtiles_max;
+    if ((int)blockIdx.x >= nwg_p) return;
+    const int tile = xcd_tile_id((int)blockIdx.x, nwg_p);
+    int tm = tile % mt_p, tn = tile / mt_p;
     if constexpr (!KR) {
         // plain products carry the band height of the tile walk in k0 (GemmTune::band): bands of `k0` column tiles of Y,
         // walked column tile first, so that the workgroups in flight on an XCD (a window of consecutive tile numbers)
         // cover a near-square block of the output and share both operands' panels in that XCD's L2
-        if (k0 > 1) {
-            const int per_band = k0 * mtiles_max, band = tile / per_band, left = tile - band * per_band;
-            const int ntiles = (int)gridDim.x / mtiles_max, bh = min(k0, ntiles - band * k0);
+        if (k0 > 1 && nt_p >= 2 * k0) {
+            const int per_band = k0 * mt_p, band = tile / per_band, left = tile - band * per_band;
+            const int bh = min(k0, nt_p - band * k0);
             tn = band * k0 + left % bh;
             tm = left / bh;
         }

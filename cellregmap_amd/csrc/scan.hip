@@ -1033,7 +1033,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     int pair_cap = BLK;
     if (ng > 1) {
         const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
-        const double cap_gb = cap_env && atof(cap_env) > 0 ? atof(cap_env) : 96.0;
+        const double cap_gb = cap_env && atof(cap_env) > 0 ? atof(cap_env) : 128.0;
         const double per_pair = 2.0 * sizeof(double) * g0->k0 * (double)bg->ldq;
         const long most = (long)std::min(nrho, ng) * BLK, least = (long)std::min(nrho, ng) * std::min(BLK, 128);
         pair_cap = (int)std::max<long>(least, std::min<long>(most, (long)(cap_gb * (1ull << 30) / per_pair)));
