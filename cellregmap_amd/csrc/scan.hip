@@ -1025,7 +1025,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     auto_blk = std::max<long>(256, std::min<long>(auto_blk, CRM_MAX_AUTO_BLOCK));
     int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
     // Several phenotypes: the pair-ordered buffers (A~ and, on the routes through H, its gathered operand) grow with the
-    // number of distinct (variant, rho*) pairs, up to min(nrho, ng) per variant.  They are kept within 96 GB (a third of the
+    // number of distinct (variant, rho*) pairs, up to min(nrho, ng) per variant.  They are kept within 128 GB (under half of the
     // device) by running the pair stage of a block -- steps 5 to 11 -- over sub-ranges of its variants, while the stages
     // before it (block copies, rotations and, above all, the per-phenotype null fits, which run twice as fast per variant in
     // launches of 4096 variants as in launches of 2048) keep the full block.
