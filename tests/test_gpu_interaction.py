@@ -235,7 +235,7 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
 
 
-@pytest.mark.parametrize("route", [2, 0])
+@pytest.mark.parametrize("route", [2, 0, "folded"])
 def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
     """Several phenotypes can ask for more (variant, rho*) pairs than the pair-ordered buffers hold (min(11, genes) per
     variant in the worst case): the block keeps its size for the stages before -- the per-phenotype null fits above all --
@@ -246,12 +246,17 @@ def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values, scan_interaction_many
     from cellregmap_amd.synth import make_cohort
 
-    c = make_cohort(8, 30, 4, 700, seed=43)
+    folded = route == "folded"
+    if folded:     # the kinship-structure route with the donor-level factor folded into the mixing matrices (forced: the
+        route = 2  # library folds by itself from 32 columns of us on); another seed keeps this background out of the cache
+        monkeypatch.setenv("CRM_KIN_FOLD", "2")
+    c = make_cohort(8, 30, 4, 700, seed=44 if folded else 43)
     rng = np.random.default_rng(9)
     n = c.y.size
     ys = [c.y, c.y[rng.permutation(n)], rng.normal(size=n), c.y + rng.normal(size=n), c.y[::-1].copy()]
     Ls = get_L_values(c.hK, c.E)
     first = CellRegMap(ys[0], c.E, W=c.W, Ls=Ls)
+    assert (_lib.load().crm_background_kinship_folded(first._bg.handle) > 0) == folded
     crms = [first] + [CellRegMap(y, c.E, W=c.W, Ls=Ls, background=first._bg) for y in ys[1:]]
     G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes
     panel = GenotypePanel(G, groups=None)
