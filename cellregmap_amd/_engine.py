@@ -260,6 +260,22 @@ class BackgroundBuilder:
         E1c = _lib.f64(E1)
         h = ctypes.c_void_p()
         self._halves = B if (isinstance(B, HadamardHalves) or B is not None) else None
+        # (the donor structure of the kinship factor is looked for on the host while the device decomposes, as in
+        # _make_background_hadamard; seal() then finds it in the cache)
+        hK_host = B.hK if isinstance(B, HadamardHalves) else (np.ascontiguousarray(B, dtype=float) if B is not None else None)
+        finder = None
+        if hK_host is not None:
+            finder = threading.Thread(target=_kinship_groups, args=(hK_host,), daemon=True)
+            finder.start()
+        try:
+            self._begin(lib, E1c, B, nrho, flags, rel_tol, h, device)
+        finally:
+            if finder is not None:
+                finder.join()
+        self._bg = _Background(h, self.rho, device)   # (owns the handle from here on)
+        self.nrho = nrho
+
+    def _begin(self, lib, E1c, B, nrho, flags, rel_tol, h, device):
         if isinstance(B, HadamardHalves):
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
                                                 B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.us), B.us.shape[1],
@@ -270,8 +286,6 @@ class BackgroundBuilder:
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], _lib.ptr(Bc),
                                                 0 if Bc is None else Bc.shape[1], None, 0, None, 0, nrho,
                                                 _lib.ptr(self.rho), _lib.ptr(flags), float(rel_tol), ctypes.byref(h)))
-        self._bg = _Background(h, self.rho, device)   # (owns the handle from here on)
-        self.nrho = nrho
 
     def rank(self, i):
         """Rank of an owned grid point after ``begin``; -1 for the others."""
