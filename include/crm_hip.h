@@ -121,7 +121,14 @@ int crm_background_rank(const crm_background* bg, int i);
 int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0);
 
 /* ---- one phenotype bound to a background: y, W (n x c), E0 (n x k0) ------------------
- * (the per-object state of CellRegMap: _y, _W, _E0; _cellregmap.py:64-79). */
+ * (the per-object state of CellRegMap: _y, _W, _E0; _cellregmap.py:64-79).
+ * W: best passed as U diag(s) of its thin SVD with the singular values below sqrt(eps) dropped (numpy_sugar.economic_svd,
+ * the basis glimix-core's LMM holds its covariates in; the scans depend on W through its column space only) -- mutually
+ * orthogonal columns need no arithmetic here.  Other full-rank W is accepted and served through (W'W)^-1; W that is rank
+ * deficient by that rule, or too ill-conditioned for the Gram-matrix route (eigenvalues of W'W spanning more than 1e13),
+ * is refused with CRM_ERR_NUMERIC.  The scans then orthogonalise every block of variants against W in the cell axis and
+ * apply the reference's rank rules to [W, g] (economic_svd in the null fits, lstsq in the projection of the score test).
+ * c <= 128 (the interaction scan: k0 + c + 2 <= 144), k0 <= 128. */
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out);
 void crm_gene_destroy(crm_gene* gene);
