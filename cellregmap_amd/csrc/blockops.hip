@@ -478,6 +478,63 @@ int launch_pair_features(hipStream_t st, const double* H, long ldh, int k1, cons
     return CRM_OK;
 }
 
+// flag[0] |= 1 when H[c, a] differs (bitwise) from Ep[c, a] for some cell c < cells, a < k: are the background's E1 columns
+// the scan's own contexts (the reference's default E1 = E, no context permutation)?
+__global__ void same_columns_kernel(const double* __restrict__ H, long ldh, const double* __restrict__ Ep, long ld_ep,
+                                    long cells, int k, int* __restrict__ flag) {
+    const long c = blockIdx.x;
+    if (c >= cells) return;
+    bool diff = false;
+    for (int a = threadIdx.x; a < k; a += blockDim.x)
+        diff |= __double_as_longlong(H[c * ldh + a]) != __double_as_longlong(Ep[c * ld_ep + a]);
+    if (diff) atomicOr(flag, 1);
+}
+
+int launch_same_columns(hipStream_t st, const double* H, long ldh, const double* Ep, long ld_ep, long cells, int k, int* flag) {
+    if (cells <= 0 || k <= 0) return CRM_OK;
+    hipLaunchKernelGGL(same_columns_kernel, dim3((unsigned)cells), dim3(64), 0, st, H, ldh, Ep, ld_ep, cells, k, flag);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+// S[a, b k0 + i] = C[b, pair(min(a, i), max(a, i))]: the E1 rows from G'(E (x) E) when E1 is E itself (pairs j <= j' in
+// row-major order of the upper triangle, as context_features writes them)
+__global__ void pair_rows_sym_kernel(const double* __restrict__ C, long ldc, int variants, int k0, double* __restrict__ S,
+                                     long lds) {
+    const int a = blockIdx.y;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // b k0 + i
+    if (e >= (long)variants * k0) return;
+    const long b = e / k0;
+    const int i = (int)(e - b * k0);
+    const int lo = a < i ? a : i, hi = a < i ? i : a;
+    const long pidx = (long)lo * k0 - (long)lo * (lo - 1) / 2 + (hi - lo);
+    S[(long)a * lds + e] = C[b * ldc + pidx];
+}
+
+int launch_pair_rows_sym(hipStream_t st, const double* C, long ldc, int variants, int k0, double* S, long lds) {
+    if (variants <= 0 || k0 <= 0) return CRM_OK;
+    dim3 grid((unsigned)(((long)variants * k0 + 255) / 256), (unsigned)k0);
+    hipLaunchKernelGGL(pair_rows_sym_kernel, grid, dim3(256), 0, st, C, ldc, variants, k0, S, lds);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
+// dst[k, j] = src[k, j] * scale[k * ld_scale]  (j < cols): the contexts times the single column of us, donor order
+__global__ void scale_rows_kernel(const double* __restrict__ src, long ld_src, const double* __restrict__ scale, long ld_scale,
+                                  int cols, double* __restrict__ dst, long ld_dst) {
+    const long k = blockIdx.x;
+    const double f = scale[k * ld_scale];
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) dst[k * ld_dst + j] = src[k * ld_src + j] * f;
+}
+
+int launch_scale_rows(hipStream_t st, const double* src, long ld_src, const double* scale, long ld_scale, long rows, int cols,
+                      double* dst, long ld_dst) {
+    if (rows <= 0 || cols <= 0) return CRM_OK;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)rows), dim3(128), 0, st, src, ld_src, scale, ld_scale, cols, dst, ld_dst);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 // S[a, b k0 + i] = C[b, a k0 + i]  (b < variants, a < k1, i < k0): k0-long runs are contiguous on both sides
 __global__ void pair_rows_kernel(const double* __restrict__ C, long ldc, int variants, int k1, int k0,
                                  double* __restrict__ S, long lds) {

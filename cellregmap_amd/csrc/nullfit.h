@@ -115,6 +115,12 @@ int launch_kin_sum_e1(hipStream_t st, const double* S, long ld_s, int KT, int k2
 int launch_pair_features(hipStream_t st, const double* H, long ldh, int k1, const double* Ep, long ld_ep, int k0,
                          long cells_pad, double* P, long ldp);
 int launch_pair_rows(hipStream_t st, const double* C, long ldc, int variants, int k1, int k0, double* S, long lds);
+// are H[:, :k] and Ep[:, :k] the same numbers (flag[0] |= 1 if not)?  and S[a, b k0 + i] = C[b, pair(a, i)] for E1 = E
+int launch_same_columns(hipStream_t st, const double* H, long ldh, const double* Ep, long ld_ep, long cells, int k, int* flag);
+int launch_pair_rows_sym(hipStream_t st, const double* C, long ldc, int variants, int k0, double* S, long lds);
+// dst[k, :cols] = src[k, :cols] * scale[k * ld_scale]
+int launch_scale_rows(hipStream_t st, const double* src, long ld_src, const double* scale, long ld_scale, long rows, int cols,
+                      double* dst, long ld_dst);
 // dense block from a grouped panel: dst[i, b] = Gd[group[row(i)], b]
 int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
                         long cells, const int* row_index, int variants, double* dst, long ld_dst,

@@ -219,9 +219,10 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     const long kfold = k1 + groups * (long)k2, m_pad = round_up(m, GEMM_BK);
     const char* fold_env = getenv("CRM_KIN_FOLD");
     // (k2 >= 32: the folded form launches the per-donor sums for the us columns alone, 64 columns wide -- with few of them,
-    // mode B's single column of ones or config 2's 20, one launch over [us | E1] together and the small contraction over
-    // the donors per block is the better form: cfg3 mode B 205 000 against 168 000 variant-tests/s, config 2 463 000 / 451 000)
-    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && (k2 >= 32 || (fold_env && atoi(fold_env) > 1)) &&
+    // config 2's 20, one launch over [us | E1] together and the small contraction over the donors per block is the better
+    // form: config 2 463 000 against 451 000 variant-tests/s.  k2 == 1 -- mode B, us a single column -- folds too: its us rows
+    // are per-donor sums of the Khatri-Rao rows themselves, a plain batched product, see scan_pass step 6)
+    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && (k2 >= 32 || k2 == 1 || (fold_env && atoi(fold_env) > 1)) &&
         !(fold_env && atoi(fold_env) == 0)) {
         const long kdim = round_up(kfold, GEMM_BK), ldq = bg->ldq, ld_t = round_up(groups, 128);
         ScopedBuf hKdT, probs_dev;
@@ -519,7 +520,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->Wproj, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
-                    &g->dt_Zt, &g->kinEp, &g->kinP})
+                    &g->dt_Zt, &g->kinEp, &g->kinP, &g->kinUE})
         b->release();
     delete g;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
@@ -1308,7 +1309,27 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_TRY(launch_gather_rows(st, d_Ep, g0->ld_ep, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ep,
                                    g0->kinEp.as<double>(), g0->ld_ep));
     }
-    if (e1_pairs) {
+    if (kfold && bg->kin_k2 == 1) {
+        // one column of us: S[(k1 + d'), (b, i)] = sum over the cells of donor d' of us(c) g_b(c) E0(c, i) is the plain product
+        // G_d'' (us o E0)_d' of the donor's own cells -- its (b, i) layout is the row of S as it stands.  kinUE = us o E0 in
+        // donor order.
+        CRM_TRY(g0->kinUE.ensure(sizeof(double) * (size_t)bg->kin_rows * g0->ld_ep));
+        CRM_TRY(launch_scale_rows(st, g0->kinEp.as<double>(), g0->ld_ep, bg->kin_Y.as<double>(), bg->kin_ldy, bg->kin_rows,
+                                  (int)g0->ld_ep, g0->kinUE.as<double>(), g0->ld_ep));
+    }
+    // E1 = E, the reference's default (and no context permutation): the pair features E1_a o E0_i are the symmetric
+    // E_a E_i that the scan holds anyway for E0'diag(g^2)E0 (EE: k0 (k0 + 1) / 2 columns) -- half the product
+    bool e1_sym = false;
+    if (e1_pairs && bg->kin_k1 == k0 && d_EE && !getenv("CRM_KIN_E1_GENERAL")) {
+        int h_flag = 0;
+        int* d_flag = reinterpret_cast<int*>(d_near);
+        CRM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+        CRM_TRY(launch_same_columns(st, bg->H.as<double>(), bg->ldh, d_Ep, g0->ld_ep, n, k0, d_flag));
+        CRM_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        CRM_HIP(hipStreamSynchronize(st));
+        e1_sym = h_flag == 0;
+    }
+    if (e1_pairs && !e1_sym) {
         CRM_TRY(g0->kinP.ensure(sizeof(double) * (size_t)np * ldP));
         CRM_TRY(launch_pair_features(st, bg->H.as<double>(), bg->ldh, bg->kin_k1, d_Ep, g0->ld_ep, k0, np, g0->kinP.as<double>(), ldP));
     }
@@ -1754,6 +1775,11 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 p.Y = bg->kin_Y.as<double>() + bg->kin_row0[d] * bg->kin_ldy; p.ldy = bg->kin_ldy;
                 p.C = S + (size_t)(k1 + d * k2) * ld_ah; p.ldc = ld_ah;
                 p.M = ncol * k0; p.N = k2; p.cells = bg->kin_len[d];
+                if (k2 == 1) {   // plain product G_d'' (us o E0)_d': C[b, i] = row k1 + d' of S at column b k0 + i
+                    p.E = nullptr; p.lde = 0; p.k0 = 0;
+                    p.Y = g0->kinUE.as<double>() + bg->kin_row0[d] * g0->ld_ep; p.ldy = g0->ld_ep;
+                    p.ldc = k0; p.M = ncol; p.N = k0;
+                }
                 maxlen = std::max(maxlen, bg->kin_len[d]);
                 kp[d] = p;
             }
@@ -1766,6 +1792,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 GemmProblem p{};
                 p.X = Gsrc; p.ldx = ldg_k; p.Y = g0->kinP.as<double>(); p.ldy = ldP;
                 p.C = ctx->ws_AH.as<double>(); p.ldc = ldP; p.M = ncol; p.N = k1 * k0;
+                if (e1_sym) { p.Y = d_EE; p.ldy = g0->ld_ee; p.N = npair; }
                 kp[groups] = p;
             }
             for (int sps = 0; sps < fold_split6 && !e1_pairs; sps++) {
@@ -1782,12 +1809,14 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
             CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * (size_t)(groups + std::max(slices, 1)), hipMemcpyHostToDevice, st));
-            CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, k2, maxlen, k0));
+            if (k2 == 1) CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, ncol, k0, maxlen, false, 0, 1, 0));
+            else CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, k2, maxlen, k0));
             if (e1_pairs) {
                 const long p_slab = (long)(std::max<long>(BLK, max_pairs) + 128) * ldP;
-                CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, ncol, k1 * k0, np, false, 0, fold_split6, p_slab));
+                CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, ncol, e1_sym ? npair : k1 * k0, np, false, 0, fold_split6, p_slab));
                 CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), (long)ncol * ldP, fold_split6, p_slab));
-                CRM_TRY(launch_pair_rows(st, ctx->ws_AH.as<double>(), ldP, ncol, k1, k0, S, ld_ah));
+                if (e1_sym) CRM_TRY(launch_pair_rows_sym(st, ctx->ws_AH.as<double>(), ldP, ncol, k0, S, ld_ah));
+                else CRM_TRY(launch_pair_rows(st, ctx->ws_AH.as<double>(), ldP, ncol, k1, k0, S, ld_ah));
             } else {
                 CRM_TRY(launch_kr_transposed(ctx, d_kp + groups, slices, ncol * k0, k1, chunk_max, k0));
                 CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), e1_slab, slices, e1_slab));

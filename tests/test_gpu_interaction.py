@@ -235,6 +235,59 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
 
 
+@pytest.mark.parametrize("hook", ["none", "E", "G"])
+def test_mode_b_on_the_kinship_structure_route(hook):
+    """Mode B (hS = [sqrt(rho) E1, sqrt(1 - rho) hK]) with a donor-expanded hK is the same structure with a single column
+    of ones in the place of us: the folded form then takes the us rows as per-donor sums of the Khatri-Rao rows themselves
+    -- a plain batched product G_d'(us o E0)_d -- and the E1 rows through the pair features.  Against the direct route
+    (optimum pinned) and the oracle, dense full-rank donor-level factor, ragged donors, both hooks, several phenotypes."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, scan_interaction_many
+    from oracle.crm import OracleCellRegMap
+
+    rng = np.random.default_rng(91)
+    donors, k0, p = 11, 6, 45
+    donor = np.repeat(np.arange(donors), rng.integers(9, 50, size=donors))
+    n = donor.size
+    hK = rng.normal(size=(donors, donors))[donor]
+    E = rng.normal(size=(n, k0))
+    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 1))], axis=1)
+    G = rng.normal(size=(n, p))
+    y = 0.5 * G[:, 3] * E[:, 0] + E @ rng.normal(size=k0) * 0.3 + hK @ rng.normal(size=donors) * 0.2 + rng.normal(size=n)
+    idx = rng.permutation(n)
+    hooks = {} if hook == "none" else ({"idx_E": idx} if hook == "E" else {"idx_G": idx})
+    crm = CellRegMap(y, E, W=W, hK=hK)
+    lib, ctx = _lib.load(), _engine._context(0)
+    assert lib.crm_background_kinship_groups(crm._bg.handle) == donors and lib.crm_background_kinship_folded(crm._bg.handle) > 0
+    panel = GenotypePanel(G, groups=None)
+    try:
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
+        try:
+            ppv, pinfo, pst = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+            _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+            pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+        finally:
+            _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
+            _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+        assert np.array_equal(pinfo["rho1"], info0["rho1"])
+        scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
+        assert np.all(np.abs(pst["Q"] - st0["Q"]) <= 1e-9 * scale)
+        assert np.all(np.abs(pst["F"] - st0["F"]) <= 1e-9 * np.abs(st0["F"]).max(axis=(1, 2), keepdims=True))
+        pv, info, st = crm.scan_interaction(panel, return_stats=True, progress=False, **hooks)
+        opv, oinfo, ost = OracleCellRegMap(y, E, W=W, hK=hK).scan_interaction(G, return_stats=True, **hooks)
+        _compare(pv, info, st, opv, oinfo, ost)
+        ys = [y, y[rng.permutation(n)], rng.normal(size=n)]
+        crms = [crm] + [CellRegMap(v, E, W=W, hK=hK, background=crm._bg) for v in ys[1:]]
+        mpv, minfo = scan_interaction_many(crms, panel, **hooks)
+        for i, obj in enumerate(crms):
+            spv, sinfo = obj.scan_interaction(panel, progress=False, **hooks)
+            assert np.array_equal(minfo["rho1"][i], sinfo["rho1"])
+            assert np.all(np.abs(mpv[i] - spv) <= 1e-7 * spv + 1e-13)
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+
+
 @pytest.mark.parametrize("route", [2, 0, "folded"])
 def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
     """Several phenotypes can ask for more (variant, rho*) pairs than the pair-ordered buffers hold (min(11, genes) per
