@@ -526,8 +526,10 @@ int crm_test_eigvalsh(crm_ctx* c, int count, int k, const double* F, double* lam
     CRM_TRY(bP.ensure(sizeof(double) * count));
     CRM_HIP(hipMemcpyAsync(bF.ptr, F, sizeof(double) * (size_t)count * k * k, hipMemcpyHostToDevice, c->stream));
     CRM_HIP(hipMemsetAsync(bQ.ptr, 0, sizeof(double) * count, c->stream));
+    ScopedBuf bS;
+    CRM_TRY(bS.ensure(sizeof(double) * eig_scratch_doubles(count, k)));
     CRM_TRY(launch_eig_davies(c->stream, bF.as<double>(), bQ.as<double>(), count, k, bL.as<double>(),
-                              bP.as<double>(), nullptr, nullptr, true));
+                              bP.as<double>(), nullptr, nullptr, true, bS.as<double>()));
     CRM_HIP(hipMemcpyAsync(lambda, bL.ptr, sizeof(double) * (size_t)count * k, hipMemcpyDeviceToHost, c->stream));
     CRM_HIP(hipStreamSynchronize(c->stream));
     return CRM_OK;

@@ -29,10 +29,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // workgroup per variant; S is staged through LDS in chunks of 64 spectrum entries (scaled on the way
 // in, next chunk prefetched into registers during the MFMAs).  Only the upper triangle of 16x16
 // output tiles is computed; the tiles are dealt round-robin to the four wavefronts, rotated by the
-// block index so that the SIMDs of a CU see the same load.
-template <int NTL>
+// block index so that the SIMDs of a CU see the same load.  NG > 1 (more than 144 rows: the slower form for many contexts +
+// covariates): NG workgroups per variant, workgroup g of them takes the tiles g, g + NG, ... of the list -- every one
+// stages all rows, the accumulators of a wavefront stay within its registers.
+template <int NTL, int NG = 1>
 __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* __restrict__ Gext, int KT) {
-    constexpr int ROWS = 16 * NTL, NTILES = NTL * (NTL + 1) / 2, MAXT = (NTILES + 3) / 4, RPT = ROWS / 4;
+    constexpr int ROWS = 16 * NTL, NTILES = NTL * (NTL + 1) / 2, NLOC = (NTILES + NG - 1) / NG, MAXT = (NLOC + 3) / 4,
+                  RPT = ROWS / 4;
     extern __shared__ double Ss[];  // [ROWS][SLD]
     __shared__ int tile_ij[NTILES];
     __shared__ const double* tail_ptr[CRM_MAX_COV_XWIDE + 2];
@@ -48,10 +51,10 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     const int l15 = lane & 15, lq = lane >> 4;
     const int k0 = a.k0, c = a.c;
 
-    if (tid < NTILES) {
-        int ti = 0, rem = tid;
+    for (int e = tid; e < NTILES; e += 256) {
+        int ti = 0, rem = e;
         while (rem >= NTL - ti) { rem -= NTL - ti; ti++; }
-        tile_ij[tid] = ti | ((ti + rem) << 8);
+        tile_ij[e] = ti | ((ti + rem) << 8);
     }
     if (tid < c + 2) {
         const double* p;
@@ -61,13 +64,15 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
         tail_ptr[tid] = p;
     }
     __syncthreads();
-    // tiles of this wavefront: idx = first, first + 4, ... (MAXT or MAXT - 1 of them)
+    // tiles of this wavefront: the entries first, first + 4, ... of this workgroup's list (MAXT or MAXT - 1 of them)
+    const int grp = NG > 1 ? (int)blockIdx.y : 0;
     const int first = (wave + b) & 3;
-    const int ntw = (NTILES - first + 3) / 4;
+    const int nloc = (NTILES - grp + NG - 1) / NG;
+    const int ntw = (nloc - first + 3) / 4;
     int t_i[MAXT], t_j[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
-        const int idx = first + 4 * t;
+        const int idx = grp + NG * (first + 4 * t);
         const int ij = tile_ij[idx < NTILES ? idx : 0];
         t_i[t] = ((ij & 255) * 16 + l15) * SLD + lq;
         t_j[t] = ((ij >> 8) * 16 + l15) * SLD + lq;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     double* __restrict__ out = Gext + (long)b * KT * KT;
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
-        const int idx = first + 4 * t;
+        const int idx = grp + NG * (first + 4 * t);
         if (idx >= NTILES) continue;
         const int ij = tile_ij[idx];
         const int ri = (ij & 255) * 16, cj = (ij >> 8) * 16;
@@ -367,17 +372,21 @@ __global__ __launch_bounds__(256) void gram_ext_dma_kernel(AssembleArgs a, doubl
 constexpr int PMAX = CRM_MAX_COV_XWIDE + 1;
 
 __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const double* __restrict__ Gext,
-                                                        int KT) {
+                                                        int KT, double* __restrict__ rows) {
     // per variant: everything below is k0- or (c+1)-sized; LDS carved from the dynamic segment:
-    // L [P][P] (Cholesky factor of X'K^-1X), xky [P], dkx [k0][P] (D'K^-1X), sol [k0][P], uvec [k0]
+    // L [P][P] (Cholesky factor of X'K^-1X), xky [P], uvec [k0], vv, ww [P] each, then dkx [k0][P] (D'K^-1X) and
+    // sol [k0][P] -- or, when those two do not fit (many contexts x many covariates), in `rows` (global memory,
+    // 2 k0 P doubles per variant: the slower form)
     extern __shared__ double fsm[];
     __shared__ int ok_flag, keep_flag;
     const int Pd = a.c + 1;
     double* Lm = fsm;
     double* xky = Lm + Pd * Pd;
-    double* dkxm = xky + Pd;
+    double* uvec = xky + Pd;
+    double* vv = uvec + a.k0;
+    double* ww = vv + Pd;
+    double* dkxm = rows ? rows + (size_t)blockIdx.x * 2 * a.k0 * Pd : ww + Pd;
     double* solm = dkxm + a.k0 * Pd;
-    double* uvec = solm + a.k0 * Pd;
 #define L(i, j) Lm[(i) * Pd + (j)]
 #define dkx(j, i) dkxm[(j) * Pd + (i)]
 #define sol(j, i) solm[(j) * Pd + (i)]
@@ -434,8 +443,6 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
             // K-metric regression of x on W' -- s / (1 + |a + b|^2) with s the Schur complement (last pivot squared);
             // largest one: a few power iterations through the factor.  Cutting that direction leaves the projection of W
             // alone (to the order of the singular-value ratio).
-            double* vv = dkxm;           // scratch [P] + [P]: dkxm and solm are adjacent, 2 k0 P >= 2 P doubles, and are
-            double* ww = dkxm + P;       // only filled after the barrier below
             double nrm2 = 1.0;
             {
                 // b = L_WW^-T L(c, 0..c-1)'
@@ -555,14 +562,23 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
 
 }  // namespace
 
-int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext) {
+size_t assemble_rows_scratch_doubles(int variants, int k0, int c) {
+    const size_t P = (size_t)c + 1;
+    const size_t lds = sizeof(double) * (P * P + 3 * P + k0 + 2 * (size_t)k0 * P);
+    return lds > 150 * 1024 ? (size_t)variants * 2 * k0 * P : 0;
+}
+
+int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext, double* fin_rows) {
     if (variants <= 0) return CRM_OK;
     const int KT = a.k0 + a.c + 2;
     const int P = a.c + 1;
-    const size_t fin_lds = sizeof(double) * ((size_t)P * P + P + 2 * (size_t)a.k0 * P + a.k0);
-    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV_XWIDE || KT > 144 || fin_lds > 150 * 1024) {
-        set_error("assemble: k0=%d, c=%d outside the supported range (k0 <= %d, c <= %d, k0 + c + 2 <= 144, "
-                  "(c+1)(2 k0 + c + 2) <= 19000)", a.k0, a.c, CRM_MAX_K0, CRM_MAX_COV_XWIDE);
+    const size_t fin_small = sizeof(double) * ((size_t)P * P + 3 * P + a.k0);
+    size_t fin_lds = fin_small + sizeof(double) * 2 * (size_t)a.k0 * P;
+    const bool rows_global = fin_lds > 150 * 1024;
+    if (rows_global) fin_lds = fin_small;
+    if (a.k0 > CRM_MAX_K0 || a.c > CRM_MAX_COV_XWIDE || KT > CRM_MAX_GRAM_ROWS || (rows_global && !fin_rows)) {
+        set_error("assemble: k0=%d, c=%d outside the supported range (k0 <= %d, c <= %d, k0 + c + 2 <= %d)", a.k0, a.c,
+                  CRM_MAX_K0, CRM_MAX_COV_XWIDE, CRM_MAX_GRAM_ROWS);
         return CRM_ERR_UNSUPPORTED;
     }
     const int ts = (KT + 15) / 16;
@@ -595,17 +611,28 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         hipLaunchKernelGGL(gram_ext_kernel<NTL>, dim3(variants), dim3(256), lds, st, a, Gext, KT);            \
     } while (0)
+#define CRM_GRAM_GROUPS(NTL, NG)                                                                              \
+    do {                                                                                                      \
+        const size_t lds = sizeof(double) * 16 * NTL * SLD;                                                   \
+        CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_ext_kernel<NTL, NG>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL((gram_ext_kernel<NTL, NG>), dim3(variants, NG), dim3(256), lds, st, a, Gext, KT);  \
+    } while (0)
     if (dma) {
     } else if (ts <= 2) CRM_GRAM(2);
     else if (ts <= 4) CRM_GRAM(4);
     else if (ts <= 6) CRM_GRAM(6);
-    else CRM_GRAM(9);
+    else if (ts <= 9) CRM_GRAM(9);
+    else if (ts <= 12) CRM_GRAM_GROUPS(12, 2);
+    else if (ts <= 15) CRM_GRAM_GROUPS(15, 4);
+    else CRM_GRAM_GROUPS(18, 4);
 #undef CRM_GRAM
+#undef CRM_GRAM_GROUPS
     CRM_HIP(hipGetLastError());
     if (fin_lds > 60 * 1024)
         CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&finalize_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-    hipLaunchKernelGGL(finalize_kernel, dim3(variants), dim3(128), fin_lds, st, a, Gext, KT);
+    hipLaunchKernelGGL(finalize_kernel, dim3(variants), dim3(128), fin_lds, st, a, Gext, KT, rows_global ? fin_rows : nullptr);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

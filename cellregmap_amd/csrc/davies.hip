@@ -396,13 +396,17 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
                                                          double* __restrict__ lambda_out,
                                                          double* __restrict__ pv_out,
                                                          int* __restrict__ ifault_out,
-                                                         double* __restrict__ liu_out, int do_eig) {
+                                                         double* __restrict__ liu_out, int do_eig,
+                                                         double* __restrict__ scratch) {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int ks = k | 1;
-    double* A = sm;               // k * ks
-    double* ev = A + (long)k * ks;  // k
+    // the working copy of F: in LDS, or -- more than 128 contexts, the slower form -- in global memory (one wavefront per
+    // matrix: the barriers below order its accesses)
+    const bool a_global = k > 128;                             // (the launcher's rule)
+    double* A = a_global ? scratch + (size_t)b * k * ks : sm;  // k * ks  (touched only with do_eig)
+    double* ev = a_global ? sm : sm + (long)k * ks;            // k
     double* kept = ev + k;        // k
     double* rc = kept + k;        // k/2+1 cos
     double* rs = rc + (k / 2 + 1);  // k/2+1 sin
@@ -584,8 +588,10 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
 
 }  // namespace
 
+size_t eig_scratch_doubles(int count, int k) { return k > 128 ? (size_t)count * k * (k | 1) : 0; }
+
 int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int count, int k,
-                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig) {
+                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig, double* scratch) {
     if (count <= 0) return CRM_OK;
     if (k < 1 || k > CRM_MAX_K0) {
         set_error("eigen/Davies: k0=%d (supported 1..%d)", k, CRM_MAX_K0);
@@ -594,10 +600,15 @@ int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int coun
     const int ks = k | 1;
     // A [k x ks], ev [k], kept [k] (doubles as the tridiagonal's diagonal), rc/rs [2*(k/2+1)] (its
     // sub-diagonal), then 2k doubles for the Householder vectors
-    size_t lds = sizeof(double) * ((size_t)k * ks + 2 * k + 2 * (k / 2 + 1) + 2 * k);
+    const bool global_copy = k > 128;
+    if (global_copy && do_eig && !scratch) {
+        set_error("eigen/Davies: k0=%d needs the global-memory work space", k);
+        return CRM_ERR_ARG;
+    }
+    size_t lds = sizeof(double) * ((global_copy ? 0 : (size_t)k * ks) + 2 * k + 2 * (k / 2 + 1) + 2 * k);
     lds = (lds + 15) / 16 * 16;
     hipLaunchKernelGGL(eig_davies_kernel, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
-                       ifault, liu, do_eig ? 1 : 0);
+                       ifault, liu, do_eig ? 1 : 0, global_copy ? scratch : nullptr);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

@@ -40,10 +40,12 @@ typedef const double __attribute__((address_space(1))) * gptr_t;   // global (no
 typedef const v2d __attribute__((address_space(1))) * gptr2_t;
 
 // KRQ: 8-byte prefetch slots per thread for the G tile of the Khatri-Rao operand
-template <bool KR, int KRQ, int BN>
-__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
+// EW: 1 = context tiles of up to 128 columns; 2 = up to 256 (the slower form for 129 .. 256 contexts, one workgroup per CU)
+// transposed: store C' (N x M, leading dimension ldc)
+template <bool KR, int KRQ, int BN, int EW = 1>
+__global__ __launch_bounds__(256, (EW == 2 ? 1 : BN == 64 ? 3 : 2)) void gemm_tn_kernel(const GemmProblem* __restrict__ probs,
                                                           int mtiles_max, long cells_per_split, long cells_total,
-                                                          long split_stride, int k0) {
+                                                          long split_stride, int k0, int transposed) {
     extern __shared__ __align__(16) double smem[];
     const GemmProblem P = probs[blockIdx.z];
     const int tile = xcd_tile_id((int)blockIdx.x, (int)gridDim.x);
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
     v2d ry[NPY], rx[NPF];
     // KR context tile: BK rows x round32(k0) columns (P.lde >= that, zero padded), 16-byte pieces
     const int e_pieces_row = KR ? ((k0 + 31) / 32 * 16) : 1;  // 16-byte pieces per row (k0 rounded to 32)
-    constexpr int NPE = GEMM_BK / 4;                        // pieces per thread (lde <= 128)
+    constexpr int NPE = EW * GEMM_BK / 4;                   // pieces per thread (lde <= 128 EW)
     v2d re[NPE];
     double rg[KRQ];
     const int b0 = KR ? (m0 / k0) : 0;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void gemm_tn_kernel(const 
                 for (int j = 0; j < NT; j++) {
                     const int n = n0 + wn * (BN / 2) + j * 16 + l15;
                     if (n < P.N) {
-                        double* cp = Cb + (long)m * P.ldc + n;
+                        double* cp = transposed ? Cb + (long)n * P.ldc + m : Cb + (long)m * P.ldc + n;
                         *cp = (P.flags & GEMM_SUBTRACT) ? *cp - acc[i][j][reg] : acc[i][j][reg];
                     }
                 }
@@ -323,13 +325,39 @@ int kr_split_for(const crm_ctx* ctx, long row_tiles, int max_n, int nz, long cel
     return best;
 }
 
+// 129 .. CRM_MAX_K0 contexts: the staged kernel with context tiles twice as wide (no LDS-DMA form; one workgroup per CU).  The
+// slower correct path for context counts past the tiles of the fast kernels.
+static int launch_kr_wide(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells, int k0,
+                          int ksplit, long split_stride, bool transposed) {
+    const int bn = max_n <= 64 ? 64 : 128;
+    const int mt = (max_m + GEMM_BM - 1) / GEMM_BM, nt = (max_n + bn - 1) / bn;
+    const long total_stages = cells / GEMM_BK;
+    const long cps = (total_stages + ksplit - 1) / ksplit * GEMM_BK;
+    dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
+    const size_t lds = sizeof(double) * 2 * GEMM_BK * ((size_t)(bn + 16) + kr_variants_per_tile(k0) + kr_e_stride(k0));
+    if (bn == 64) {
+        CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<true, 1, 64, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 64, 2>), grid, dim3(256), lds, ctx->stream, probs_dev, mt, cps, cells,
+                           split_stride, k0, transposed ? 1 : 0);
+    } else {
+        CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<true, 1, 128, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 128, 2>), grid, dim3(256), lds, ctx->stream, probs_dev, mt, cps, cells,
+                           split_stride, k0, transposed ? 1 : 0);
+    }
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0) {
     if (nz <= 0 || max_m <= 0 || max_n <= 0) return CRM_OK;
-    if (cells % GEMM_BK != 0 || k0 < 1 || k0 > 128) {
+    if (cells % GEMM_BK != 0 || k0 < 1 || k0 > CRM_MAX_K0) {
         set_error("transposed Khatri-Rao contraction: cells=%ld, k0=%d", cells, k0);
         return CRM_ERR_ARG;
     }
+    if (k0 > 128) return launch_kr_wide(ctx, probs_dev, nz, max_m, max_n, cells, k0, 1, 0, true);
     // outputs of at most 64 columns (the [us | E1] rows of the kinship-structure route at config 2: 40, in mode B: 51) through
     // the 64-wide tile: a 128-wide one would be less than half full
     const int bn = max_n <= 64 && ctx->tune.bn != 128 ? 64 : 128;
@@ -349,49 +377,46 @@ int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m
         set_error("contraction: %ld cells cannot be cut into %d slices of whole stages", cells, ksplit);
         return CRM_ERR_ARG;
     }
+    if (khatri_rao && (k0 < 1 || k0 > CRM_MAX_K0)) {
+        set_error("Khatri-Rao contraction supports 1 <= k0 <= %d (got %d)", CRM_MAX_K0, k0);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    if (khatri_rao && k0 > 128) return launch_kr_wide(ctx, probs_dev, nz, max_m, max_n, cells, k0, ksplit, split_stride, false);
     const int mt = (max_m + GEMM_BM - 1) / GEMM_BM;
     const int bn = contraction_tile_width(ctx, mt, max_n, nz, ksplit, khatri_rao);
     const int nt = (max_n + bn - 1) / bn;
     if (ctx->tune.glds && (bn == 128 || khatri_rao)) {
-        if (khatri_rao && (k0 < 1 || k0 > 128)) {
-            set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
-            return CRM_ERR_UNSUPPORTED;
-        }
         return launch_gemm_tn_glds(ctx, probs_dev, nz, mt, nt, cells, khatri_rao, k0, ksplit, split_stride, false, bn);
     }
     dim3 grid((unsigned)(mt * nt), (unsigned)ksplit, (unsigned)nz);
     size_t lds = (size_t)2 * GEMM_BK * (bn + 16) * sizeof(double);
     if (khatri_rao) {
-        if (k0 < 1 || k0 > 128) {
-            set_error("Khatri-Rao contraction supports 1 <= k0 <= 128 (got %d)", k0);
-            return CRM_ERR_UNSUPPORTED;
-        }
         lds += (size_t)2 * GEMM_BK * (kr_variants_per_tile(k0) + kr_e_stride(k0)) * sizeof(double);
         constexpr int KRQ_BIG = (GEMM_BK * GEMM_BM + 255) / 256;
         const bool small = GEMM_BK * kr_variants_per_tile(k0) <= 256;
         if (bn == 64) {
             if (small)
                 hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cps, cells, split_stride, k0);
+                                   cps, cells, split_stride, k0, 0);
             else
                 hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cps, cells, split_stride, k0);
+                                   cps, cells, split_stride, k0, 0);
         } else {
             if (small)
                 hipLaunchKernelGGL((gemm_tn_kernel<true, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cps, cells, split_stride, k0);
+                                   cps, cells, split_stride, k0, 0);
             else
                 hipLaunchKernelGGL((gemm_tn_kernel<true, KRQ_BIG, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                                   cps, cells, split_stride, k0);
+                                   cps, cells, split_stride, k0, 0);
         }
     } else {
         lds += (size_t)2 * GEMM_BK * LDT * sizeof(double);
         if (bn == 64)
             hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 64>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cps, cells, split_stride, 0);
+                               cps, cells, split_stride, 0, 0);
         else
             hipLaunchKernelGGL((gemm_tn_kernel<false, 1, 128>), grid, dim3(256), lds, st, probs_dev, mt,
-                               cps, cells, split_stride, 0);
+                               cps, cells, split_stride, 0, 0);
     }
     CRM_HIP(hipGetLastError());
     return CRM_OK;

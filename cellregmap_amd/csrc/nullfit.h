@@ -170,12 +170,16 @@ struct AssembleArgs {
     double* F;   // [variants x k0 x k0]
 };
 
-// Gext: workspace [variants x (k0+c+2)^2]
-int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext);
+// Gext: workspace [variants x (k0+c+2)^2]; fin_rows: assemble_rows_scratch_doubles(...) doubles (0: not needed -- the
+// per-variant rows D'K^-1X and their solves fit LDS)
+int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double* Gext, double* fin_rows = nullptr);
+size_t assemble_rows_scratch_doubles(int variants, int k0, int c);
 
 // ---- eigenvalues + Davies / Liu (davies.hip) -----------------------------------------------------
 // lambda: ascending eigenvalues of the lower triangle of F (count x k x k); pvalue per SKAT rule.
+// scratch: eig_scratch_doubles(count, k) doubles (0: F fits LDS, k <= 128)
 int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int count, int k,
-                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig);
+                      double* lambda, double* pvalue, int* ifault, double* liu, bool do_eig, double* scratch = nullptr);
+size_t eig_scratch_doubles(int count, int k);
 
 }  // namespace crm

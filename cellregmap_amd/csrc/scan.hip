@@ -994,13 +994,12 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     }
     struct InScan { crm_ctx* c; explicit InScan(crm_ctx* c_) : c(c_) { c->in_scan = true; } ~InScan() { c->in_scan = false; } } in_scan(ctx);
     {
-        // (the Gram kernel's register tiles reach 144 rows, the finalisation keeps (c + 1)(2 k0 + c + 2) doubles in LDS:
-        // refused here, before anything is launched, with the limit named)
-        const long Pq = g0->c + 1;
-        if (g0->k0 + g0->c + 2 > 144 || sizeof(double) * (Pq * Pq + Pq + 2 * g0->k0 * Pq + g0->k0) > 150 * 1024) {
-            set_error("interaction scan: %d contexts with %d covariate columns (supported: contexts + covariates + 2 <= 144 and "
-                      "(c + 1)(2 k0 + c + 2) <= 19000; the association scans take up to %d covariate columns)",
-                      g0->k0, g0->c, CRM_MAX_COV_XWIDE);
+        // (the Gram kernel stages all k0 + c + 2 rows of a variant in LDS: refused here, before anything is launched, with
+        // the limit named; past 144 rows / 128 contexts the scan runs through the slower forms of its per-variant kernels)
+        if (g0->k0 + g0->c + 2 > CRM_MAX_GRAM_ROWS) {
+            set_error("interaction scan: %d contexts with %d covariate columns (supported: contexts + covariates + 2 <= %d; "
+                      "the association scans take up to %d covariate columns)", g0->k0, g0->c, CRM_MAX_GRAM_ROWS,
+                      CRM_MAX_COV_XWIDE);
             return CRM_ERR_UNSUPPORTED;
         }
     }
@@ -1031,6 +1030,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // before it (block copies, rotations and, above all, the per-phenotype null fits, which run twice as fast per variant in
     // launches of 4096 variants as in launches of 2048) keep the full block.
     if (g0->c > CRM_MAX_COV_WIDE) BLK = std::min(BLK, 512);   // (63 .. 128 covariate columns: the slow null-fit kernel's scratch)
+    // the slower per-variant kernels (more than 144 Gram rows or 128 contexts): their global-memory work space
+    const bool slow_forms = g0->k0 + g0->c + 2 > 144 || g0->k0 > 128 || assemble_rows_scratch_doubles(1, g0->k0, g0->c) > 0;
+    if (slow_forms) BLK = std::min(BLK, 512);
     int pair_cap = BLK;
     if (ng > 1) {
         const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
@@ -1993,8 +1995,14 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = ld_gW;
             aa.coef = collapsed ? nullptr : d_coef; aa.ld_coef = ldb;
             aa.Q = d_Q; aa.F = ctx->ws_F.as<double>();
-            CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>()));
-            CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true));
+            double* slow_ws = nullptr;
+            if (slow_forms) {
+                CRM_TRY(ctx->ws_xwide.ensure(sizeof(double) * std::max(std::max(assemble_rows_scratch_doubles(BLK, k0, c), eig_scratch_doubles(BLK, k0)),
+                                                                       c > CRM_MAX_COV_WIDE ? nullfit_xwide_scratch_doubles(BLK, nrho, c) : (size_t)0)));
+                slow_ws = ctx->ws_xwide.as<double>();   // (the null fits of the block are done: their scratch is free)
+            }
+            CRM_TRY(launch_assemble(st, aa, nb, ctx->ws_Gext.as<double>(), slow_ws));
+            CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true, slow_ws));
             if (o.pv) CRM_HIP(hipMemcpyAsync(o.pv + done, d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
             if (o.Q) CRM_HIP(hipMemcpyAsync(o.Q + done, d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
             if (o.lambda) CRM_HIP(hipMemcpyAsync(o.lambda + done * k0, d_lam, sizeof(double) * nb * k0, hipMemcpyDeviceToHost, st));

@@ -251,6 +251,70 @@ def test_interaction_scan_with_seventy_covariate_columns():
     assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL), np.c_[pv, opv]
 
 
+@pytest.mark.parametrize("k0,c,mode,route", [
+    (160, 70, "A", None),        # the review's case: Gram over 232 rows (4 workgroups per variant), finalisation rows and the
+                                 # eigenvalue kernel's working copy in global memory, Khatri-Rao with 256-wide context tiles
+    (100, 60, "A", None),        # 162 Gram rows with contexts within the fast kernels' tiles
+    (250, 1, "A", None),         # 253 rows: the 288-row Gram image
+    (136, 1, "C", None),         # kinship factor with donor structure: the folded route's per-donor launch, transposed store
+    (136, 1, "C", "1"),          # ... the unfolded kinship-structure route
+    (136, 1, "C", "0"),          # ... the direct contraction against H
+    (150, 3, "B", None),         # mode B (E2 = ones)
+])
+def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch):
+    """More than 128 contexts / more than 144 rows of contexts + covariates + 2: the slower forms of the
+    Khatri-Rao, Gram, finalisation and eigenvalue kernels under the whole scan, against the oracle."""
+    from cellregmap_amd import CellRegMap, GenotypePanel
+    from oracle.crm import OracleCellRegMap
+
+    if route is not None:
+        monkeypatch.setenv("CRM_KIN_ROUTE", route if route != "1" else "2")
+        if route == "1":
+            monkeypatch.setenv("CRM_KIN_FOLD", "0")
+    donors, cells = (3, 400) if mode == "C" else (8, 100)      # mode C: 136 + 3 x 136 = 544 columns for 1200 cells
+    co = _cohort(donors, cells, k0, 5, seed=41 + k0)
+    rng = np.random.default_rng(k0 + c)
+    W = np.concatenate([co.W, rng.normal(size=(co.y.size, c - 1))], axis=1) if c > 1 else co.W
+    kw = dict(hK=co.hK) if mode == "C" else {}
+    okw = dict(kw)
+    if mode == "B":
+        from cellregmap_amd import get_L_values
+        from oracle.crm import khatri_rao_halves
+        kw = dict(Ls=get_L_values(co.hK, np.ones((co.y.size, 1))))
+        okw = dict(Ls=khatri_rao_halves(co.hK, np.ones((co.y.size, 1))))
+    opv, oinfo, ost = OracleCellRegMap(co.y, co.E, W=W, **okw).scan_interaction(co.G, return_stats=True)
+    pv, info, st = CellRegMap(co.y, co.E, W=W, **kw).scan_interaction(GenotypePanel(co.G, groups=None), return_stats=True)
+    assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
+    assert_allclose(st["Q"], ost["Q"], rtol=2e-5)          # (verbatim procedure: the oracle-vs-oracle envelope)
+    assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL), np.c_[pv, opv]
+    oF = np.asarray(ost["F"])
+    assert_allclose(st["F"], oF, rtol=0, atol=2e-5 * np.abs(oF).max())
+    for lam, F in zip(st["lambda"], st["F"]):               # the eigenvalue kernel on the device's own F
+        ref = np.linalg.eigvalsh(F)
+        assert_allclose(lam, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_many_contexts_on_the_collapsed_and_the_shared_passes():
+    """136 contexts: the donor-collapsed path equals the dense one (donor-constant genotypes), and several phenotypes in
+    one pass equal their single scans."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, scan_interaction_many
+
+    co = _cohort(3, 400, 136, 6, seed=77)
+    rng = np.random.default_rng(5)
+    Ls = get_L_values(co.hK, co.E)
+    first = CellRegMap(co.y, co.E, W=co.W, Ls=Ls)
+    crms = [first] + [CellRegMap(y, co.E, W=co.W, Ls=Ls, background=first._bg)
+                      for y in (co.y[rng.permutation(co.y.size)], rng.normal(size=co.y.size))]
+    dense, auto = GenotypePanel(co.G, groups=None), GenotypePanel(co.G)
+    assert auto.n_groups == 3
+    pv_dense, _ = first.scan_interaction(dense)
+    pv_auto, _ = first.scan_interaction(auto)
+    assert_allclose(pv_auto, pv_dense, rtol=5e-5)           # (two summation orders through Brent: the usual envelope)
+    pv, info = scan_interaction_many(crms, dense)
+    for i, crm in enumerate(crms):
+        assert_allclose(pv[i], crm.scan_interaction(dense)[0], rtol=5e-5)   # (the shared pass orders its sums by pair)
+
+
 def test_unsupported_sizes_fail_loudly():
     from cellregmap_amd import CellRegMap, _lib
 
@@ -259,14 +323,14 @@ def test_unsupported_sizes_fail_loudly():
     W = np.concatenate([c.W, rng.normal(size=(c.y.size, 128))], axis=1)  # 129 covariate columns > 128
     with pytest.raises(_lib.CrmError, match="covariate columns"):
         CellRegMap(c.y, c.E, W=W).scan_interaction(c.G)
-    c2 = _cohort(8, 20, 60, 4, seed=35)
-    W = np.concatenate([c2.W, rng.normal(size=(c2.y.size, 89))], axis=1)  # 60 contexts + 90 covariates + 2 > 144
+    c2 = _cohort(8, 40, 170, 4, seed=35)
+    W = np.concatenate([c2.W, rng.normal(size=(c2.y.size, 119))], axis=1)  # 170 contexts + 120 covariates + 2 > 288
     crm = CellRegMap(c2.y, c2.E, W=W)
-    with pytest.raises(_lib.CrmError, match="contexts \\+ covariates \\+ 2 <= 144"):
+    with pytest.raises(_lib.CrmError, match="contexts \\+ covariates \\+ 2 <= 288"):
         crm.scan_interaction(c2.G)
     pv, info = crm.scan_association(c2.G, progress=False)      # ... which the association scans take (up to 128 columns)
     assert np.all(np.isfinite(pv))
-    E = rng.normal(size=(c.y.size, 129))                               # 129 contexts > 128
+    E = rng.normal(size=(c.y.size, 257))                               # 257 contexts > 256
     with pytest.raises(_lib.CrmError, match="contexts"):
         CellRegMap(c.y, E, W=c.W).scan_interaction(c.G)
 

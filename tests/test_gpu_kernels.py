@@ -69,7 +69,9 @@ def test_contract_random(ctx, variant, cells, M, N, ksplit):
 
 @pytest.mark.parametrize("cells,B,k0,N", [(500, 7, 10, 140), (2048, 20, 50, 300), (333, 40, 3, 64),
                                            (1024, 5, 128, 130), (640, 300, 1, 128), (5, 9, 50, 200),
-                                           (30, 40, 7, 130), (40, 6, 33, 129), (100, 3, 97, 140)])
+                                           (30, 40, 7, 130), (40, 6, 33, 129), (100, 3, 97, 140),
+                                           # more than 128 contexts: the slower form with context tiles twice as wide
+                                           (200, 5, 129, 140), (333, 7, 160, 300), (64, 3, 256, 50), (1000, 4, 200, 129)])
 def test_contract_khatri_rao(ctx, variant, cells, B, k0, N):
     from cellregmap_amd import _lib
 
@@ -109,7 +111,8 @@ def test_khatri_rao_contraction_in_persistent_generations(ctx, every):
 
 
 @pytest.mark.parametrize("cells,B,k0,N", [(64, 3, 5, 17), (1000, 37, 50, 300), (320, 130, 4, 129), (4096, 8, 128, 64),
-                                          (208, 9, 20, 40), (224, 700, 3, 51), (1600, 64, 50, 51), (96, 40, 33, 64)])
+                                          (208, 9, 20, 40), (224, 700, 3, 51), (1600, 64, 50, 51), (96, 40, 33, 64),
+                                          (208, 5, 129, 40), (500, 7, 160, 300), (64, 3, 256, 50), (96, 4, 200, 129)])
 def test_khatri_rao_contraction_with_transposed_store(ctx, cells, B, k0, N):
     """The shared-H route of the multi-gene scan stores (KR(G,E)' H)' directly (operands of the MFMA
     swapped, stores along M)."""
@@ -126,7 +129,7 @@ def test_khatri_rao_contraction_with_transposed_store(ctx, cells, B, k0, N):
     assert_allclose(CT, Y.T @ KR, rtol=0, atol=1e-11 * np.sqrt(cells))
 
 
-@pytest.mark.parametrize("k", [1, 2, 7, 50, 64, 65, 128])
+@pytest.mark.parametrize("k", [1, 2, 7, 50, 64, 65, 128, 129, 160, 256])   # past 128: working copy in global memory
 def test_eigvalsh_batched(ctx, k):
     from cellregmap_amd import _lib
 
