@@ -128,7 +128,7 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
  * deficient by that rule, or too ill-conditioned for the Gram-matrix route (eigenvalues of W'W spanning more than 1e13),
  * is refused with CRM_ERR_NUMERIC.  The scans then orthogonalise every block of variants against W in the cell axis and
  * apply the reference's rank rules to [W, g] (economic_svd in the null fits, lstsq in the projection of the score test).
- * c <= 128 (the interaction scan: k0 + c + 2 <= 144), k0 <= 128. */
+ * c <= 128, k0 <= 256, and in the interaction scan k0 + c + 2 <= 288 (past 128 contexts or 144 rows: slower kernel forms). */
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out);
 void crm_gene_destroy(crm_gene* gene);
