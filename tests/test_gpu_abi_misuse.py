@@ -80,8 +80,9 @@ def test_sizes_out_of_range(world):
     Wwide = _lib.f64(np.random.default_rng(0).normal(size=(n, 129)))
     assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(Wwide), 129, _lib.ptr(world["E"]), 3,
                                ctypes.byref(out)) == ERR_UNSUPPORTED
-    Ewide = _lib.f64(np.random.default_rng(1).normal(size=(n, 129)))
-    assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(world["W"]), 1, _lib.ptr(Ewide), 129,
+    # up to 256 contexts bind (past 128 the interaction scan takes the slower kernel forms); 257 do not
+    Ewide = _lib.f64(np.random.default_rng(1).normal(size=(n, 257)))
+    assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(world["W"]), 1, _lib.ptr(Ewide), 257,
                                ctypes.byref(out)) == ERR_UNSUPPORTED
     assert lib.crm_gene_create(world["bg"], _lib.ptr(world["y"]), _lib.ptr(world["W"]), 0, _lib.ptr(world["E"]), 3,
                                ctypes.byref(out)) == ERR_UNSUPPORTED
