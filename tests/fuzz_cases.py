@@ -26,13 +26,16 @@ def random_problem(n, k0, c, p, donors, seed, mode):
     return y, E, W, G, kw
 
 
-def fuzz_cases(count, seed=7, max_cells=600, max_contexts=128, max_variants=70, wide_covariates=True):
+def fuzz_cases(count, seed=7, max_cells=600, max_contexts=128, max_variants=70, wide_covariates=True, max_rows=144,
+               extra_covariates=()):
     """``count`` problem descriptions (i, n, k0, c, p, donors, mode, perm) drawn from one seeded stream:
     30..max_cells cells, 1..max_contexts contexts (1..8 in mode C), 1..14 covariate columns (1..8
     without ``wide_covariates``: the null-fit polish is built for the register kernel only), the three
-    background modes, no / context / genotype permutation hook."""
+    background modes, no / context / genotype permutation hook.  ``max_rows`` (contexts + covariates + 2) and
+    ``extra_covariates`` (more choices for c) open the stream to the sizes of the slower kernel forms
+    (tools/fuzz_scan.py; the defaults keep the streams of the committed records)."""
     rng = np.random.default_rng(seed)
-    covs = [1, 1, 1, 2, 3, 5, 8, 9, 14] if wide_covariates else [1, 1, 1, 2, 3, 5, 8]
+    covs = ([1, 1, 1, 2, 3, 5, 8, 9, 14] if wide_covariates else [1, 1, 1, 2, 3, 5, 8]) + list(extra_covariates)
     out = []
     i = 0
     while len(out) < count:
@@ -44,7 +47,7 @@ def fuzz_cases(count, seed=7, max_cells=600, max_contexts=128, max_variants=70, 
         donors = int(rng.integers(2, 14))
         perm = ["none", "E", "G"][int(rng.integers(0, 3))]
         i += 1
-        if k0 + c + 2 > 144 or n <= c + 2 or donors > n:
+        if k0 + c + 2 > max_rows or n <= c + 2 or donors > n:
             continue
         # Mode A with at least as many contexts as cells: Sigma = E1 E1' has full rank n, Q0 is square and the
         # complement terms (u'v - (Q0'u)'(Q0'v)) / delta of the reference's likelihood are rounding noise
