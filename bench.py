@@ -338,6 +338,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             local_rank = 0
+            # (the ranks of a dry run share one device's memory: each keeps its config-4 pair buffers to its part of it)
+            os.environ.setdefault("CRM_PAIR_BUFFER_GB", str(max(8, 96 // world)))
     torch.cuda.set_device(local_rank)
     comm = Comm(dist, torch, share_gpu, local_rank)
 
