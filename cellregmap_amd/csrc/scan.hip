@@ -146,7 +146,7 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     const long n = bg->n;
     const int k1 = (int)(bg->cols - (long)k2 * m);
     // only backgrounds that kept their half factor H = [E1, L_1 .. L_k2] (thin branch, well-conditioned spectrum) can use it
-    if (!bg->fast_T || !bg->H.ptr || k1 < 1 || k1 + k2 > 256 || groups > 4096) return CRM_OK;
+    if (!bg->fast_T || !bg->H.ptr || k1 < 1 || k1 + k2 > 2 * CRM_MAX_K0 || groups > 4096) return CRM_OK;   // (kin_operand: one thread per column of [us | E1], <= 1024)
     for (long i = 0; i < n; i++)
         if (group[i] < 0 || group[i] >= groups) {
             set_error("kinship groups: group index %d at cell %ld outside [0, %ld)", group[i], i, groups);

@@ -259,7 +259,7 @@ def test_interaction_scan_with_seventy_covariate_columns():
     (136, 1, "C", None),         # kinship factor with donor structure: the folded route's per-donor launch, transposed store
     (136, 1, "C", "1"),          # ... the unfolded kinship-structure route
     (136, 1, "C", "0"),          # ... the direct contraction against H
-    (150, 3, "B", None),         # mode B (E2 = ones)
+    (150, 3, "B", None),         # mode B (hK alone)
 ])
 def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch):
     """More than 128 contexts / more than 144 rows of contexts + covariates + 2: the slower forms of the
@@ -267,23 +267,32 @@ def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch):
     from cellregmap_amd import CellRegMap, GenotypePanel
     from oracle.crm import OracleCellRegMap
 
-    if route is not None:
-        monkeypatch.setenv("CRM_KIN_ROUTE", route if route != "1" else "2")
-        if route == "1":
-            monkeypatch.setenv("CRM_KIN_FOLD", "0")
+    from cellregmap_amd import _engine, _lib
+
+    lib, ctx = _lib.load(), _engine._context(0)
+    if route == "1":     # (read when the structure is announced; the seed below keeps this background out of the cache)
+        monkeypatch.setenv("CRM_KIN_FOLD", "0")
     donors, cells = (3, 400) if mode == "C" else (8, 100)      # mode C: 136 + 3 x 136 = 544 columns for 1200 cells
-    co = _cohort(donors, cells, k0, 5, seed=41 + k0)
+    co = _cohort(donors, cells, k0, 5, seed=41 + k0 + (1000 if route == "1" else 0))
     rng = np.random.default_rng(k0 + c)
     W = np.concatenate([co.W, rng.normal(size=(co.y.size, c - 1))], axis=1) if c > 1 else co.W
-    kw = dict(hK=co.hK) if mode == "C" else {}
-    okw = dict(kw)
-    if mode == "B":
-        from cellregmap_amd import get_L_values
-        from oracle.crm import khatri_rao_halves
-        kw = dict(Ls=get_L_values(co.hK, np.ones((co.y.size, 1))))
-        okw = dict(Ls=khatri_rao_halves(co.hK, np.ones((co.y.size, 1))))
+    from cellregmap_amd import get_L_values
+    from oracle.crm import khatri_rao_halves
+    kw, okw = {}, {}
+    if mode == "C":      # K o EE' through its factored halves (run_interaction's E2 = E)
+        kw, okw = dict(Ls=get_L_values(co.hK, co.E)), dict(Ls=khatri_rao_halves(co.hK, co.E))
+    elif mode == "B":    # hS = [sqrt(rho) E1, sqrt(1 - rho) hK]
+        kw = okw = dict(hK=co.hK)
     opv, oinfo, ost = OracleCellRegMap(co.y, co.E, W=W, **okw).scan_interaction(co.G, return_stats=True)
-    pv, info, st = CellRegMap(co.y, co.E, W=W, **kw).scan_interaction(GenotypePanel(co.G, groups=None), return_stats=True)
+    crm = CellRegMap(co.y, co.E, W=W, **kw)
+    if mode != "A":      # the donor structure was found and announced; folded unless told otherwise
+        assert lib.crm_background_kinship_groups(crm._bg.handle) == donors
+        assert (lib.crm_background_kinship_folded(crm._bg.handle) > 0) == (route != "1")
+    _lib.check(lib.crm_test_set_kinship_route(ctx, {None: 2, "1": 2, "0": 0}[route]))
+    try:
+        pv, info, st = crm.scan_interaction(GenotypePanel(co.G, groups=None), return_stats=True)
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
     assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
     assert_allclose(st["Q"], ost["Q"], rtol=2e-5)          # (verbatim procedure: the oracle-vs-oracle envelope)
     assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL), np.c_[pv, opv]
