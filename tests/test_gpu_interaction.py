@@ -288,6 +288,43 @@ def test_mode_b_on_the_kinship_structure_route(hook):
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
 
 
+@pytest.mark.parametrize("mode", ["B", "C"])
+def test_folded_route_with_an_E1_of_its_own(mode, monkeypatch):
+    """E1 given and different from E (other columns, another count): the folded form's E1 rows then come from the general
+    pair features E1_a o E0_i (k1 k0 columns), not from the symmetric ones the scan shares with E0'diag(g^2)E0 when E1 is E
+    itself.  Against the oracle and against the direct route."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
+    from oracle.crm import OracleCellRegMap, khatri_rao_halves
+
+    monkeypatch.setenv("CRM_KIN_FOLD", "2")      # (mode C folds by itself from 32 columns of us on)
+    rng = np.random.default_rng(17 if mode == "B" else 18)
+    donors, k0, k1, p = 9, 5, 3, 40
+    donor = np.repeat(np.arange(donors), rng.integers(12, 40, size=donors))
+    n = donor.size
+    hK = rng.normal(size=(donors, donors))[donor]
+    E, E1 = rng.normal(size=(n, k0)), rng.normal(size=(n, k1))
+    W = np.ones((n, 1))
+    G = rng.normal(size=(n, p))
+    y = 0.5 * G[:, 3] * E[:, 0] + E1 @ rng.normal(size=k1) * 0.3 + hK @ rng.normal(size=donors) * 0.2 + rng.normal(size=n)
+    kw, okw = (dict(hK=hK),) * 2 if mode == "B" else (dict(Ls=get_L_values(hK, E)), dict(Ls=khatri_rao_halves(hK, E)))
+    crm = CellRegMap(y, E, W=W, E1=E1, **kw)
+    lib, ctx = _lib.load(), _engine._context(0)
+    assert lib.crm_background_kinship_groups(crm._bg.handle) == donors and lib.crm_background_kinship_folded(crm._bg.handle) > 0
+    panel = GenotypePanel(G, groups=None)
+    try:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
+        pv, info, st = crm.scan_interaction(panel, return_stats=True, progress=False)
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+        pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True, progress=False)
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+    assert np.array_equal(info["rho1"], info0["rho1"])
+    assert_allclose(st["lml"], st0["lml"], rtol=1e-12)
+    assert_allclose(st["Q"], st0["Q"], rtol=2e-5)
+    opv, oinfo, ost = OracleCellRegMap(y, E, W=W, E1=E1, **okw).scan_interaction(G, return_stats=True)
+    _compare(pv, info, st, opv, oinfo, ost)
+
+
 @pytest.mark.parametrize("route", [2, 0, "folded"])
 def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
     """Several phenotypes can ask for more (variant, rho*) pairs than the pair-ordered buffers hold (min(11, genes) per
