@@ -418,8 +418,16 @@ class GenotypePanel:
         lib = _lib.load()
         G = np.asarray(G, float)
         assert G.ndim == 2
+        # a block of columns of a row-major matrix (rows a fixed number of doubles apart) goes to the library as it lies --
+        # the C-ABI takes the leading dimension -- so that a large host matrix can be uploaded in column chunks without
+        # a host copy of each (``CellRegMap._scan_streamed``); anything else is made contiguous first
+        ldg = G.shape[1]
         if not G.flags.c_contiguous:
-            G = np.ascontiguousarray(G)
+            if (G.shape[0] > 1 and G.shape[1] > 0 and G.strides[1] == G.itemsize and G.strides[0] % G.itemsize == 0
+                    and G.strides[0] >= G.shape[1] * G.itemsize):
+                ldg = G.strides[0] // G.itemsize
+            else:
+                G = np.ascontiguousarray(G)
         self.shape = G.shape
         self.device = device
         self.n_groups = None
@@ -428,10 +436,10 @@ class GenotypePanel:
 
         def create(hint):
             if hint is None:
-                return lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1], None, 0,
+                return lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), ldg, G.shape[1], None, 0,
                                                  None, ctypes.byref(h), ctypes.byref(grouped))
             group, reps = hint
-            return lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), G.shape[1], G.shape[1],
+            return lib.crm_panel_create_auto(_context(device), G.shape[0], _lib.ptr(G), ldg, G.shape[1],
                                              _lib.ptr(group), reps.shape[0], _lib.ptr(reps), ctypes.byref(h),
                                              ctypes.byref(grouped))
 
@@ -524,6 +532,17 @@ def _release_gene(lib, handle, _background_kept_alive):
 
 
 _PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
+
+
+def _stream_chunk():
+    """Variants per chunk of the streamed scan of a host matrix (``CellRegMap._scan_streamed``): two blocks of the
+    scan's largest block size; CELLREGMAP_AMD_STREAM_CHUNK overrides (0: never stream)."""
+    import os
+
+    try:
+        return max(0, int(os.environ.get("CELLREGMAP_AMD_STREAM_CHUNK", "8192")))
+    except ValueError:
+        return 8192
 
 
 _progress_stack = {}   # (device, thread) -> callbacks installed by the scans in flight on that thread (innermost last)
@@ -732,22 +751,25 @@ class CellRegMap:
         self._gene_fin = weakref.finalize(self, _release_gene, lib, h, self._bg)
         return h
 
-    def _panel(self, G):
+    def _panel(self, G, groups="auto"):
         if isinstance(G, GenotypePanel):
             panel = G
         else:
             G = np.asarray(G, float)
             if G.ndim != 2 or G.shape[0] != self.n_samples:
                 raise ValueError(f"G must be {self.n_samples} x p, got {G.shape}")
-            panel = GenotypePanel(G, self._device)  # raises ValueError on non-finite entries
+            panel = GenotypePanel(G, self._device, groups)  # raises ValueError on non-finite entries
         if panel.shape[0] != self.n_samples:
             raise ValueError(f"G has {panel.shape[0]} rows, expected {self.n_samples}")
         return panel
 
     # -- interaction scan (_cellregmap.py:317-440) ----------------------------------------------
     def scan_interaction(self, G, idx_E: Optional[any] = None, idx_G: Optional[any] = None,
-                         return_stats: bool = False, progress=None):
-        """Per-variant GxC score test.  ``G`` is n x p (array-like) or a ``GenotypePanel``.
+                         return_stats: bool = False, progress=None, groups="auto"):
+        """Per-variant GxC score test.  ``G`` is n x p (array-like) or a ``GenotypePanel``; an array goes to the device as
+        ``GenotypePanel(G, groups=groups)`` would take it (``"auto"``: donor-constant genotypes are found and scanned on
+        the donor-collapsed path; ``None``: kept dense), in column chunks beside the scan when it has many variants
+        (``_scan_streamed``).
         ``progress``: the reference always shows a tqdm bar over the variants (:340) and so does this method by
         default (it advances block by block); ``False`` silences it (or CELLREGMAP_AMD_PROGRESS=0 in the
         environment), a callable ``(done, total)`` replaces it.
@@ -767,13 +789,85 @@ class CellRegMap:
                                             "scale": np.empty(0), "lambda": np.empty((0, k0)),
                                             "F": np.empty((0, k0, k0))}
             return np.empty(0), empty
-        panel = self._panel(G)
+        if not isinstance(G, GenotypePanel):
+            G = np.asarray(G, float)
+            if G.ndim == 2 and G.shape[0] == self.n_samples and G.shape[1] >= 2 * _stream_chunk() > 0:
+                return self._scan_streamed(lib, G, k0, idx_E, idx_G, return_stats, progress, groups)
+        panel = self._panel(G, groups)
         n, p = panel.shape
         gene = self._bind_gene()
 
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         with _progress(self._device, progress, p):
             return self._scan_interaction(lib, gene, panel, p, k0, iE, iG, return_stats)
+
+    def _scan_streamed(self, lib, G, k0, idx_E, idx_G, return_stats, progress, groups="auto"):
+        """A host matrix of many variants goes to the device in column chunks from a second thread while this one scans
+        the chunks that have arrived (the library uploads on a stream of its own, outside the context's lock): PCIe
+        beside the scan, and device memory for three chunks instead of the whole matrix.  The chunks are whole blocks
+        of the scan, so the results are those of the one-panel scan; every chunk looks for the donor structure by
+        itself (``GenotypePanel(..., groups="auto")``), as the one panel would."""
+        import queue
+
+        n, p = G.shape
+        chunk = _stream_chunk()
+        # (the first chunk is the only one nothing hides: half a chunk -- still a whole block when the chunk is two)
+        first = chunk // 2 if chunk % 256 == 0 else chunk
+        bounds = [(0, first)] + [(j0, min(p, j0 + chunk)) for j0 in range(first, p, chunk)]
+        iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+        ready = queue.Queue(maxsize=2)
+        stop = threading.Event()
+        if progress is None:
+            progress = _progress_default()
+        bar = None
+        if progress is True:      # one bar over all chunks
+            try:
+                from tqdm import tqdm
+
+                bar, seen = tqdm(total=p), {"done": 0}
+
+                def progress(done, total, _bar=bar, _seen=seen):
+                    _bar.update(done - _seen["done"])
+                    _seen["done"] = done
+            except ImportError:  # pragma: no cover
+                progress = False
+
+        def upload():
+            try:
+                for j0, j1 in bounds:
+                    if stop.is_set():
+                        return
+                    ready.put(GenotypePanel(G[:, j0:j1], self._device, groups))   # (ValueError on non-finite entries)
+            except BaseException as exc:  # noqa: BLE001 -- handed to the scanning thread, which raises it
+                ready.put(exc)
+
+        worker = threading.Thread(target=upload, name="cellregmap-amd-upload", daemon=True)
+        worker.start()
+        parts = []
+        try:
+            gene = self._bind_gene()      # (beside the first chunk's upload)
+            for j0, j1 in bounds:
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                with _progress(self._device, progress, j1 - j0, offset=j0, grand_total=p):
+                    parts.append(self._scan_interaction(lib, gene, item, j1 - j0, k0, iE, iG, return_stats))
+                del item
+        finally:
+            stop.set()
+            while worker.is_alive():      # (let a blocked put() through, drop what it still uploads)
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            worker.join()
+            if bar is not None:
+                bar.close()
+        pv = np.concatenate([part[0] for part in parts])
+        info = {key: np.concatenate([part[1][key] for part in parts]) for key in parts[0][1]}
+        if return_stats:
+            return pv, info, {key: np.concatenate([part[2][key] for part in parts]) for key in parts[0][2]}
+        return pv, info
 
     def _scan_interaction(self, lib, gene, panel, p, k0, iE, iG, return_stats):
         out = {k: np.empty(p) for k in ("pv", "rho1", "e2", "g2", "eps2")}

@@ -847,3 +847,49 @@ def test_kinship_structure_route_equals_the_direct_route(hook, shape, monkeypatc
     finally:
         _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+
+
+@pytest.mark.parametrize("genotypes", ["general", "donor-constant"])
+def test_streamed_scan_of_a_host_matrix_equals_the_one_panel_scan(genotypes, monkeypatch):
+    """A host matrix of many variants is uploaded in column chunks from a second thread while the chunks that have arrived
+    are scanned (``CellRegMap._scan_streamed``).  With the chunks whole blocks of the scan the results are those of the
+    one-panel scan bit for bit -- p-values, info, statistics, with a permutation hook, for general and for donor-constant
+    genotypes (every chunk finds the donor structure by itself) --, one progress report runs over all chunks, a
+    non-finite entry in a late chunk raises the reference's ValueError, and a block of columns of a row-major matrix
+    makes the same panel as its contiguous copy."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(9, 30, 4, 700, seed=52)
+    rng = np.random.default_rng(2)
+    G = c.G if genotypes == "donor-constant" else c.G + 0.05 * rng.normal(size=c.G.shape)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib, ctx = _lib.load(), _engine._context(0)
+    _lib.check(lib.crm_set_block_variants(ctx, 128))
+    try:
+        for kw in ({}, {"idx_G": rng.permutation(c.y.size)}):
+            monkeypatch.setenv("CELLREGMAP_AMD_STREAM_CHUNK", "0")
+            pv, info, st = crm.scan_interaction(G, return_stats=True, progress=False, **kw)
+            monkeypatch.setenv("CELLREGMAP_AMD_STREAM_CHUNK", "256")       # 700 variants: chunks of 128, 256, 256, 60
+            seen = []
+            spv, sinfo, sst = crm.scan_interaction(G, return_stats=True, progress=lambda done, total: seen.append((done, total)), **kw)
+            assert np.array_equal(pv, spv)
+            for key in info:
+                assert np.array_equal(info[key], sinfo[key]), key
+            for key in st:
+                assert np.array_equal(st[key], sst[key]), key
+            assert seen[-1] == (700, 700) and all(t == 700 for _, t in seen) and [d for d, _ in seen] == sorted(d for d, _ in seen)
+        bad = G.copy()
+        bad[17, 650] = np.nan
+        with pytest.raises(ValueError, match="non-finite"):
+            crm.scan_interaction(bad, progress=False)
+        assert np.array_equal(crm.scan_interaction(G, progress=False, **kw)[0], spv)   # the context is sound afterwards
+        dense = crm.scan_interaction(G, progress=False, groups=None)[0]                # every chunk kept dense
+        assert np.array_equal(dense, crm.scan_interaction(GenotypePanel(G, groups=None), progress=False)[0])
+    finally:
+        _lib.check(lib.crm_set_block_variants(ctx, 0))
+    view = G[:, 100:356]                                                 # rows 700 doubles apart: no host copy is made
+    assert not view.flags.c_contiguous
+    a = crm.scan_interaction(GenotypePanel(view, groups=None), progress=False)[0]
+    b = crm.scan_interaction(GenotypePanel(np.ascontiguousarray(view), groups=None), progress=False)[0]
+    assert np.array_equal(a, b)
