@@ -811,8 +811,9 @@ class CellRegMap:
 
         n, p = G.shape
         chunk = _stream_chunk()
-        # (the first chunk is the only one nothing hides: half a chunk -- still a whole block when the chunk is two)
-        first = chunk // 2 if chunk % 256 == 0 else chunk
+        # (the first chunk is the only one nothing hides: one block of the scan when the chunk is a multiple of it, else half
+        # a chunk)
+        first = 4096 if chunk % 4096 == 0 else (chunk // 2 if chunk % 256 == 0 else chunk)
         bounds = [(0, first)] + [(j0, min(p, j0 + chunk)) for j0 in range(first, p, chunk)]
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         ready = queue.Queue(maxsize=2)
