@@ -194,3 +194,14 @@ def test_kinship_groups_of_expanded_factors():
     assert rows.shape[0] == donors + 1 and np.array_equal(rows[group], hK)
     # no repeated rows at all
     assert _engine._kinship_groups(rng.normal(size=(300, 10))) is None
+
+
+def test_stream_chunk_setting(monkeypatch):
+    """CELLREGMAP_AMD_STREAM_CHUNK: variants per chunk of the streamed scan of a host matrix; 0 disables, junk falls back."""
+    from cellregmap_amd import _engine
+
+    monkeypatch.delenv("CELLREGMAP_AMD_STREAM_CHUNK", raising=False)
+    assert _engine._stream_chunk() == 8192
+    for text, want in (("0", 0), ("4096", 4096), ("-7", 0), ("many", 8192)):
+        monkeypatch.setenv("CELLREGMAP_AMD_STREAM_CHUNK", text)
+        assert _engine._stream_chunk() == want
