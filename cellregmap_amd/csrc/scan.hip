@@ -1752,7 +1752,6 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // (kinship-structure route: the pair brackets the dominant launch alone, the Mix(rho*)' product further down)
             if (!kin_route) CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].first, st));
         }
-        double kin_prep_flops = 0.0;
         if (via_H && kfold) {
             // Folded form (objects.h: kin_fold): S = [E1 rows ; (donor, us_j) rows] of "H'(g o E0) before the contraction over
             // the donors", which MixK carries.  (a) the block in donor order; (b) per donor d' the Khatri-Rao contraction over
@@ -1824,8 +1823,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), e1_slab, slices, e1_slab));
                 CRM_HIP(hipMemcpyAsync(S, ctx->ws_AH.ptr, sizeof(double) * (size_t)e1_slab, hipMemcpyDeviceToDevice, st));
             }
-            kin_prep_flops = 2.0 * (double)bg->kin_rows * k2 * (double)k0 * ncol + 2.0 * (double)np * k1 * (double)k0 * ncol;
-            (void)kin_prep_flops;
+            // (2 kin_rows k2 k0 + 2 n k1 k0 flops per variant, outside the timed pair: the roofline figure is the MixK product's own;
+            // bench.py's whole_path counts them)
             if (!in_pair_order) {
                 const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
                 CRM_TRY(launch_gather_slabs(st, S, ld_ah, kdim, d_ord, npairs, k0, ctx->ws_XG.as<double>(), ld_xg, xg_cols));
@@ -1873,8 +1872,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, KK, maxlen, k0));
             CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, k2, (int)mk, ncol * k0, bg->kin_groups_pad, false, 0, 1, 0));
             CRM_TRY(launch_kin_sum_e1(st, S, ld_ah, KK, k2, k1, (int)groups, (long)ncol * k0, ctx->ws_AH.as<double>(), ld_ah));
-            kin_prep_flops = 2.0 * (double)bg->kin_rows * KK * (double)k0 * ncol + 2.0 * (double)bg->kin_groups_pad * mk * k2 * (double)k0 * ncol;
-            (void)kin_prep_flops;   // (outside the timed pair: the roofline figure is the Mix product's own)
+            // (2 kin_rows KK k0 + 2 groups_pad m k2 k0 flops per variant, outside the timed pair: the roofline figure is the Mix
+            // product's own; bench.py's whole_path counts them)
             if (!in_pair_order) {
                 const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
                 CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
