@@ -801,58 +801,38 @@ class CellRegMap:
         with _progress(self._device, progress, p):
             return self._scan_interaction(lib, gene, panel, p, k0, iE, iG, return_stats)
 
-    def _scan_streamed(self, lib, G, k0, idx_E, idx_G, return_stats, progress, groups="auto"):
-        """A host matrix of many variants goes to the device in column chunks from a second thread while this one scans
-        the chunks that have arrived (the library uploads on a stream of its own, outside the context's lock): PCIe
-        beside the scan, and device memory for three chunks instead of the whole matrix.  The chunks are whole blocks
-        of the scan, so the results are those of the one-panel scan; every chunk looks for the donor structure by
-        itself (``GenotypePanel(..., groups="auto")``), as the one panel would."""
+    def _streamed_panels(self, G, groups="auto"):
+        """Generator over ``(first, last, panel)``: the column chunks of a host matrix, uploaded one after the other by a
+        second thread (at most two ahead of the consumer) on the library's upload stream, outside the context's lock.  The
+        first chunk -- the only one nothing hides -- is one block of the scan when the chunk is a multiple of it; every
+        chunk looks for the donor structure by itself, as one panel would.  An error of the uploading thread (the
+        reference's ValueError on non-finite entries) is raised here; closing the generator stops the thread."""
         import queue
 
-        n, p = G.shape
+        p = G.shape[1]
         chunk = _stream_chunk()
-        # (the first chunk is the only one nothing hides: one block of the scan when the chunk is a multiple of it, else half
-        # a chunk)
         first = 4096 if chunk % 4096 == 0 else (chunk // 2 if chunk % 256 == 0 else chunk)
-        bounds = [(0, first)] + [(j0, min(p, j0 + chunk)) for j0 in range(first, p, chunk)]
-        iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+        bounds = [(0, min(p, first))] + [(j0, min(p, j0 + chunk)) for j0 in range(first, p, chunk)]
         ready = queue.Queue(maxsize=2)
         stop = threading.Event()
-        if progress is None:
-            progress = _progress_default()
-        bar = None
-        if progress is True:      # one bar over all chunks
-            try:
-                from tqdm import tqdm
-
-                bar, seen = tqdm(total=p), {"done": 0}
-
-                def progress(done, total, _bar=bar, _seen=seen):
-                    _bar.update(done - _seen["done"])
-                    _seen["done"] = done
-            except ImportError:  # pragma: no cover
-                progress = False
 
         def upload():
             try:
                 for j0, j1 in bounds:
                     if stop.is_set():
                         return
-                    ready.put(GenotypePanel(G[:, j0:j1], self._device, groups))   # (ValueError on non-finite entries)
-            except BaseException as exc:  # noqa: BLE001 -- handed to the scanning thread, which raises it
+                    ready.put(GenotypePanel(G[:, j0:j1], self._device, groups))
+            except BaseException as exc:  # noqa: BLE001 -- handed to the consuming thread, which raises it
                 ready.put(exc)
 
         worker = threading.Thread(target=upload, name="cellregmap-amd-upload", daemon=True)
         worker.start()
-        parts = []
         try:
-            gene = self._bind_gene()      # (beside the first chunk's upload)
             for j0, j1 in bounds:
                 item = ready.get()
                 if isinstance(item, BaseException):
                     raise item
-                with _progress(self._device, progress, j1 - j0, offset=j0, grand_total=p):
-                    parts.append(self._scan_interaction(lib, gene, item, j1 - j0, k0, iE, iG, return_stats))
+                yield j0, j1, item
                 del item
         finally:
             stop.set()
@@ -862,6 +842,43 @@ class CellRegMap:
                 except queue.Empty:
                     pass
             worker.join()
+
+    @staticmethod
+    def _one_bar(progress, total):
+        """``progress`` of a scan that runs chunk by chunk: a tqdm bar becomes ONE bar over all chunks.  Returns the
+        callable (or False) to hand to every chunk's ``_progress`` and the bar to close."""
+        if progress is None:
+            progress = _progress_default()
+        if progress is not True:
+            return progress, None
+        try:
+            from tqdm import tqdm
+        except ImportError:  # pragma: no cover
+            return False, None
+        bar, seen = tqdm(total=total), {"done": 0}
+
+        def advance(done, _total):
+            bar.update(done - seen["done"])
+            seen["done"] = done
+
+        return advance, bar
+
+    def _scan_streamed(self, lib, G, k0, idx_E, idx_G, return_stats, progress, groups="auto"):
+        """A host matrix of many variants goes to the device in column chunks from a second thread while this one scans
+        the chunks that have arrived: PCIe beside the scan, and device memory for three chunks instead of the whole
+        matrix.  The chunks are whole blocks of the scan, so the results are those of the one-panel scan."""
+        n, p = G.shape
+        iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
+        progress, bar = self._one_bar(progress, p)
+        panels = self._streamed_panels(G, groups)
+        parts = []
+        try:
+            gene = self._bind_gene()      # (beside the first chunk's upload)
+            for j0, j1, panel in panels:
+                with _progress(self._device, progress, j1 - j0, offset=j0, grand_total=p):
+                    parts.append(self._scan_interaction(lib, gene, panel, j1 - j0, k0, iE, iG, return_stats))
+        finally:
+            panels.close()
             if bar is not None:
                 bar.close()
         pv = np.concatenate([part[0] for part in parts])
@@ -913,6 +930,27 @@ class CellRegMap:
             # no SNPs: the null model is still fitted and reported (_cellregmap.py:250-266)
             p_user = 0
             G = np.zeros((np.asarray(G).shape[0], 1))
+        null = np.empty(6)
+        if p_user is None and not isinstance(G, GenotypePanel):
+            G = np.asarray(G, float)
+            if G.ndim == 2 and G.shape[0] == self.n_samples and G.shape[1] >= 2 * _stream_chunk() > 0:
+                # a host matrix of many SNPs: column chunks uploaded beside the scan (``_streamed_panels``); every call
+                # fits the null model again -- the same eleven fits, the same numbers
+                p = G.shape[1]
+                pv, alt = np.empty(p), np.empty(p)
+                progress, bar = self._one_bar(progress, p)
+                panels = self._streamed_panels(G)
+                try:
+                    gene = self._bind_gene()
+                    for j0, j1, panel in panels:
+                        with _progress(self._device, progress, j1 - j0, offset=j0, grand_total=p):
+                            _lib.check(lib.crm_scan_association(gene, panel.handle, 0, j1 - j0, int(bool(fast)),
+                                                                _lib.ptr(pv[j0:j1]), _lib.ptr(alt[j0:j1]), _lib.ptr(null)))
+                finally:
+                    panels.close()
+                    if bar is not None:
+                        bar.close()
+                return self._association_result(pv, alt, null, return_stats)
         panel = self._panel(G)
         n, p = panel.shape
         if p_user is not None:
@@ -920,10 +958,13 @@ class CellRegMap:
         gene = self._bind_gene()
         pv = np.empty(p)
         alt = np.empty(p)
-        null = np.empty(6)
         with _progress(self._device, progress, p):
             _lib.check(lib.crm_scan_association(gene, panel.handle, 0, p, int(bool(fast)), _lib.ptr(pv),
                                                 _lib.ptr(alt), _lib.ptr(null)))
+        return self._association_result(pv, alt, null, return_stats)
+
+    @staticmethod
+    def _association_result(pv, alt, null, return_stats):
         info = {"rho1": np.asarray([null[0]], float), "e2": np.asarray([null[1]], float),
                 "g2": np.asarray([null[2]], float), "eps2": np.asarray([null[3]], float)}
         if return_stats:

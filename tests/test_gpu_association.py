@@ -124,3 +124,28 @@ def test_run_association_with_many_contexts(contexts, fast):
     for key in ("e2", "g2", "eps2"):
         assert_allclose(info[key], oinfo[key], rtol=1e-5, atol=1e-10)
     assert np.all(np.abs(pv - opv) <= 1e-5 * opv + 1e-300), np.c_[pv, opv]
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_streamed_association_scan_equals_the_one_panel_scan(fast, monkeypatch):
+    """A host matrix of many SNPs goes to the device in column chunks beside the scan of the chunks that have arrived
+    (``CellRegMap._streamed_panels``), for the association scans as for the interaction scan: same p-values, alternative
+    likelihoods and null model as the one-panel scan, one progress report over all chunks."""
+    from cellregmap_amd import CellRegMap
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(9, 30, 4, 700, seed=61)
+    G = c.G + 0.05 * np.random.default_rng(3).normal(size=c.G.shape)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    scan = crm.scan_association_fast if fast else crm.scan_association
+    monkeypatch.setenv("CELLREGMAP_AMD_STREAM_CHUNK", "0")
+    pv, info, st = scan(G, return_stats=True, progress=False)
+    monkeypatch.setenv("CELLREGMAP_AMD_STREAM_CHUNK", "256")
+    seen = []
+    spv, sinfo, sst = scan(G, return_stats=True, progress=lambda done, total: seen.append((done, total)))
+    assert_allclose(spv, pv, rtol=1e-12, atol=0)
+    assert_allclose(sst["alt_lml"], st["alt_lml"], rtol=1e-13)
+    assert sst["null_lml"] == st["null_lml"] and sst["null_delta"] == st["null_delta"]
+    for key in info:
+        assert np.array_equal(info[key], sinfo[key])
+    assert seen and seen[-1] == (700, 700) and all(t == 700 for _, t in seen)
