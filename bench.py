@@ -681,7 +681,7 @@ def main():
         "setup_s": {"synthetic_data": round(t_data, 2), "background_constructor": round(t_ctor, 2)},
         "speedup_vs_cpu_baseline": None if not cpu else round(value / cpu["value"], 1),
         "multi_gpu": {"ranks": world, "group": comm.backend, "group_note": comm.note,
-                      "collectives": ("constructor: all_reduce of the ranks + one all_gather of the packed spectra / mixing "
+                      "collectives": ("constructor: two small all_reduces (ranks + trouble flag, ok flag) + one all_gather of the packed spectra / mixing "
                                       "matrices; results: one all_gather of the per-variant outputs") if world > 1 else None,
                       "note": "per-N values are whatever this run measured on this node; the repository holds no measured N > 1 "
                               "run of its own (its build sessions only ever had one GPU) and models no scaling figure"},

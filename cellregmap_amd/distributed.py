@@ -74,16 +74,29 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
     (tests inject a numpy one); default: the HIP library's ``BackgroundBuilder``.
     ``overlap``: callable run while the collective is in flight (the caller's panel upload: PCIe beside xGMI);
     its return value lands in ``info["overlap_result"]``.
-    ``info``: dict that receives the phase timings (``decompose_s``, ``exchange_s`` = pack + collective + unpack,
+    ``info``: dict that receives the phase timings (``decompose_s``, ``exchange_s`` = pack + collectives + unpack,
     ``overlap_s``), the bytes this rank contributed, and ``exchange`` = "ok" / "not needed" / "failed: ...".
-    If anything in the exchange raises -- a collective, an import -- this rank falls back to decomposing every grid
-    point itself (the 0.9 s single-GPU constructor): the result is the same background either way, so ranks need
-    not agree on which way they took.
+
+    Failure protocol.  Every rank issues the SAME sequence of collectives whatever happens to it locally, so a rank in
+    trouble never leaves its peers waiting and never gets one collective out of step with them:
+      1. local: decompose the owned grid points (may fail: out of memory, a solver error);
+      2. ``all_reduce(MAX)`` of the ranks of the grid points with a failure flag in the last entry;
+      3. local: common leading dimension, pack the owned slots (may fail);
+      4. ``all_reduce(MIN)`` of an ok flag;
+      5. one ``all_gather`` of the packed buffers -- only if every rank said ok in 2 and 4;
+      6. local: import what the others sent (may fail).
+    A flag raised in 2 or 4 is seen by everybody: all ranks then decompose every grid point themselves (the single-GPU
+    constructor) and no further collective is issued.  A failure in 6 concerns this rank alone and comes after the
+    last collective: it alone rebuilds.  A collective that itself raises (a communicator that cannot start, a
+    timeout) also ends in the local build; the caller's next collective is then on its own (``bench.py`` keeps a
+    gloo group behind RCCL for that).  ``overlap`` runs outside all of this: what it raises is the caller's error
+    and propagates (after the collective in flight has been waited for).
 
     Order of initialisation in a process that uses torch on the GPU and this library: torch first
     (``torch.cuda.set_device`` / ``init_process_group(..., device_id=...)``), then the first call into the
     library -- both then share one HIP runtime and device pointers can be handed across."""
     import time
+    import warnings
 
     import torch
     import torch.distributed as dist
@@ -107,25 +120,63 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
         full.complete([full.rank(i) for i in range(nrho)])
         return full.seal()
 
+    def run_overlap():
+        if overlap is not None and "overlap_result" not in info:
+            t2 = time.perf_counter()
+            info["overlap_result"] = overlap()
+            info["overlap_s"] = time.perf_counter() - t2
+
     t0 = time.perf_counter()
     exchanging = world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
     if not exchanging:
         bg = everything_here()
         info.update(decompose_s=time.perf_counter() - t0, exchange_s=0.0, exchange="not needed", exchanged_bytes=0)
-        if overlap is not None:
-            info["overlap_result"] = overlap()
+        run_overlap()
         return bg
     # (force_exchange: a world of one still runs the collective calls and copies every slot out and back in --
     # the whole exchange path on a single GPU)
+
+    def local_build(why):
+        warnings.warn(f"rank {rank}: the exchange of the background failed ({why}); decomposing every grid "
+                      "point on this rank instead", RuntimeWarning, stacklevel=3)
+        t3 = time.perf_counter()
+        bg_ = everything_here()
+        info.update(exchange="failed: " + why[:240], fallback_s=time.perf_counter() - t3)
+        return bg_
+
+    def say(exc):
+        return "%s: %s" % (type(exc).__name__, exc)
+
+    nccl = dist.get_backend(group) == "nccl"
+    dev = tensor_device if tensor_device is not None else (torch.device("cuda", device) if nccl else torch.device("cpu"))
+    # 1. local: my grid points
+    b, trouble = None, None
     try:
         b = builder(mine)
-        info["decompose_s"] = time.perf_counter() - t0
-        t1 = time.perf_counter()
-        nccl = dist.get_backend(group) == "nccl"
-        dev = tensor_device if tensor_device is not None else (torch.device("cuda", device) if nccl else torch.device("cpu"))
-        ranks = torch.tensor([b.rank(i) if mine[i] else -1 for i in range(nrho)], dtype=torch.int64, device=dev)
+        mine_ranks = [b.rank(i) if mine[i] else -1 for i in range(nrho)]
+    except Exception as exc:  # noqa: BLE001 -- reported to the peers through the flag below, then retried alone
+        b, trouble, mine_ranks = None, say(exc), [-1] * nrho
+    info["decompose_s"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    # 2. ranks of all grid points + failure flag
+    try:
+        ranks = torch.tensor(mine_ranks + [1 if trouble else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(ranks, op=dist.ReduceOp.MAX, group=group)
-        b.complete(ranks.cpu().numpy())
+        ranks = ranks.cpu().numpy()
+    except Exception as exc:  # noqa: BLE001 -- the collective itself
+        b = None
+        bg = local_build(trouble or say(exc))
+        run_overlap()
+        return bg
+    if ranks[-1] != 0:
+        b = None
+        bg = local_build(trouble or "another rank could not decompose its grid points")
+        run_overlap()
+        return bg
+    # 3. local: common layout, pack
+    pack = per_point = most = None
+    try:
+        b.complete(ranks[:nrho])
         layout = b.layout()                                   # slot name -> doubles, the same on every rank
         per_point = int(sum(layout.values()))
         most = (nrho + world - 1) // world                    # grid points of the busiest rank: every piece has that size
@@ -135,45 +186,62 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
             for what, size in layout.items():
                 b.export_slot(i, what, pack[off:off + size])
                 off += size
+    except Exception as exc:  # noqa: BLE001
+        trouble = say(exc)
+    # 4. does everybody have its piece?
+    try:
+        ok = torch.tensor([0 if trouble else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        ok = int(ok.cpu().item())
+    except Exception as exc:  # noqa: BLE001
+        ok, trouble = 0, trouble or say(exc)
+    if not ok:
+        b = pack = None
+        bg = local_build(trouble or "another rank could not pack its grid points")
+        run_overlap()
+        return bg
+    # 5. the exchange: one all_gather, the caller's overlap hook beside it
+    work = None
+    try:
         # (gloo has no all_gather of GPU tensors: device buffers -- the two-ranks-on-one-GPU test -- travel through host copies)
         staged = (not nccl) and pack.is_cuda
         wire = pack.cpu() if staged else pack
         everything = torch.empty(world * most * per_point, dtype=torch.float64, device=wire.device)
         work = dist.all_gather(list(everything.chunk(world)), wire, group=group, async_op=True)
-        if overlap is not None:
-            t2 = time.perf_counter()
-            info["overlap_result"] = overlap()
-            info["overlap_s"] = time.perf_counter() - t2
-        work.wait()
-        if staged:
-            everything = everything.to(dev)
-        if everything.is_cuda:
-            # the wait orders torch's current stream behind the collective; the library copies on its own stream
-            torch.cuda.current_stream(everything.device).synchronize()
-        for r in range(world):
-            if r == rank and not force_exchange:
-                continue
-            for k, i in enumerate(owned_grid_points(nrho, r, world)):
-                off = (r * most + k) * per_point
-                for what, size in layout.items():
-                    b.import_slot(i, what, everything[off:off + size])
-                    off += size
-        bg = b.seal()
-        info.update(exchange_s=time.perf_counter() - t1 - info.get("overlap_s", 0.0), exchange="ok",
-                    exchanged_bytes=8 * int(mine.sum()) * per_point, collectives=2)
-        return bg
-    except Exception as exc:  # noqa: BLE001 -- whatever went wrong, every rank can still build the whole background alone
-        import warnings
-
-        warnings.warn(f"rank {rank}: the exchange of the background failed ({type(exc).__name__}: {exc}); decomposing every grid "
-                      "point on this rank instead", RuntimeWarning, stacklevel=2)
-        t3 = time.perf_counter()
-        b = None
-        bg = everything_here()
-        info.update(exchange="failed: %s: %s" % (type(exc).__name__, str(exc)[:200]), fallback_s=time.perf_counter() - t3)
-        if overlap is not None and "overlap_result" not in info:
-            info["overlap_result"] = overlap()
-        return bg
+    except Exception as exc:  # noqa: BLE001
+        trouble = say(exc)
+    try:
+        run_overlap()
+    finally:
+        if work is not None:
+            try:
+                work.wait()
+            except Exception as exc:  # noqa: BLE001
+                trouble = trouble or say(exc)
+    # 6. local: take what the others sent
+    if trouble is None:
+        try:
+            if staged:
+                everything = everything.to(dev)
+            if everything.is_cuda:
+                # the wait orders torch's current stream behind the collective; the library copies on its own stream
+                torch.cuda.current_stream(everything.device).synchronize()
+            for r in range(world):
+                if r == rank and not force_exchange:
+                    continue
+                for k, i in enumerate(owned_grid_points(nrho, r, world)):
+                    off = (r * most + k) * per_point
+                    for what, size in layout.items():
+                        b.import_slot(i, what, everything[off:off + size])
+                        off += size
+            bg = b.seal()
+            info.update(exchange_s=time.perf_counter() - t1 - info.get("overlap_s", 0.0), exchange="ok",
+                        exchanged_bytes=8 * int(mine.sum()) * per_point, collectives=3)
+            return bg
+        except Exception as exc:  # noqa: BLE001 -- after the last collective: this rank's business alone
+            trouble = say(exc)
+    b = pack = everything = None
+    return local_build(trouble)
 
 
 def _my_columns(G, p_total, rank, world):

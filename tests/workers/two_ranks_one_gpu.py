@@ -48,7 +48,7 @@ def main():
                             overlap=lambda: "ran beside the collective")
     # the packed exchange itself must have carried the grid points (a silent fall-back to a local build would pass the
     # comparisons below just as well)
-    assert info["exchange"] == "ok" and info["collectives"] == 2 and info["exchanged_bytes"] > 0, info
+    assert info["exchange"] == "ok" and info["collectives"] == 3 and info["exchanged_bytes"] > 0, info
     assert info["overlap_result"] == "ran beside the collective"
     obj = crm.CellRegMap(c.y, c.E, W=c.W, background=bg, **kw)
     first, count = variant_shard(p, rank, world)
