@@ -174,7 +174,9 @@ def cpu_baseline_leg(crm, cohort, Ls, n, sample_of, G_weak, G_full, pv_dense, cp
     import threadpoolctl
 
     blas = threadpoolctl.threadpool_info()
-    nthreads = max([b.get("num_threads", 1) for b in blas] or [1])
+    # the threads that did the work: the BLAS pool behind numpy (not the OpenMP pool torch brings along)
+    nthreads = max([b.get("num_threads", 1) for b in blas if b.get("user_api") == "blas"] or
+                   [b.get("num_threads", 1) for b in blas] or [1])
     dev = np.abs(opv - pv_dense[pick]) / np.maximum(opv, 1e-300)
     # (gene, variant) pairs of the config-4 leg against the oracle (other phenotypes, same decomposition)
     c4_check = None
@@ -301,6 +303,9 @@ def main():
     ap.add_argument("--full-panel", type=int, default=1, help="strong-scaling leg on the config's fixed panel")
     ap.add_argument("--kinship", default="indicator", choices=["indicator", "rotated"],
                     help="kinship factor of the synthetic cohort: donor indicators, or the dense U sqrt(S) of the same K")
+    ap.add_argument("--direct-steps", type=int, default=3,
+                    help="timed steps of the general-input side leg (the direct contraction against Q0(rho*), what a "
+                         "cell-level hK / Ls gets; N = 1 only; 0 = skip)")
     ap.add_argument("--genes", type=int, default=64, help="phenotypes of the config-4 leg (0 = skip)")
     ap.add_argument("--genes-variants", type=int, default=0,
                     help="variants of the config-4 leg, all ranks together (0 = the config's whole fixed panel when "
@@ -374,9 +379,9 @@ def main():
     f_first, f_count = variant_shard(p_total, rank, world)
     G_full = None
     if args.full_panel:
-        full = make_cohort(donors, cells, k0, p_total, seed=77, with_phenotype=False)   # same panel on every rank ...
-        G_full = np.ascontiguousarray(full.G[:, f_first:f_first + f_count])             # ... of which it keeps its shard
-        donor_of_cell = full.donor_of_cell
+        # the same panel for every world size; a rank expands only its own shard of it to cells
+        full = make_cohort(donors, cells, k0, p_total, seed=77, with_phenotype=False, columns=(f_first, f_count))
+        G_full, donor_of_cell = full.G, full.donor_of_cell
         del full
     weak_blocks = max(1, min(steps, 12 if world == 1 else 4))   # (N ranks generate their panels side by side on one host)
     if G_full is not None and f_count >= weak_blocks * batch:
@@ -546,6 +551,48 @@ def main():
     total_variants = steps * batch * world
     value = total_variants / elapsed
 
+    # ---- side leg: the general-input route.  The headline's cohort has a donor-expanded kinship factor, which the engine
+    #      detects and serves through the kinship-structure route; a cell-level hK / Ls -- which the
+    #      reference accepts just the same (_cellregmap.py:107-131) -- gets the direct Khatri-Rao contraction against
+    #      Q0(rho*) over all cells, i.e. SURVEY 8(d)'s 2 n r* k0 flops per variant.  Same steps, same panel, same results.
+    direct = None
+    kin_on = lib.crm_background_kinship_groups(crm._bg.handle) if os.environ.get("CRM_KIN_ROUTE", "1") != "0" else 0
+    if world == 1 and args.direct_steps > 0 and kin_on:
+        dpv, drho, dQ = np.empty(batch), np.empty(batch), np.empty(batch)
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 0))
+        try:
+            scan(panel, 0, batch, dpv, drho, dQ)       # warm-up: Q0 of the selected grid points is formed on first use
+            fence()
+            _lib.check(lib.crm_kernel_timer_reset(ctx))
+            t0 = time.perf_counter()
+            for i in range(args.direct_steps):
+                first = (i % weak_blocks) * batch
+                scan(panel, first, batch, dpv, drho, dQ)
+            fence()
+            t_direct = time.perf_counter() - t0
+            d_ms, d_n, d_fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+            _lib.check(lib.crm_kernel_timer_read(ctx, ctypes.byref(d_ms), ctypes.byref(d_n), ctypes.byref(d_fl), ctypes.byref(tot)))
+            _lib.check(lib.crm_kernel_timer_stop(ctx))
+        finally:
+            _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+        last = ((args.direct_steps - 1) % weak_blocks) * batch
+        d_tf = d_fl.value / (d_ms.value * 1e-3) * 1e-12 if d_ms.value > 0 else 0.0
+        direct = {"value": round(args.direct_steps * batch / t_direct, 1), "unit": "variant-tests/s", "steps": args.direct_steps,
+                  "ms_per_step": round(t_direct / args.direct_steps * 1e3, 3),
+                  "roofline": {"bound": "mfma",
+                               "kernel": "gemm_tn_glds_sync_kernel<true, ...> + its tail launch and split reduction: "
+                                         "A~ = KR(G, E0)' Q0(rho*) over all cells (Khatri-Rao columns formed in LDS, FP64 MFMA)",
+                               "achieved": round(d_tf, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(d_tf / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches": int(d_n.value), "avg_launch_ms": round(d_ms.value / max(d_n.value, 1), 3),
+                               "flops_per_launch": d_fl.value / max(d_n.value, 1),
+                               "flops": "executed = SURVEY 8(d)'s 2 n r* k0 per variant (r* padded to the tile grid)",
+                               "share_of_step_time": round(d_ms.value * 1e-3 / t_direct, 4)},
+                  "max_rel_dp_vs_kinship_route": float(np.max(np.abs(dpv - pv[last:last + batch]) / np.maximum(pv[last:last + batch], 1e-300))),
+                  "rho_star_identical": bool(np.array_equal(drho, rho1[last:last + batch])),
+                  "note": "the route a cell-level hK / Ls takes (crm_test_set_kinship_route(ctx, 0) on the same cohort): every "
+                          "variant contracted against Q0(rho*) over all cells; side figure, never `value`"}
+
     # ---- config 4's shape: `genes` phenotypes against one panel, the variants sharded over the ranks ---------------
     config4 = None
     multi_keep = None
@@ -567,16 +614,17 @@ def main():
             mpanel, mb, nv = fpanel_kept, f_count, p_total
         else:
             want = args.genes_variants if args.genes_variants > 0 else 2048
-            _, mb = variant_shard(min(want, p_need * world), rank, world)
-            mb = min(mb, p_need)
-            mpanel, nv = panel, mb * world
-        mpv = np.empty((len(crms), mb)); mrho = np.empty((len(crms), mb))
+            nv = min(want, p_need * world)
+            _, mb = variant_shard(nv, rank, world)      # (<= p_need: nv <= p_need * world)
+            mpanel = panel
+        keys5 = ("pv", "rho1", "e2", "g2", "eps2")      # what scan_interaction returns per (gene, variant)
+        mout = {k: np.empty((len(crms), mb)) for k in keys5}
+        mpv, mrho = mout["pv"], mout["rho1"]
 
         def run_multi(count):
+            outs = mout if count == mb else {k: np.empty((len(crms), count)) for k in keys5}
             _lib.check(lib.crm_scan_interaction_multi(handles, len(crms), mpanel.handle, 0, count, None, None,
-                                                      _lib.ptr(mpv[:, :count].copy() if count < mb else mpv),
-                                                      _lib.ptr(mrho[:, :count].copy() if count < mb else mrho),
-                                                      None, None, None, None))
+                                                      *[_lib.ptr(outs[k]) for k in keys5], None))
             _lib.check(lib.crm_ctx_synchronize(ctx))
 
         run_multi(min(mb, 4096))   # warm-up: work buffers at the size of a full block (4096 variants), Q0 of the selected grid points
@@ -585,9 +633,29 @@ def main():
         run_multi(mb)
         fence()
         t_multi = max_over_ranks(time.perf_counter() - t0)
+        # config 4's one collective: the (genes x variants) results of every shard on every rank -- 5 arrays per gene,
+        # packed into ONE all_gather (cellregmap_amd/distributed.py: gather_many_results; RCCL over xGMI when the group is nccl)
+        t_gather4, gather4_note = 0.0, None
+        if dist is not None:
+            from cellregmap_amd.distributed import gather_many_results
+
+            t0 = time.perf_counter()
+            try:
+                gpv, ginfo = gather_many_results(mpv, {k: mout[k] for k in keys5[1:]}, nv, comm.group)
+                torch.cuda.synchronize()
+                f4, c4 = variant_shard(nv, rank, world)
+                assert gpv.shape == (len(crms), nv) and np.array_equal(gpv[:, f4:f4 + c4], mpv)
+                assert np.array_equal(ginfo["rho1"][:, f4:f4 + c4], mrho)
+                gather4_note = "ok"
+            except Exception as exc:  # noqa: BLE001 -- the shard results are still valid; say what happened
+                gather4_note = "failed (%s: %s)" % (type(exc).__name__, str(exc)[:160])
+            comm.barrier()
+            t_gather4 = max_over_ranks(time.perf_counter() - t0)
         same_panel = mpanel is panel
-        config4 = {"value": round(len(crms) * nv / t_multi, 1), "unit": "variant-tests/s", "genes": len(crms),
-                   "variants": nv, "variants_per_rank": mb, "seconds": round(t_multi, 3),
+        config4 = {"value": round(len(crms) * nv / (t_multi + t_gather4), 1), "unit": "variant-tests/s", "genes": len(crms),
+                   "variants": nv, "variants_per_rank": mb, "seconds": round(t_multi + t_gather4, 3),
+                   "scan_s": round(t_multi, 3), "gather_s": round(t_gather4, 4) if dist is not None else None,
+                   "gather": gather4_note, "gathered_bytes_per_rank": 8 * 5 * len(crms) * mb if dist is not None else None,
                    "distinct_rho_per_variant": float(np.mean([len(set(mrho[:, j])) for j in range(min(mb, 4096))])),
                    "max_rel_dp_gene0_vs_single_gene_scan": float(np.max(np.abs(mpv[0, :min(mb, p_need)] - pv_dense[:min(mb, p_need)]) /
                                                                    np.maximum(pv_dense[:min(mb, p_need)], 1e-300))) if same_panel else
@@ -686,6 +754,7 @@ def main():
                       "note": "per-N values are whatever this run measured on this node; the repository holds no measured N > 1 "
                               "run of its own (its build sessions only ever had one GPU) and models no scaling figure"},
         "full_panel": full_panel,
+        "direct_route": direct,
         "config4": config4,
         "donor_collapsed": collapsed,
     }

@@ -78,16 +78,25 @@ def kinship_factor(donor_of_cell, n_donors, kind="indicator", seed=20):
 
 def make_cohort(n_donors, cells_per_donor, n_contexts, n_variants, seed=20,
                 g_causals=(5, 6), gxe_causals=(10, 11), with_phenotype=True, dtype=np.float64, kinship="indicator",
-                components=None):
+                components=None, columns=None):
     """``kinship``: see ``kinship_factor``.  ``components``: a dict that receives the phenotype's moment-normalised
-    parts (offset, y_g, y_gxe, y_k, y_e, y_n), as the reference's ``Simulation`` tuple exposes them."""
+    parts (offset, y_g, y_gxe, y_k, y_e, y_n), as the reference's ``Simulation`` tuple exposes them.
+    ``columns = (first, count)`` (only with ``with_phenotype=False``): ``G`` holds just those columns of the panel --
+    the donor-level draw (donors x variants, small) is made whole so that every column is what the full panel would
+    hold, only the expansion to cells is restricted (a rank of a multi-GPU job never forms the n x p matrix)."""
     rng = np.random.default_rng(seed)
     n = n_donors * cells_per_donor
     Gd, mafs = donor_genotypes(n_donors, n_variants, rng)
     donor_of_cell = np.repeat(np.arange(n_donors), cells_per_donor)
     # normalise at donor level == normalising the expanded matrix (equal group sizes)
     Gd = column_normalize(Gd)
-    G = np.ascontiguousarray(Gd[donor_of_cell, :], dtype=dtype)
+    if columns is not None:
+        if with_phenotype:
+            raise ValueError("columns=...: only for panels without a phenotype (the causal variants are columns of G)")
+        first, count = columns
+        G = np.ascontiguousarray(Gd[:, first:first + count][donor_of_cell, :], dtype=dtype)
+    else:
+        G = np.ascontiguousarray(Gd[donor_of_cell, :], dtype=dtype)
     E = column_normalize(rng.normal(size=(n, n_contexts)))
     W = np.ones((n, 1))
     # donor-block kinship: K = Z Z' / mean diag + 1e-8 I ;  hK = U sqrt(S) (rank n_donors)
