@@ -30,6 +30,14 @@ struct EighWork {
     DevBuf QA, QB;   // eigenvector rows of the tridiagonal (ping-pong over the D&C levels)
     DevBuf d, e, tau, lam;   // [batch][ld]
     DevBuf small;    // panels, partial sums, problem records, D&C descriptors
+    // two-stage solver of a family D(rho) C D(rho) (eigh2_band.hip, eigh2_chase.hip)
+    bool v_shared = false;   // the reflectors of the back-transformation (Vt, tau: slab 0) serve every matrix of the batch
+    DevBuf AB;       // [batch][dimp + 128][128]  lower band storage, column c at offsets row - c (room for the chase's fill)
+    DevBuf Vbc;      // [batch][positions][dimp][64]  reflectors of the chase, chain position major
+    DevBuf taubc;    // [batch][positions][dimp]
+    DevBuf Tbc;      // [batch][sweep blocks][positions][64 x 64]  T factors of the grouped reflectors
+    DevBuf s1;       // stage-1 scratch (T factors, partial sums, panels, counters, problem records)
+    DevBuf sync;     // progress counters of the chase, abort flag
 };
 
 // Eigen-decomposition of `batch` symmetric matrices held in w.A (dim x dim each, leading dimension w.ld,
@@ -44,6 +52,22 @@ int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt);
 int eigh_tridiagonalise(crm_ctx* ctx, EighWork& w);                       // A -> d, e, tau, Vt
 int eigh_dc(crm_ctx* ctx, EighWork& w, double* lam_host, double** Qt);    // d, e -> lam (ascending), rows
 int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt);
+
+// Two-stage solver for the constructor's family of grid points (eigh2_band.hip / eigh2_chase.hip):
+//   A_q = D_q C D_q,  D_q = diag(wa[q] on the first E2_W coordinates, wb[q] on the rest),  q < w.batch,
+// with C (dim x dim, both triangles, leading dimension w.ld) in slab 0 of w.A.  The first E2_W coordinates are the
+// caller's leading block (the contexts' columns of the half factor, padded in front with zero rows / columns up to E2_W).
+// Same outputs as eigh_batched.  CRM_ERR_UNSUPPORTED with nothing computed when the problem is outside what the
+// two-stage form serves, CRM_ERR_BUSY-like CRM_ERR_HIP never: a chase that cannot keep its workgroups co-resident gives
+// up after a bounded wait and returns CRM_ERR_UNSUPPORTED too -- the caller then runs eigh_batched.
+constexpr int E2_W = 64;       // panel width of stage 1 = half-bandwidth = reflector length of the chase = sweeps per group
+int eigh2_family(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb, double* lam_host, double** Zt);
+bool eigh2_serves(long dim, int batch);
+// phases
+int eigh2_to_band(crm_ctx* ctx, EighWork& w);                                   // slab 0 of A -> band (lower), Vt / tau slab 0
+int eigh2_scale_band(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb);   // -> AB of every matrix
+int eigh2_chase(crm_ctx* ctx, EighWork& w);                                     // AB -> d, e, Vbc, taubc
+int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Qt);                    // rows of Qt <- Q2' applied (in place)
 
 int launch_transpose(hipStream_t st, const double* src, long ld_src, long rows, long cols, double* dst, long ld_dst);
 

@@ -92,7 +92,9 @@ int eigh_alloc(EighWork& w, int batch, long dim) {
 }
 
 void eigh_free(EighWork& w) {
-    for (DevBuf* b : {&w.A, &w.Vt, &w.Vc, &w.QA, &w.QB, &w.d, &w.e, &w.tau, &w.lam, &w.small}) b->release();
+    for (DevBuf* b : {&w.A, &w.Vt, &w.Vc, &w.QA, &w.QB, &w.d, &w.e, &w.tau, &w.lam, &w.small, &w.AB, &w.Vbc, &w.taubc, &w.Tbc, &w.s1,
+                      &w.sync})
+        b->release();
 }
 
 // Qt: rows = eigenvectors of the tridiagonal (sorted); returns *Zt: rows = eigenvectors of A.
@@ -100,6 +102,9 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     hipStream_t st = ctx->stream;
     const long dim = w.dim, ld = w.ld, dimp = w.dimp, slab = w.slab;
     const int B = w.batch;
+    // (two-stage solver: one set of reflectors -- slab 0 of Vt, row 0 of tau -- serves every matrix of the batch)
+    const int VB = w.v_shared ? 1 : B;
+    auto vb = [&](int b) { return w.v_shared ? 0 : b; };
     double* other = Qt == w.QA.as<double>() ? w.QB.as<double>() : w.QA.as<double>();
     if (dim < 2) {   // no reflectors
         *Zt_out = Qt;
@@ -110,9 +115,9 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     double* Vc = w.Vc.as<double>();
     const double* Vt = w.Vt.as<double>();
     CRM_HIP(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)B * slab, st));
-    CRM_HIP(hipMemsetAsync(Vc, 0, sizeof(double) * (size_t)B * slab, st));
+    CRM_HIP(hipMemsetAsync(Vc, 0, sizeof(double) * (size_t)VB * slab, st));
     CRM_TRY(transpose_batch(st, B, Qt, Z, slab, ld, dim, dim));
-    CRM_TRY(transpose_batch(st, B, Vt, Vc, slab, ld, dim, dim));
+    CRM_TRY(transpose_batch(st, VB, Vt, Vc, slab, ld, dim, dim));
     const int nblocks = (int)((dim - 1 + BT_NB - 1) / BT_NB);
     // scratch: S and Tt per (matrix, block), W1 / W2 per matrix, problem records
     const size_t tt = (size_t)B * nblocks * BT_NB * BT_NB;
@@ -124,9 +129,9 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     double* W1 = Tt + tt;
     double* W2 = W1 + (size_t)B * wsz;
     GemmProblem* d_probs = reinterpret_cast<GemmProblem*>(W2 + (size_t)B * wsz);
-    std::vector<GemmProblem> probs((size_t)B * nblocks);
+    std::vector<GemmProblem> probs((size_t)VB * nblocks);
     // S_p = V_p' V_p for every block (one 128 x 128 tile each, split over the rows)
-    for (int b = 0; b < B; b++)
+    for (int b = 0; b < VB; b++)
         for (int p = 0; p < nblocks; p++) {
             GemmProblem g{};
             const long j0 = (long)p * BT_NB;
@@ -141,7 +146,7 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     CRM_TRY(launch_gemm_tn(ctx, d_probs, (int)probs.size(), BT_NB, BT_NB, dimp, false, 0, 1, 0));
     CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(double) * BT_NB * (BT_NB + 1))));
-    hipLaunchKernelGGL(bt_larft_kernel, dim3(nblocks, B), dim3(BT_NB), sizeof(double) * BT_NB * (BT_NB + 1), st, S,
+    hipLaunchKernelGGL(bt_larft_kernel, dim3(nblocks, VB), dim3(BT_NB), sizeof(double) * BT_NB * (BT_NB + 1), st, S,
                        w.tau.as<double>(), ld, nblocks, dim, Tt);
     CRM_HIP(hipGetLastError());
     CRM_HIP(hipStreamSynchronize(st));
@@ -154,21 +159,21 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
         for (int b = 0; b < B; b++) {
             GemmProblem g{};
             // W1 (BT_NB x dim) = V_p' Z   over the rows r0 .. dimp
-            g.X = Vc + (size_t)b * slab + (size_t)r0 * ld + j0; g.ldx = ld;
+            g.X = Vc + (size_t)vb(b) * slab + (size_t)r0 * ld + j0; g.ldx = ld;
             g.Y = Z + (size_t)b * slab + (size_t)r0 * ld; g.ldy = ld;
             g.C = W1 + (size_t)b * wsz; g.ldc = ld;
             g.M = BT_NB; g.N = (int)dim;
             p3[b] = g;
             // W2 = T W1  ==  Tt' W1
             GemmProblem h{};
-            h.X = Tt + ((size_t)b * nblocks + p) * BT_NB * BT_NB; h.ldx = BT_NB;
+            h.X = Tt + ((size_t)vb(b) * nblocks + p) * BT_NB * BT_NB; h.ldx = BT_NB;
             h.Y = W1 + (size_t)b * wsz; h.ldy = ld;
             h.C = W2 + (size_t)b * wsz; h.ldc = ld;
             h.M = BT_NB; h.N = (int)dim;
             p3[B + b] = h;
             // Z[r0:, :] -= V_p W2  ==  (Vt rows j0 .., columns r0 ..)' W2
             GemmProblem u{};
-            u.X = Vt + (size_t)b * slab + (size_t)j0 * ld + r0; u.ldx = ld;
+            u.X = Vt + (size_t)vb(b) * slab + (size_t)j0 * ld + r0; u.ldx = ld;
             u.Y = W2 + (size_t)b * wsz; u.ldy = ld;
             u.C = Z + (size_t)b * slab + (size_t)r0 * ld; u.ldc = ld;
             u.M = (int)(dim - r0); u.N = (int)dim;

@@ -72,6 +72,14 @@ int crm_test_davies(crm_ctx* ctx, int count, int k, const double* Q, const doubl
 int crm_test_eigh(crm_ctx* ctx, int batch, int dim, const double* A, double* lam, double* Z, int stage,
                   double* d_out, double* e_out);
 
+/* The constructor's two-stage solver for a family of grid points A_q = D_q C D_q, D_q = diag(wa[q] on the first 64
+ * coordinates, wb[q] on the rest) (cellregmap_amd/csrc/eigh2_band.hip, eigh2_chase.hip): C dim x dim host matrix
+ * (row-major, symmetric).  stage 0: everything -- lam (nq x dim, ascending), Z (nq x dim x dim, column j = eigenvector j;
+ * may be NULL); stage 1: the dense -> band reduction only (band_out: dim x dim, its lower triangle holds Q1' C Q1);
+ * stage 2: ... and the chase of every scaled band (d_out / e_out: nq x dim diagonals and sub-diagonals). */
+int crm_test_eigh2(crm_ctx* ctx, int nq, int dim, const double* C, const double* wa, const double* wb, double* lam, double* Z,
+                   int stage, double* d_out, double* e_out, double* band_out);
+
 /* Host-only (no GPU needed): the deflation plan of one divide-and-conquer merge of the eigen-solver -- eigenvalues
  * lam[n] of the two halves (n1 + n2), z[n] = last / first components of their eigenvectors, coupling beta.  Returns
  * k surviving poles, the rho of the normalised secular problem, rows[n] (local source rows: k survivors in pole order,

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${1:-steps_profile}; shift
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o t -- python3 bench.py --cpu-variants 0 --genes 0 --full-panel 0 --collapsed 0 "$@" \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o t -- python3 bench.py --cpu-variants 0 --genes 0 --full-panel 0 --collapsed 0 --direct-steps 0 "$@" \
     > $out/bench_steps_under_rocprof.json 2> $out/rocprof.err; echo "rocprof rc=$?"
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv && rm -rf $out/prof
 tail -1 $out/bench_steps_under_rocprof.json | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'])"

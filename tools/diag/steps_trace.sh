@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${1:-steps_trace}; shift
 mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/prof -o t -- python3 bench.py --steps 4 --warmup 1 --cpu-variants 0 --genes 0 --full-panel 0 --collapsed 0 "$@" \
+rocprofv3 --kernel-trace --output-format csv -d $out/prof -o t -- python3 bench.py --steps 4 --warmup 1 --cpu-variants 0 --genes 0 --full-panel 0 --collapsed 0 --direct-steps 0 "$@" \
     > $out/bench.json 2> $out/rocprof.err; echo "rocprof rc=$?"
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $out/step_breakdown.txt <<'PY'
@@ -16,18 +16,16 @@ last_ctor = max(i for i, r in enumerate(rows) if any(t in r["Kernel_Name"] for t
 steps = rows[last_ctor + 1:]
 tagged = [i for i, r in enumerate(steps) if "128, 1>" in r["Kernel_Name"]]
 nsteps = len(tagged)
-# drop the warm-up step: start after the first tagged launch's step ends (= just before the second step's first kernel)
-agg = collections.OrderedDict()
-first = tagged[1] if nsteps > 1 else 0
-# walk back from the second tagged launch to the start of its step: the gather_block kernel that opens a block
-start = first
-while start > 0 and "gather_block" not in steps[start]["Kernel_Name"]:
-    start -= 1
-while start > 0 and "gather_block" in steps[start - 1]["Kernel_Name"]:
-    start -= 1
-use = steps[start:]
+# Whole steps only.  Every step holds exactly one tagged launch and ends with the kernel the trace ends with; a step's
+# last launch is therefore the last kernel of that name before the next step's tagged launch.  The warm-up step is dropped.
+last_name = steps[-1]["Kernel_Name"]
+ends = []
+for a_, b_ in zip(tagged, tagged[1:] + [len(steps)]):
+    ends.append(max(j for j in range(a_, b_) if steps[j]["Kernel_Name"] == last_name))
+use = steps[ends[0] + 1: ends[-1] + 1]
 n = max(nsteps - 1, 1)
-t0, t1 = int(use[0]["Start_Timestamp"]), int(use[-1]["End_Timestamp"])
+agg = collections.OrderedDict()
+t0, t1 = int(steps[ends[0]]["End_Timestamp"]), int(use[-1]["End_Timestamp"])
 for r in use:
     name = r["Kernel_Name"].split("(")[0].replace("void crm::", "").replace("(anonymous namespace)::", "")
     key = (name[:70], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""), r.get("Grid_Size_Z", ""))
@@ -35,12 +33,13 @@ for r in use:
     a = agg.setdefault(key, [0, 0.0])
     a[0] += 1
     a[1] += d
-print("steps analysed: %d; wall %.2f ms per step; kernel time per step by (kernel, grid x, grid z):" % (n, (t1 - t0) * 1e-6 / n))
+print("whole steps analysed: %d (warm-up dropped); %.2f ms per step from the end of one step's last kernel to the end of the next one's; "
+      "kernel time per step by (kernel, grid x, grid z):" % (n, (t1 - t0) * 1e-6 / n))
 tot = 0.0
 for key, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%9.3f ms  x%-5.1f %s  grid %s z %s" % (ms / n, cnt / n, key[0], key[1], key[2]))
     tot += ms
-print("%9.3f ms  sum of kernel time per step" % (tot / n))
+print("%9.3f ms  sum of kernel time per step; %.3f ms per step between kernels (launch gaps, host)" % (tot / n, (t1 - t0) * 1e-6 / n - tot / n))
 PY
 rm -rf $out/prof
 head -40 $out/step_breakdown.txt

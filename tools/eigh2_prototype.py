@@ -87,73 +87,45 @@ def stage1(C, k1, w):
     return A, blocks
 
 
-def to_band_storage(A, w):
-    """AB[c, i] = A[c + i, c] for 0 <= i < 2 w (room for the chase's fill), zero beyond the matrix."""
+def chase(A, w):
+    """Symmetric band matrix (dense storage, half-width w) -> tridiagonal.  Returns d, e and the reflectors
+    {(s, k): (r0, v, tau)} (sweep s, chain position k; rows r0 = s + 1 + k w ...).  The device keeps the band in lower
+    band storage AB[c][row - c] with room for the fill (2 w entries per column); the arithmetic is the same."""
+    A = A.copy()
     n = A.shape[0]
-    AB = np.zeros((n + 2 * w, 2 * w))
-    for c in range(n):
-        m = min(w + 1, n - c)
-        AB[c, :m] = A[c:c + m, c]
-    return AB
-
-
-def chase(AB, n, w):
-    """Band (lower storage, see to_band_storage) -> tridiagonal.  Returns d, e and the reflectors {(s, k): (r0, v, tau)}
-    (sweep s, chain position k; rows r0 = s + 1 + k w ...)."""
-    AB = AB.copy()
-
-    def get(r, c):            # symmetric access, lower storage
-        if r < c:
-            r, c = c, r
-        return AB[c, r - c]
-
-    def block(r0, nr, c0, nc):
-        return np.array([[get(r0 + i, c0 + j) for j in range(nc)] for i in range(nr)])
-
-    def put_lower(r0, nr, c0, nc, M):
-        for i in range(nr):
-            for j in range(nc):
-                r, c = r0 + i, c0 + j
-                if r >= c:
-                    assert r - c < 2 * w
-                    AB[c, r - c] = M[i, j]
-
     refl = {}
     for s in range(n - 2):
         # reflector of the sweep's own column
         r0 = s + 1
         L = min(w, n - r0)
-        x = np.array([get(r0 + i, s) for i in range(L)])
-        v, tau, beta = house(x)
-        AB[s, 1] = beta
-        AB[s, 2:L + 1] = 0.0
+        v, tau, beta = house(A[r0:r0 + L, s].copy())
+        A[r0:r0 + L, s] = 0.0
+        A[r0, s] = beta
+        A[s, r0:r0 + L] = A[r0:r0 + L, s]
         k = 0
         while True:
             refl[(s, k)] = (r0, v, tau)
             # (a) two-sided update of the diagonal block
-            D = block(r0, L, r0, L)
+            D = A[r0:r0 + L, r0:r0 + L]
             p = tau * (D @ v)
             q = p - 0.5 * tau * np.dot(p, v) * v
             D -= np.outer(v, q) + np.outer(q, v)
-            put_lower(r0, L, r0, L, D)
             # (b) the block below: right-multiplied, first column annihilated, the rest left-multiplied
             r1 = r0 + L
             L1 = min(w, n - r1)
             if L1 <= 0:
                 break
-            B = block(r1, L1, r0, L)
+            B = A[r1:r1 + L1, r0:r0 + L]
             B -= tau * np.outer(B @ v, v)
             v1, tau1, beta1 = house(B[:, 0].copy())
             B[0, 0] = beta1
             B[1:, 0] = 0.0
             if L > 1:
                 B[:, 1:] -= tau1 * np.outer(v1, v1 @ B[:, 1:])
-            put_lower(r1, L1, r0, L, B)
+            A[r0:r0 + L, r1:r1 + L1] = B.T
             r0, L, v, tau = r1, L1, v1, tau1
             k += 1
-    d = AB[:n, 0].copy()
-    e = AB[:n - 1, 1].copy()
-    return d, e, refl
+    return np.diag(A).copy(), np.diag(A, -1).copy(), refl
 
 
 def back2(Z, refl, n, w, g):
@@ -197,8 +169,7 @@ def eigh_family(C, k1, rhos, w=8, g=None):
     out = []
     for rho in rhos:
         dscale = np.r_[np.full(k1, np.sqrt(rho)), np.full(n - k1, np.sqrt(1.0 - rho))]
-        AB = to_band_storage(Band * np.outer(dscale, dscale), w)
-        d, e, refl = chase(AB, n, w)
+        d, e, refl = chase(Band * np.outer(dscale, dscale), w)
         lam, Zt = eigh_tridiagonal(d, e)
         Z = back1(back2(Zt, refl, n, w, g), blocks)
         out.append((lam, Z))
