@@ -324,6 +324,41 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
         // the context's cached work buffers (grown on demand; see crm_ctx::eigh_ws)
         EighWork& ew = *acquire_eigh_workspace(ctx);
         struct EGuard { crm_ctx* c; ~EGuard() { release_eigh_workspace(c); } } eguard{ctx};
+        // Two-stage form for the thin branch's family  A(rho) = D(rho) C D(rho)  (eigh2_band.hip): the leading block --
+        // the k1 contexts' columns, padded in front with zero rows / columns to 64 coordinates -- is the first panel of a
+        // dense -> band reduction done ONCE, each grid point then only chases its own rescaling of that band.  The padding
+        // adds 64 - k1 null directions, which the rank rule below drops like any other.
+        const long pad = (thin && sub == dim && k1 >= 1 && k1 <= E2_W && eigh2_serves(sub + (E2_W - k1), npts)) ? E2_W - k1 : -1;
+        std::vector<double> lam;
+        double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
+        long voff = 0, nlam = sub;
+        bool solved = false;
+        if (pad >= 0) {
+            const long sub2 = sub + pad;
+            CRM_TRY(eigh_alloc(ew, npts, sub2));
+            trace.lap("  eigen workspace");
+            CRM_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * ew.slab, st));
+            dim3 grid((unsigned)((sub + 255) / 256), (unsigned)sub);
+            hipLaunchKernelGGL(scale_gram_kernel, grid, dim3(256), 0, st, dC.as<double>(), cp, (int)sub, k1, 1.0, 1.0,
+                               ew.A.as<double>() + pad * ew.ld + pad, ew.ld);
+            CRM_HIP(hipGetLastError());
+            std::vector<double> wa(npts), wb(npts);
+            for (int q = 0; q < npts; q++) {
+                wa[q] = std::sqrt(rho[pts[q]]);
+                wb[q] = std::sqrt(1.0 - rho[pts[q]]);
+            }
+            lam.resize((size_t)npts * sub2);
+            const int rc = eigh2_family(ctx, ew, wa.data(), wb.data(), lam.data(), &Zt);
+            if (rc == CRM_OK) {
+                solved = true;
+                voff = pad;
+                nlam = sub2;
+                trace.lap("eigen-decompositions (two-stage)");
+            } else if (rc != CRM_ERR_UNSUPPORTED) {
+                return rc;
+            }
+        }
+        if (!solved) {
         CRM_TRY(eigh_alloc(ew, npts, sub));
         trace.lap("  eigen workspace");
         CRM_HIP(hipMemsetAsync(ew.A.ptr, 0, sizeof(double) * (size_t)npts * ew.slab, st));
@@ -343,22 +378,22 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
             }
         }
         CRM_HIP(hipGetLastError());
-        std::vector<double> lam((size_t)npts * sub);
-        double* Zt = nullptr;   // rows = eigenvectors, leading dimension ew.ld
+        lam.assign((size_t)npts * sub, 0.0);
         trace.lap("  scaled Gram matrices");
         CRM_TRY(eigh_batched(ctx, ew, lam.data(), &Zt));
         trace.lap("eigen-decompositions");
+        }
         ScopedBuf wKeep, wLam;
-        CRM_TRY(wKeep.ensure(sizeof(int) * subp));
-        CRM_TRY(wLam.ensure(sizeof(double) * subp));
+        CRM_TRY(wKeep.ensure(sizeof(int) * (subp + 128)));
+        CRM_TRY(wLam.ensure(sizeof(double) * (subp + 128)));
         for (int q = 0; q < npts; q++) {
             const int i = pts[q];
-            const double* hW = &lam[(size_t)q * sub];   // ascending
+            const double* hW = &lam[(size_t)q * nlam];   // ascending
             const double a = std::sqrt(rho[i]), b = std::sqrt(1.0 - rho[i]);
             std::vector<int> keep;
             if (thin) {
-                const double cut = rel_tol * std::max(hW[sub - 1], 0.0);
-                for (long j = sub - 1; j >= 0; j--)  // descending, like singular values
+                const double cut = rel_tol * std::max(hW[nlam - 1], 0.0);
+                for (long j = nlam - 1; j >= 0; j--)  // descending, like singular values
                     if (hW[j] > cut && hW[j] > 0.0) keep.push_back((int)j);
             } else {
                 const double eps_small = 1.4901161193847656e-08;  // sqrt(machine eps), _math.py:204
@@ -375,9 +410,9 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
             CRM_TRY(bb->Mbuf[i].ensure(sizeof(double) * (thin ? cp : np) * ldm));
             CRM_HIP(hipMemsetAsync(bb->Mbuf[i].ptr, 0, sizeof(double) * (thin ? cp : np) * ldm, st));
             if (r > 0) {
-                const double* Vi = Zt + (size_t)q * ew.slab;
+                const double* Vi = Zt + (size_t)q * ew.slab + voff;   // (two-stage form: past the padding coordinates)
                 CRM_HIP(hipMemcpyAsync(wKeep.ptr, keep.data(), sizeof(int) * r, hipMemcpyHostToDevice, st));
-                CRM_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * sub, hipMemcpyHostToDevice, st));
+                CRM_HIP(hipMemcpyAsync(wLam.ptr, hW, sizeof(double) * nlam, hipMemcpyHostToDevice, st));
                 if (thin) {
                     dim3 grid((unsigned)((r + 255) / 256), (unsigned)sub);
                     hipLaunchKernelGGL(build_mixing_kernel, grid, dim3(256), 0, st, Vi, ew.ld, wLam.as<double>(),

@@ -402,7 +402,12 @@ int eigh2_to_band(crm_ctx* ctx, EighWork& w) {
         g.C = Wb; g.ldc = 64;
         g.M = (int)m; g.N = 64;
         probs[2 * (size_t)p] = g;
-        splits[p] = std::min(ksplit_max, split_for(dimp - r0, (m + 127) / 128));
+        {   // slices of whole stages, every one non-empty, at most ksplit_max of them
+            const long stages = (dimp - r0) / GEMM_BK;
+            const long want = std::min<long>(ksplit_max, split_for(dimp - r0, (m + 127) / 128));
+            const long per = (stages + want - 1) / want;
+            splits[p] = (int)((stages + per - 1) / per);
+        }
         GemmProblem u{};      // A22 -= [V; Z]' [Z; V]
         u.X = base + oPX + r0; u.ldx = ld;
         u.Y = base + oPY + r0; u.ldy = ld;

@@ -39,6 +39,18 @@ __device__ inline double ld_sc1(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+// 16-byte accesses that another CU can see / that bypass this CU's L1: buffer instructions with the sc1 bit (aux = 16)
+__device__ inline v2d ld_sc1_x2(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+__device__ inline void st_sc1_x2(__amdgpu_buffer_rsrc_t rs, int byte_off, double x, double y) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v2d){x, y}), rs, byte_off, 0, 16);
+}
+// barrier of a workgroup for its LDS traffic only: global loads in flight (prefetches) stay in flight
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct ChaseArgs {
     double* AB;  long ab_slab;      // [batch][dimp + 128][128]
     double* V;   long v_slab;       // [batch][npos][dimp][64]
@@ -66,7 +78,11 @@ __device__ inline double wave_house(double x, int lane, int len, double* tau_out
     return lane < len ? x * scale : 0.0;
 }
 
-// grid (G, batch), 256 threads, one workgroup per CU (the dynamic LDS request sees to that)
+// grid (G, batch), 256 threads, one workgroup per CU (the dynamic LDS request sees to that).
+// Latencies kept off the critical path of a step: the workgroup's barriers wait for LDS traffic only (a flag store or a
+// prefetch in flight does not hold them up); the predecessor's progress is re-read in the background once per step, so the
+// blocking poll is the exception; and when that progress already covers the NEXT step, its two blocks -- which this step
+// does not touch -- are fetched into registers while this step computes.
 __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
     extern __shared__ double sm[];
     double* Dm = sm;                    // [64][CH_LD] diagonal block, both triangles
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
     double* zv = qv + W;                // [64]
     double* zpart = zv + W;             // [4][64]
     double* scal = zpart + 4 * W;       // [8]
-    __shared__ int wait_ok;
+    __shared__ int wait_val, wait_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, b = blockIdx.y;
     const long n = a.n;
@@ -87,38 +103,45 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
     double* Vout = a.V + (size_t)b * a.v_slab;
     double* tauout = a.tau + (size_t)b * a.tau_slab;
     int* prog = a.prog + (size_t)b * a.prog_slab;
-
-    auto wait_for = [&](long s_prev, int need) -> bool {   // progress[s_prev] >= need (or the sweep has ended)
-        if (s_prev < 0) return true;
-        if (tid == 0) {
-            int ok = 1;
-            long spins = 0;
-            while (__hip_atomic_load(prog + s_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 4095) == 0) {
-                    if (spins > (1L << 26) || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
-                    }
-                }
-            }
-            wait_ok = ok;
-        }
-        __syncthreads();
-        return wait_ok != 0;
-    };
-    auto publish = [&](long s, int value) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(prog + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(AB, 0, (int)(a.ab_slab * 8), 0x00020000);
 
     for (long s = blockIdx.x; s < n - 2; s += G) {
-        if (!wait_for(s - 1, 2)) return;
+        int seen = s > 0 ? 0 : PROG_DONE;      // progress of sweep s - 1 as last observed (the same on every thread)
+        // blocking form: poll until the predecessor has finished `need` steps
+        auto ensure = [&](int need) -> bool {
+            if (seen >= need) return true;
+            if (tid == 0) {
+                int ok = 1, val;
+                long spins = 0;
+                while ((val = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 4095) == 0) {
+                        if (spins > (1L << 26) || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                }
+                wait_val = val;
+                wait_ok = ok;
+            }
+            lds_barrier();
+            seen = wait_val;
+            const bool ok = wait_ok != 0;
+            lds_barrier();
+            return ok;
+        };
+        auto fetch = [&](long r_, v2d (&x)[16]) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e2 = tid + 256 * q, j = e2 >> 6, o = (e2 & 63) * 2;
+                x[q] = ld_sc1_x2(rs, (int)(((r_ + j) * 128 + o) * 8));
+            }
+        };
+        if (!ensure(2)) return;
         long r = s + 1;
         int L = (int)min((long)W, n - r);
-        double tau;
         // the sweep's own reflector from column s
         if (wave == 0) {
             const double x = lane < L ? ld_sc1(AB + s * 128 + 1 + lane) : 0.0;
@@ -128,24 +151,40 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
             if (lane == 0) { scal[0] = t; st_sc1(AB + s * 128 + 1, beta); }
             else if (lane < L) st_sc1(AB + s * 128 + 1 + lane, 0.0);
         }
-        __syncthreads();
-        tau = scal[0];
+        lds_barrier();
+        double tau = scal[0];
         int k = 0;
+        bool have = false;
+        v2d xr[16];
         while (true) {
-            if (k > 0 && !wait_for(s - 1, k + 2)) return;
             const long r1 = r + L;
             const int L1 = (int)max(0L, min((long)W, n - r1));
-            // ---- load the diagonal block (mirrored) and the block below --------------------------------------------
-            for (int e = tid; e < W * CH_LD; e += 256) { Dm[e] = 0.0; Bm[e] = 0.0; }
-            __syncthreads();
-            for (int e = tid; e < W * 128; e += 256) {
-                const int j = e >> 7, o = e & 127, i = j + o;
-                if (j >= L || i >= L + L1) continue;
-                const double x = ld_sc1(AB + (r + j) * 128 + o);
-                if (i < L) { Dm[i * CH_LD + j] = x; Dm[j * CH_LD + i] = x; }
-                else Bm[(i - L) * CH_LD + j] = x;
+            if (!have) {
+                if (!ensure(k + 2)) return;
+                fetch(r, xr);
             }
-            __syncthreads();
+            int peek = 0;
+            if (tid == 0 && s > 0) peek = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- the two blocks into LDS (the diagonal one mirrored) -------------------------------------------------------
+            if (L < W || L1 < W) {      // (the end of the band: partial blocks, the rest of the LDS image must read zero)
+                for (int e = tid; e < W * CH_LD; e += 256) { Dm[e] = 0.0; Bm[e] = 0.0; }
+                lds_barrier();
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e2 = tid + 256 * q, j = e2 >> 6, o = (e2 & 63) * 2;
+                if (j >= L) continue;
+                for (int h = 0; h < 2; h++) {
+                    const int i = j + o + h;
+                    if (i >= L + L1) continue;
+                    if (i < L) { Dm[i * CH_LD + j] = xr[q][h]; Dm[j * CH_LD + i] = xr[q][h]; }
+                    else Bm[(i - L) * CH_LD + j] = xr[q][h];
+                }
+            }
+            // the next step's blocks, if the predecessor is known to be far enough ahead already
+            have = L1 > 0 && seen >= k + 3;
+            if (have) fetch(r1, xr);
+            lds_barrier();
             // ---- (D; B) v ----------------------------------------------------------------------------------------------
             {
                 const int i = tid & 127, half = tid >> 7;
@@ -154,16 +193,18 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
                 for (int j = half * 32; j < half * 32 + 32; j++) acc += row[j] * v[j];
                 part[half * 128 + i] = acc;
             }
-            __syncthreads();
+            lds_barrier();
             if (tid < 128) pu[tid] = part[tid] + part[128 + tid];
-            __syncthreads();
+            lds_barrier();
             if (wave == 0) {    // p = tau D v,  q = p - 1/2 tau (p'v) v
                 const double p = tau * pu[lane];
                 double dot = p * v[lane];
                 for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
                 qv[lane] = p - 0.5 * tau * dot * v[lane];
+                if (lane == 0 && s > 0) wait_val = peek;      // (the background read of the predecessor's progress has landed)
             }
-            __syncthreads();
+            lds_barrier();
+            if (s > 0) seen = max(seen, wait_val);
             {
                 const int i = tid & 63, cq = tid >> 6;
                 const double vi = v[i], qi = qv[i], ui = tau * pu[W + i];
@@ -172,7 +213,7 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
                     Bm[i * CH_LD + j] -= ui * v[j];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- the fill's first column -> next reflector; the rest of the block from the left -------------------------
             double tau1 = 0.0;
             if (L1 > 0) {
@@ -184,7 +225,7 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
                     if (lane < L1) Bm[lane * CH_LD] = lane == 0 ? beta : 0.0;
                     if (lane == 0) scal[1] = t;
                 }
-                __syncthreads();
+                lds_barrier();
                 tau1 = scal[1];
                 {
                     const int j = tid & 63, rq = tid >> 6;
@@ -192,35 +233,43 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
                     for (int i = rq * 16; i < rq * 16 + 16; i++) acc += v1[i] * Bm[i * CH_LD + j];
                     zpart[rq * 64 + j] = acc;
                 }
-                __syncthreads();
+                lds_barrier();
                 if (tid < 64) zv[tid] = tid >= 1 ? tau1 * (zpart[tid] + zpart[64 + tid] + zpart[128 + tid] + zpart[192 + tid]) : 0.0;
-                __syncthreads();
+                lds_barrier();
                 {
                     const int i = tid & 63, cq = tid >> 6;
                     const double vi = v1[i];
                     for (int j = cq * 16; j < cq * 16 + 16; j++) Bm[i * CH_LD + j] -= vi * zv[j];
                 }
-                __syncthreads();
+                lds_barrier();
             }
-            // ---- store: the band, the reflector of this step -----------------------------------------------------------
-            for (int e = tid; e < W * 128; e += 256) {
-                const int j = e >> 7, o = e & 127, i = j + o;
+            // ---- store: the band (slots past the two blocks hold zeros: nothing fills them), the reflector of this step -----
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int e2 = tid + 256 * q, j = e2 >> 6, o = (e2 & 63) * 2, i = j + o;
                 if (j >= L || i >= L + L1) continue;
-                st_sc1(AB + (r + j) * 128 + o, i < L ? Dm[i * CH_LD + j] : Bm[(i - L) * CH_LD + j]);
+                double x[2];
+                for (int h = 0; h < 2; h++) {
+                    const int ih = i + h;
+                    x[h] = ih < L ? Dm[ih * CH_LD + j] : (ih < L + L1 ? Bm[(ih - L) * CH_LD + j] : 0.0);
+                }
+                st_sc1_x2(rs, (int)(((r + j) * 128 + o) * 8), x[0], x[1]);
             }
             if (tid < W) Vout[((size_t)k * a.dimp + s) * W + tid] = tid < L ? v[tid] : 0.0;
             if (tid == 0) tauout[(size_t)k * a.dimp + s] = tau;
-            publish(s, L1 > 0 ? k + 1 : PROG_DONE);
+            // every wave's stores drained, then ONE lane raises the sweep's progress
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid == 0) __hip_atomic_store(prog + s, L1 > 0 ? k + 1 : PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (L1 <= 0) break;
-            __syncthreads();
             if (tid < W) v[tid] = v1[tid];
-            __syncthreads();
+            lds_barrier();
             tau = tau1;
             r = r1;
             L = L1;
             k++;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -234,56 +283,143 @@ __global__ void e2_diag_kernel(const double* __restrict__ AB, long ab_slab, long
 }
 
 // T of the group (sweep block S, chain position k): reflector j is v(S 64 + j, k) placed at rows j .. j + 63 of the
-// group's window.  S[j1][j2] = v_j1' v_j2 = sum_i v_j1[i] v_j2[i + j1 - j2] (j1 >= j2), then the dlarft recurrence.
+// group's window of 127 rows.  S = V'V over the window (V kept in window coordinates in LDS: lanes run along a row), then
+// the dlarft recurrence.
 __global__ __launch_bounds__(256) void e2_group_larft_kernel(const double* __restrict__ V, long v_slab, const double* __restrict__ tau,
-                                                             long tau_slab, long dimp, int npos, double* __restrict__ Tout,
+                                                             long tau_slab, long dimp, long n, int npos, double* __restrict__ Tout,
                                                              long t_slab) {
     extern __shared__ double lsm[];
-    double (*Vs)[W + 1] = reinterpret_cast<double (*)[W + 1]>(lsm);
-    double (*Ss)[W + 1] = Vs + W;
-    double (*Ts)[W + 1] = Ss + W;
-    double* taus = reinterpret_cast<double*>(Ts + W);
+    constexpr int LW = W + 1;
+    double* Vw = lsm;                  // [128][LW]  Vw[c][j] = v_j[c - j]
+    double* Ss = Vw + 128 * LW;        // [64][LW]
+    double* Ts = Ss + W * LW;          // [64][LW]
+    double* taus = Ts + W * LW;        // [64]
     const int k = blockIdx.x, S = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    if ((long)S * W + 1 + (long)k * W >= n) return;      // no reflector of this group exists
     const double* Vg = V + (size_t)b * v_slab + ((size_t)k * dimp + (size_t)S * W) * W;
-    for (int e = tid; e < W * W; e += 256) Vs[e >> 6][e & 63] = Vg[e];
+    for (int e = tid; e < 128 * LW; e += 256) Vw[e] = 0.0;
     if (tid < W) taus[tid] = tau[(size_t)b * tau_slab + (size_t)k * dimp + (size_t)S * W + tid];
     __syncthreads();
     for (int e = tid; e < W * W; e += 256) {
-        const int j1 = e >> 6, j2 = e & 63;
-        double s = 0.0;
-        if (j1 >= j2) {
-            const int sh = j1 - j2;
-            for (int i = 0; i + sh < W; i++) s += Vs[j1][i] * Vs[j2][i + sh];
-        }
-        Ss[j1][j2] = s;
-        Ts[j1][j2] = 0.0;
+        const int j = e >> 6, o = e & 63;
+        Vw[(j + o) * LW + j] = Vg[e];
     }
     __syncthreads();
-    for (int e = tid; e < W * W; e += 256) {   // symmetric
-        const int j1 = e >> 6, j2 = e & 63;
-        if (j1 < j2) Ss[j1][j2] = Ss[j2][j1];
+    for (int e = tid; e < W * W; e += 256) {
+        const int j1 = e >> 6, j2 = e & 63;          // (a wavefront shares j1)
+        const int lo = j1 > j2 ? j1 : j2, hi = (j1 < j2 ? j1 : j2) + W;   // rows where both reflectors live
+        double s = 0.0;
+        for (int c = lo; c < hi; c++) s += Vw[c * LW + j1] * Vw[c * LW + j2];
+        Ss[j1 * LW + j2] = s;
+        Ts[j1 * LW + j2] = 0.0;
     }
     __syncthreads();
     for (int i = 0; i < W; i++) {
         const double ti = taus[i];
         if (tid < i) {
             double acc = 0.0;
-            for (int m = tid; m < i; m++) acc += Ts[tid][m] * Ss[m][i];
-            Ts[tid][i] = -ti * acc;
+            for (int m = tid; m < i; m++) acc += Ts[tid * LW + m] * Ss[m * LW + i];
+            Ts[tid * LW + i] = -ti * acc;
         }
-        if (tid == i) Ts[i][i] = ti;
+        if (tid == i) Ts[i * LW + i] = ti;
         __syncthreads();
     }
     double* Tg = Tout + (size_t)b * t_slab + ((size_t)S * npos + k) * W * W;
-    for (int e = tid; e < W * W; e += 256) Tg[e] = Ts[e >> 6][e & 63];
+    for (int e = tid; e < W * W; e += 256) Tg[e] = Ts[(e >> 6) * LW + (e & 63)];
 }
 
 // ---- back-transformation through the chase's reflectors --------------------------------------------------------------
 constexpr int BT_ROWS = 48;     // eigenvectors per workgroup
 constexpr int ZS_LD = 132;      // window of 128 coordinates
-constexpr int VC_LD = 69;
+constexpr int VC_G = 18;        // zero guard on both sides of a reflector's 64 entries: the products read V[c][j] = Vc[j][c - j]
+constexpr int VC_LD = 101;      // for every c of a k-step, inside the band or not, without a select
 constexpr int TS_LD = 68;
 constexpr int WS_LD = 68;
+
+// The three products of one group on the matrix pipe, for wavefront WV of the workgroup.  FP64 MFMAs and VALU
+// instructions do not overlap on this chip, so the loops carry no address arithmetic: every LDS address is a base
+// formed once per group plus a compile-time offset (hence the wavefront as a template parameter), and the parallelogram's
+// zeros come from guard bands in LDS instead of selects.
+//   W1[e][j]  = sum_c Z[e][c] V[c][j]            wave -> j in [16 WV, 16 WV + 16), k-steps c in [16 WV, 16 WV + 80)
+//   W2[e][j'] = sum_j W1[e][j] T[j'][j]          wave -> j' tile WV, k-steps j >= 16 WV (T upper triangular)
+//   Z[e][c]  -= sum_j W2[e][j] V[c][j]           wave -> two column tiles of c (twenty k-steps together)
+template <int WV>
+__device__ __forceinline__ void bt2_products(double* __restrict__ Zs, const double* __restrict__ Vc, const double* __restrict__ Ts,
+                                             double* __restrict__ Ws, int par, int l15, int lq) {
+    v4d acc[3];
+    double* zh[2];      // logical halves of the window
+    zh[0] = Zs + (par ? 64 : 0);
+    zh[1] = Zs + (par ? 0 : 64);
+    {
+        const double* bB = Vc + (16 * WV + l15) * VC_LD + VC_G + lq - l15;
+        const double* aA0 = zh[0] + l15 * ZS_LD + lq;
+        const double* aA1 = zh[1] + l15 * ZS_LD + lq;
+#pragma unroll
+        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 20; i++) {
+            const int c0 = 16 * WV + 4 * i;
+            const double* aA = (c0 >> 6) ? aA1 : aA0;
+            const double bv = bB[4 * i];
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[16 * m * ZS_LD + (c0 & 63)], bv, acc[m], 0, 0, 0);
+        }
+        double* w = Ws + lq * WS_LD + 16 * WV + l15;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) w[(16 * m + 4 * reg) * WS_LD] = acc[m][reg];
+    }
+    lds_barrier();
+    {
+        const double* bT = Ts + (16 * WV + l15) * TS_LD + 16 * WV + lq;
+        const double* aW = Ws + l15 * WS_LD + 16 * WV + lq;
+#pragma unroll
+        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16 - 4 * WV; i++) {
+            const double bv = bT[4 * i];
+#pragma unroll
+            for (int m = 0; m < 3; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[16 * m * WS_LD + 4 * i], bv, acc[m], 0, 0, 0);
+        }
+    }
+    lds_barrier();
+    {
+        double* w = Ws + lq * WS_LD + 16 * WV + l15;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) w[(16 * m + 4 * reg) * WS_LD] = acc[m][reg];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        constexpr int NTA = WV == 0 ? 0 : WV == 1 ? 1 : WV == 2 ? 4 : 5;
+        constexpr int NTB = WV == 0 ? 3 : WV == 1 ? 2 : WV == 2 ? 7 : 6;
+        const int nt = half == 0 ? NTA : NTB;
+        const int jlo = 16 * nt - 63 > 0 ? 16 * nt - 63 : 0, jhi = 16 * nt + 15 < 63 ? 16 * nt + 15 : 63;
+        const int ks0 = jlo >> 2, steps = (jhi >> 2) - ks0 + 1;
+        const double* bB = Vc + (4 * ks0 + lq) * VC_LD + VC_G + 16 * nt + l15 - 4 * ks0 - lq;
+        const double* aW = Ws + l15 * WS_LD + 4 * ks0 + lq;
+#pragma unroll
+        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < steps) {
+                const double bv = bB[i * (4 * VC_LD - 4)];
+#pragma unroll
+                for (int m = 0; m < 3; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[16 * m * WS_LD + 4 * i], bv, acc[m], 0, 0, 0);
+            }
+        }
+        double* z = zh[(16 * nt) >> 6] + lq * ZS_LD + ((16 * nt) & 63) + l15;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) z[(16 * m + 4 * reg) * ZS_LD] -= acc[m][reg];
+    }
+    lds_barrier();
+}
 
 struct Bt2Args {
     double* Qt; long slab, ld;          // rows = eigenvectors
@@ -293,10 +429,13 @@ struct Bt2Args {
     int npos, nS, tasks_per_matrix;
 };
 
-// grid: (tasks_per_matrix * batch), 256 threads
+// grid: (tasks_per_matrix * batch), 256 threads.  Per sweep block the 128-column window slides down the eigenvectors 64
+// columns per group: the half that leaves is stored, the half that stays keeps its place in LDS (the halves swap roles by
+// parity), and the next group's reflectors, T and 64 new columns are fetched into registers while this group's products
+// run on the matrix pipe.
 __global__ __launch_bounds__(256) void e2_bt2_kernel(Bt2Args a) {
     extern __shared__ double sm[];
-    double* Zs = sm;                          // [48][ZS_LD]
+    double* Zs = sm;                          // [48][ZS_LD]  two halves of 64 columns
     double* Vc = Zs + BT_ROWS * ZS_LD;        // [64][VC_LD]   Vc[j][o] = v_j[o]
     double* Ts = Vc + W * VC_LD;              // [64][TS_LD]
     double* Ws = Ts + W * TS_LD;              // [48][WS_LD]
@@ -308,81 +447,72 @@ __global__ __launch_bounds__(256) void e2_bt2_kernel(Bt2Args a) {
     const double* Vb = a.V + (size_t)b * a.v_slab;
     const double* Tb = a.T + (size_t)b * a.t_slab;
     const long n = a.n;
-    // product 3's column tiles per wave: {0,3} {1,2} {4,7} {5,6} -- twenty k-steps each
-    const int nt_a = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 4 : 5;
-    const int nt_b = wave == 0 ? 3 : wave == 1 ? 2 : wave == 2 ? 7 : 6;
+    auto phys = [](int c, int par) { return (c & 63) | ((((c >> 6) ^ par) & 1) << 6); };
+    for (int e = tid; e < W * VC_LD; e += 256) Vc[e] = 0.0;     // (the guard bands stay zero)
     for (int S = a.nS - 1; S >= 0; S--) {
-        const long s0 = (long)S * W;
-        for (int k = 0; k < a.npos; k++) {
-            const long c0 = s0 + 1 + (long)k * W;
-            if (c0 >= n) break;
-            const int width = (int)min(128L, n - c0);
-            // ---- load the window, the group's reflectors and T -----------------------------------------------------------
-            __syncthreads();
-            for (int e = tid; e < BT_ROWS * 128; e += 256) {
-                const int r = e >> 7, c = e & 127;
-                Zs[r * ZS_LD + c] = (r < ne && c < width) ? Q[(size_t)r * a.ld + c0 + c] : 0.0;
+        const long s0 = (long)S * W, c00 = s0 + 1;
+        if (c00 >= n) continue;
+        const int kc = (int)((n - c00 + W - 1) / W);      // groups with a window inside the vectors
+        // ---- the first window of the block, its reflectors and T ------------------------------------------------------------
+        __syncthreads();
+        for (int e = tid; e < BT_ROWS * 128; e += 256) {
+            const int r = e >> 7, c = e & 127;
+            Zs[r * ZS_LD + c] = (r < ne && c00 + c < n) ? Q[(size_t)r * a.ld + c00 + c] : 0.0;
+        }
+        {
+            const v2d* Vg = reinterpret_cast<const v2d*>(Vb + (size_t)s0 * W);
+            const v2d* Tg = reinterpret_cast<const v2d*>(Tb + (size_t)S * a.npos * W * W);
+            for (int q = 0; q < 8; q++) {
+                const int e2 = (tid + 256 * q) * 2;
+                const v2d x = Vg[tid + 256 * q], y = Tg[tid + 256 * q];
+                Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63)] = x[0]; Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63) + 1] = x[1];
+                Ts[(e2 >> 6) * TS_LD + (e2 & 63)] = y[0]; Ts[(e2 >> 6) * TS_LD + (e2 & 63) + 1] = y[1];
             }
-            const double* Vg = Vb + ((size_t)k * a.dimp + (size_t)s0) * W;
-            const double* Tg = Tb + ((size_t)S * a.npos + k) * W * W;
-            for (int e = tid; e < W * W; e += 256) {
-                Vc[(e >> 6) * VC_LD + (e & 63)] = Vg[e];
-                Ts[(e >> 6) * TS_LD + (e & 63)] = Tg[e];
-            }
-            __syncthreads();
-            // ---- W1[e][j] = sum_c Zs[e][c] V[c][j],  V[c][j] = Vc[j][c - j]:  wave -> column tile j in [16 wave, +16) --------
-            v4d acc[3];
-            for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-            {
-                const int j = 16 * wave + l15;
-                for (int ks = 4 * wave; ks < 4 * wave + 20; ks++) {
-                    const int c = 4 * ks + lq, o = c - j;
-                    const double bv = (o >= 0 && o < W) ? Vc[j * VC_LD + o] : 0.0;
-                    for (int m = 0; m < 3; m++)
-                        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Zs[(16 * m + l15) * ZS_LD + c], bv, acc[m], 0, 0, 0);
-                }
-                for (int m = 0; m < 3; m++)
-                    for (int reg = 0; reg < 4; reg++) Ws[(16 * m + lq + 4 * reg) * WS_LD + j] = acc[m][reg];
-            }
-            __syncthreads();
-            // ---- W2[e][j'] = sum_j W1[e][j] T[j'][j]  (T upper triangular: j >= j') ----------------------------------------
-            for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-            {
-                const int jp = 16 * wave + l15;
-                for (int ks = 4 * wave; ks < 16; ks++) {
-                    const int j = 4 * ks + lq;
-                    const double bv = Ts[jp * TS_LD + j];
-                    for (int m = 0; m < 3; m++)
-                        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(16 * m + l15) * WS_LD + j], bv, acc[m], 0, 0, 0);
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; k++) {
+            const long c0 = c00 + (long)k * W;
+            const int par = k & 1;
+            const bool more = k + 1 < kc;
+            // ---- (i) the next group's data on its way into registers ------------------------------------------------------
+            v2d pv[8], pt[8];
+            double pz[12];
+            if (more) {
+                const v2d* Vg = reinterpret_cast<const v2d*>(Vb + ((size_t)(k + 1) * a.dimp + (size_t)s0) * W);
+                const v2d* Tg = reinterpret_cast<const v2d*>(Tb + ((size_t)S * a.npos + k + 1) * W * W);
+#pragma unroll
+                for (int q = 0; q < 8; q++) { pv[q] = Vg[tid + 256 * q]; pt[q] = Tg[tid + 256 * q]; }
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
+                    pz[q] = (r < ne && c0 + 128 + cc < n) ? Q[(size_t)r * a.ld + c0 + 128 + cc] : 0.0;
                 }
             }
-            __syncthreads();
-            {
-                const int jp = 16 * wave + l15;
-                for (int m = 0; m < 3; m++)
-                    for (int reg = 0; reg < 4; reg++) Ws[(16 * m + lq + 4 * reg) * WS_LD + jp] = acc[m][reg];
+            // ---- (ii) the three products ------------------------------------------------------------------------------------
+            switch (wave) {
+                case 0: bt2_products<0>(Zs, Vc, Ts, Ws, par, l15, lq); break;
+                case 1: bt2_products<1>(Zs, Vc, Ts, Ws, par, l15, lq); break;
+                case 2: bt2_products<2>(Zs, Vc, Ts, Ws, par, l15, lq); break;
+                default: bt2_products<3>(Zs, Vc, Ts, Ws, par, l15, lq); break;
             }
-            __syncthreads();
-            // ---- Zs[e][c] -= sum_j W2[e][j] V[c][j] ---------------------------------------------------------------------
-            for (int half = 0; half < 2; half++) {
-                const int nt = half == 0 ? nt_a : nt_b;
-                const int c = 16 * nt + l15;
-                const int jlo = max(0, 16 * nt - 63), jhi = min(63, 16 * nt + 15);
-                for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int ks = jlo >> 2; ks <= jhi >> 2; ks++) {
-                    const int j = 4 * ks + lq, o = c - j;
-                    const double bv = (o >= 0 && o < W) ? Vc[j * VC_LD + o] : 0.0;
-                    for (int m = 0; m < 3; m++)
-                        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(16 * m + l15) * WS_LD + j], bv, acc[m], 0, 0, 0);
+            // ---- (iii) the half that leaves the window goes home; (iv) its place takes the columns that enter ---------------
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
+                double* z = Zs + r * ZS_LD + phys(cc, par);
+                if (r < ne && c0 + cc < n) Q[(size_t)r * a.ld + c0 + cc] = *z;
+                if (more) *z = pz[q];
+                else if (r < ne && c0 + 64 + cc < n) Q[(size_t)r * a.ld + c0 + 64 + cc] = Zs[r * ZS_LD + phys(64 + cc, par)];
+            }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int e2 = (tid + 256 * q) * 2;
+                    Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63)] = pv[q][0]; Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63) + 1] = pv[q][1];
+                    Ts[(e2 >> 6) * TS_LD + (e2 & 63)] = pt[q][0]; Ts[(e2 >> 6) * TS_LD + (e2 & 63) + 1] = pt[q][1];
                 }
-                for (int m = 0; m < 3; m++)
-                    for (int reg = 0; reg < 4; reg++) Zs[(16 * m + lq + 4 * reg) * ZS_LD + c] -= acc[m][reg];
             }
-            __syncthreads();
-            for (int e = tid; e < BT_ROWS * 128; e += 256) {
-                const int r = e >> 7, c = e & 127;
-                if (r < ne && c < width) Q[(size_t)r * a.ld + c0 + c] = Zs[r * ZS_LD + c];
-            }
+            lds_barrier();
         }
     }
 }
@@ -440,10 +570,10 @@ int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Qt) {
     const int nS = (int)((n - 2 + W - 1) / W);
     const long t_slab = (long)nS * npos * W * W;
     CRM_TRY(w.Tbc.ensure(sizeof(double) * (size_t)t_slab * B));
-    const size_t lds_t = sizeof(double) * (3 * W * (W + 1) + W);
+    const size_t lds_t = sizeof(double) * (4 * W * (W + 1) + W);
     CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&e2_group_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
     hipLaunchKernelGGL(e2_group_larft_kernel, dim3(npos, nS, B), dim3(256), lds_t, st, w.Vbc.as<double>(), (long)npos * dimp * W,
-                       w.taubc.as<double>(), (long)npos * dimp, dimp, npos, w.Tbc.as<double>(), t_slab);
+                       w.taubc.as<double>(), (long)npos * dimp, dimp, n, npos, w.Tbc.as<double>(), t_slab);
     Bt2Args a{};
     a.Qt = Qt; a.slab = w.slab; a.ld = w.ld;
     a.V = w.Vbc.as<double>(); a.v_slab = (long)npos * dimp * W;
