@@ -121,9 +121,8 @@ def roofline_record(lib, ctx, crm, config, kr_ms, kr_n, kr_fl, elapsed):
     # L2-fabric traffic of that kernel is NOT measured by this run (PMC counters need their own rocprofv3 --pmc passes,
     # tools/pmc_bench.sh): the figure of the committed profile is quoted only when it was collected on the same launch
     # shape AND the same kernel form (persistent / one workgroup per tile, tail launch, library version); otherwise null.
-    form = {"contraction_sync": int(os.environ.get("CRM_CONTRACTION_SYNC", "1") or 0) > 0 and not lib.crm_test_sync_fallbacks(ctx),
-            "tail_launch": not os.environ.get("CRM_KR_NO_TAIL"), "library": lib.crm_version().decode(),
-            "kinship_route": bool(kin_groups), "tile_band": int(os.environ.get("CRM_TILE_BAND", "8") or 0)}
+    form = {"contraction_sync": not lib.crm_test_sync_fallbacks(ctx), "tail_launch": True, "library": lib.crm_version().decode(),
+            "kinship_route": bool(kin_groups), "tile_band": 8}
     roofline["kernel_form"] = form
     for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r03_pmc_summary_direct_route.json", "r02_pmc_summary.json"):
         try:

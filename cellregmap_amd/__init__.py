@@ -29,7 +29,7 @@ class Term(Enum):
     RANDOM = 2
 
 
-__version__ = "0.4.0"
+__version__ = "0.5.0"
 
 __all__ = [
     "__version__",

@@ -907,9 +907,11 @@ class CellRegMap:
     def scan_interaction_info(self, G, idx_E=None, idx_G=None):
         """The p-values together with chiscore's ``info`` of ``davies_pvalue(Q, F, True)`` (which the reference
         computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"})``.
-        ``model_flags`` (bits ``MODEL_SATURATED`` = 1, ``MODEL_DELTA_AT_ZERO`` = 2, ``MODEL_G_IN_SPAN_W`` = 4, see
-        include/crm_hip.h) / ``degenerate`` mark the variants where the reference's own result is decided by rounding
-        noise (saturated model, null fit ending at delta = 0)."""
+        ``model_flags`` (bits ``MODEL_SATURATED`` = 1, ``MODEL_DELTA_AT_ZERO`` = 2, ``MODEL_G_IN_SPAN_W`` = 4,
+        ``MODEL_FLAT_OPTIMUM`` = 8, see include/crm_hip.h) / ``degenerate`` mark the variants where the reference's own
+        result is decided by rounding noise (saturated model, null fit ending at delta = 0); ``flat_optimum`` marks those
+        where the stopping point of the reference's Brent search (1e-6 on logit delta) matters beyond the tolerances
+        (statistics 1e-6, p-values 1e-5): two faithful runs may differ there, everywhere else they cannot."""
         lib = _lib.load()
         panel = self._panel(G)
         n, p = panel.shape
@@ -920,7 +922,7 @@ class CellRegMap:
         _lib.check(lib.crm_scan_interaction_info(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
                                                  _lib.ptr(ifault), _lib.ptr(liu), _lib.ptr(flags)))
         return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault,
-                    "model_flags": flags, "degenerate": (flags & 3) != 0}
+                    "model_flags": flags, "degenerate": (flags & 3) != 0, "flat_optimum": (flags & 8) != 0}
 
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False, progress=None):

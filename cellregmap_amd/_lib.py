@@ -69,6 +69,7 @@ SIGNATURES = {
     "crm_kernel_timer_reset": (ctypes.c_int, [vp]),
     "crm_kernel_timer_read": (ctypes.c_int, [vp, c_double_p, c_long_p, c_double_p, c_double_p]),
     "crm_kernel_timer_stop": (ctypes.c_int, [vp]),
+    "crm_test_set_form": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "crm_test_set_contraction": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
     "crm_test_set_shared_h": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_tail_launches": (ctypes.c_long, [vp]),

@@ -186,7 +186,7 @@ using namespace crm;
 extern "C" {
 
 const char* crm_last_error(void) { return last_error_text(); }
-const char* crm_version(void) { return "0.4.0"; }
+const char* crm_version(void) { return "0.5.0"; }
 
 int crm_ctx_create(int device, crm_ctx** out) {
     return crm::guarded("crm_ctx_create", [&]() -> int {
@@ -201,15 +201,9 @@ int crm_ctx_create(int device, crm_ctx** out) {
     CRM_HIP(hipSetDevice(device));
     crm_ctx* c = new crm_ctx();
     c->device = device;
-    // tuning knob: large Khatri-Rao launches run as persistent workgroups that re-align per XCD every k generations
-    // (default k = 1: 7.3x less L2-fabric traffic for 0.6 % of the kernel's time);
-    // CRM_CONTRACTION_SYNC=0 restores one workgroup per tile
-    if (const char* e = getenv("CRM_CONTRACTION_SYNC")) c->tune.sync = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("CRM_NULLFIT_EXACT")) c->nullfit_exact = atoi(e) != 0;
-    if (const char* e = getenv("CRM_FAST_ROTATION")) c->fast_T = atoi(e) != 0;   // (crm_set_fast_rotation)
-    if (const char* e = getenv("CRM_FAST_GENE_ROTATION")) c->fast_gene_rot = atoi(e) != 0;
+    // (the persistent form of large Khatri-Rao launches, the rotation routes and the tile walk are set through the C-ABI:
+    // crm_test_set_contraction_sync, crm_set_fast_rotation)
     if (const char* e = getenv("CRM_KIN_ROUTE")) c->kin_route = std::max(0, std::min(2, atoi(e)));
-    if (const char* e = getenv("CRM_TILE_BAND")) c->tune.band = atoi(e) > 1 ? atoi(e) : 0;   // (0 or 1: column tile of X first, the walk before round 3)
     CRM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRM_HIP(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
     CRM_HIP(hipEventCreate(&c->ev0));
@@ -302,6 +296,38 @@ int crm_set_fast_rotation(crm_ctx* c, int on) {
     if (!c) return CRM_ERR_ARG;
     c->fast_T = on != 0;
     return CRM_OK;
+    });
+}
+
+extern "C++" {
+namespace crm {
+namespace {
+struct FormSlot { const char* name; int value; bool set; };
+FormSlot g_forms[] = {{"gram_staged", 0, false}, {"kr_no_tail", 0, false}, {"nullfit_per_wave", 0, false}, {"kin_fold", 0, false},
+                      {"eigh_one_stage", 0, false}, {"nullfit_exact", 0, false}};
+std::mutex g_forms_mu;
+}  // namespace
+int form(const char* name, int otherwise) {
+    std::lock_guard<std::mutex> lock(g_forms_mu);
+    for (const FormSlot& f : g_forms)
+        if (strcmp(f.name, name) == 0) return f.set ? f.value : otherwise;
+    return otherwise;
+}
+}  // namespace crm
+}  // extern "C++"
+
+int crm_test_set_form(const char* name, int value, int reset) {
+    return crm::guarded("crm_test_set_form", [&]() -> int {
+    if (!name) return CRM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(crm::g_forms_mu);
+    for (crm::FormSlot& f : crm::g_forms)
+        if (strcmp(f.name, name) == 0) {
+            f.value = value;
+            f.set = reset == 0;
+            return CRM_OK;
+        }
+    crm::set_error("crm_test_set_form: no kernel form is called '%s'", name);
+    return CRM_ERR_ARG;
     });
 }
 

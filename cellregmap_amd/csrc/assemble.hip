@@ -379,6 +379,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
     // 2 k0 P doubles per variant: the slower form)
     extern __shared__ double fsm[];
     __shared__ int ok_flag, keep_flag;
+    __shared__ double rescale;     // 1 / scale where the fit record asks for the scale to be derived here (fit.scale < 0)
     const int Pd = a.c + 1;
     double* Lm = fsm;
     double* xky = Lm + Pd * Pd;
@@ -494,11 +495,22 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
             xky[c] = 0.0;
         }
         keep_flag = keep ? 1 : 0;
+        rescale = 1.0;
         if (ok) {
             for (int i = 0; i < P; i++) {
                 double s = xky[i];
                 for (int k = 0; k < i; k++) s -= L(i, k) * xky[k];
                 xky[i] = s / L(i, i);
+            }
+            if (fit.scale < 0.0) {
+                // A record of (v0, v1) = (1 - delta, delta) without its scale (scan.hip: the probes of the flat-optimum flag):
+                // the REML scale at that delta is y'Py / df with P of the unit-scale covariance, from what is at hand --
+                // y'K^-1y and the forward-substituted X'K^-1y (glimix-core: LMM.scale; nullfit.hip evaluates the same).
+                double r = (a.yy - Ge[(long)(k0 + c + 1) * KT + (k0 + c + 1)]) * inv;
+                const int used = c + ((fit.use_g && keep) ? 1 : 0);
+                for (int i = 0; i < used; i++) r -= xky[i] * xky[i];
+                const double df = (double)a.n - (double)(c + (fit.use_g ? 1 : 0));
+                rescale = 1.0 / fmax(r / df, 1.4901161193847656e-08);
             }
             for (int i = P - 1; i >= 0; i--) {
                 double s = xky[i];
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
         const double dky = (a.Z1[(long)b * a.ldZ1 + j] - Ge[(long)j * KT + (k0 + c + 1)]) * inv;
         double u = dky;
         for (int i = 0; i < P; i++) u -= dkx(j, i) * xky[i];
-        uvec[j] = u;
+        uvec[j] = u * rescale;
     }
     __syncthreads();
     if (tid == 0) {
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(128) void finalize_kernel(AssembleArgs a, const dou
         const long pidx = (long)lo * k0 - (long)lo * (lo - 1) / 2 + (hi - lo);
         double v = (a.Z3[(long)b * a.ldZ3 + pidx] - Ge[(long)j * KT + jp]) * inv;
         for (int i = 0; i < P; i++) v -= dkx(j, i) * sol(jp, i);
-        F[e] = ok ? 0.5 * v : NAN;
+        F[e] = ok ? 0.5 * v * rescale : NAN;
     }
 }
 #undef L
@@ -583,7 +595,7 @@ int launch_assemble(hipStream_t st, const AssembleArgs& a, int variants, double*
     }
     const int ts = (KT + 15) / 16;
     // LDS-DMA form: 16-byte loads, so every row must start on a 16-byte boundary and hold an even number of doubles
-    bool dma = ts <= 4 && a.ldA % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && !getenv("CRM_GRAM_STAGED");
+    bool dma = ts <= 4 && a.ldA % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && !form("gram_staged", 0);
     for (int i = 0; dma && i < CRM_MAX_RHO; i++) {
         const AssembleRho& R = a.rho[i];
         if (R.r <= 0 && !R.ty) continue;

@@ -77,7 +77,7 @@ extern "C" int crm_scan_association(crm_gene* gene, crm_panel* panel, long first
     CRM_HIP(hipMemsetAsync(d_gy, 0, sizeof(double), st));
     CRM_HIP(hipMemsetAsync(d_gW, 0, sizeof(double) * ld_gW, st));
     NullFitArgs fa{};
-    fa.nrho = nrho; fa.c = c; fa.restricted = 0; fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.exact = ctx->nullfit_exact ? 1 : 0; fa.n = n;
+    fa.nrho = nrho; fa.c = c; fa.restricted = 0; fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.exact = (ctx->nullfit_exact || form("nullfit_exact", 0)) ? 1 : 0; fa.n = n;
     for (int i = 0; i < nrho; i++) {
         NullFitRho& R = fa.rho[i];
         R.T = d_zero; R.ldT = 0;

@@ -485,7 +485,7 @@ static int background_complete(crm_background* bg, const int* r_all) {
         CRM_HIP(hipMemsetAsync(dT1.ptr, 0, sizeof(double) * cp * ldq, st));
     }
     CRM_HIP(hipMemsetAsync(dG.ptr, 0, sizeof(double) * ldq * ldq * 2, st));
-    const bool eager = getenv("CRM_EAGER_Q0") != nullptr;
+    const bool eager = false;   // (Q0 = H Mix is formed the first time a scan selects the grid point)
     for (int i = 0; i < nrho; i++) {
         if (!thin) {   // (thin branch: Q0 = H Mix on first use, crm_background_require_q0)
             CRM_TRY(bg->Q0[i].ensure(sizeof(double) * np * ldq));

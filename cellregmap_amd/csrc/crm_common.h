@@ -38,6 +38,17 @@ const char* last_error_text();
 
 inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
 
+// Kernel forms that exist beside the default one (a slower or older variant kept because the default falls back to it, or
+// because a test holds the two against each other).  Process-wide switches set through crm_test_set_form
+// (include/crm_hip_test.h) -- not environment variables: the suite flips every one of them.
+//   "gram_staged"       1: score-statistic Gram through the register-staged kernel instead of the direct-to-LDS one
+//   "kr_no_tail"        1: the Khatri-Rao contraction of a block in one launch of 128-column tiles whatever the spectrum
+//   "nullfit_per_wave"  1: null fits with one independent wavefront per (variant, grid point) instead of the LDS-shared queue
+//   "kin_fold"          0: never fold the donor-level factor into the mixing matrices; 2: fold also with few columns of us
+//   "eigh_one_stage"    1: the constructor's eigen-solver tridiagonalises every grid point on its own (eigh_trd.hip)
+//   "nullfit_exact"     1: null-fit likelihood with IEEE division and one log per spectrum entry
+int form(const char* name, int otherwise);
+
 // No C++ exception may cross the C-ABI (ctypes / cgo / JNI callers cannot unwind, the process would end in
 // std::terminate): every extern "C" entry point runs its body through this guard, which turns std::bad_alloc,
 // std::length_error and anything else into a status code with the text in crm_last_error().

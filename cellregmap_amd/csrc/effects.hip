@@ -75,7 +75,7 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
     // a zero "variant" is dropped by the fit kernels (rank-deficient [M, 0]): exactly LMM(y, M)
     NullFitArgs fa{};
     fa.nrho = nrho; fa.c = c; fa.restricted = restricted ? 1 : 0;
-    fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.exact = ctx->nullfit_exact ? 1 : 0;
+    fa.polish = (ctx->polish && c <= CRM_MAX_COV) ? 1 : 0; fa.exact = (ctx->nullfit_exact || form("nullfit_exact", 0)) ? 1 : 0;
     fa.n = n;
     for (int i = 0; i < nrho; i++) {
         NullFitRho& R = fa.rho[i];

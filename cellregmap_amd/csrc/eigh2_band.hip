@@ -350,8 +350,7 @@ __global__ void e2_band_kernel(const double* __restrict__ A, long ld, long dim, 
 }  // namespace
 
 bool eigh2_serves(long dim, int batch) {
-    static const bool off = getenv("CRM_EIGH_ONE_STAGE") != nullptr;
-    return !off && batch >= 1 && dim >= 1024;
+    return !form("eigh_one_stage", 0) && batch >= 1 && dim >= 1024;
 }
 
 int eigh2_to_band(crm_ctx* ctx, EighWork& w) {

@@ -470,7 +470,7 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
     if (ctx->tune.sync > 0 && ctx->sync_timeouts_host && *ctx->sync_timeouts_host >= 8) {
         ctx->tune.sync = 0;
         ctx->sync_fallbacks++;
-        if (getenv("CRM_VERBOSE") || getenv("CRM_TRACE_SETUP"))
+        if (getenv("CRM_TRACE_SETUP"))
             fprintf(stderr, "[crm] persistent contraction: %u generation waits timed out (GPU shared?) -- falling back to one "
                             "workgroup per tile\n", *ctx->sync_timeouts_host);
     }

@@ -652,7 +652,7 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
     const size_t shared_lds = sizeof(double) * 3 * (size_t)sld;
     // (one covariate column -- the reference's default W = ones -- enough variants to keep 256 x 12 wavefronts busy, and
     // the three vectors of the longest spectrum within LDS)
-    if (queue && !force_wide && a.c == 1 && variants >= 1024 && shared_lds <= 144 * 1024 && !getenv("CRM_NULLFIT_PER_WAVE")) {
+    if (queue && !force_wide && a.c == 1 && variants >= 1024 && shared_lds <= 144 * 1024 && !form("nullfit_per_wave", 0)) {
         int cus = 256, dev = 0;
         CRM_HIP(hipGetDevice(&dev));
         CRM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

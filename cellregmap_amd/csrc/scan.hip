@@ -217,13 +217,12 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     // must exist: cols + padding <= ldh).
     bg->kin_fold = false;
     const long kfold = k1 + groups * (long)k2, m_pad = round_up(m, GEMM_BK);
-    const char* fold_env = getenv("CRM_KIN_FOLD");
+    const int fold_form = form("kin_fold", 1);   // 0 never, 1 where it pays, 2 also with few columns of us
     // (k2 >= 32: the folded form launches the per-donor sums for the us columns alone, 64 columns wide -- with few of them,
     // config 2's 20, one launch over [us | E1] together and the small contraction over the donors per block is the better
     // form: config 2 463 000 against 451 000 variant-tests/s.  k2 == 1 -- mode B, us a single column -- folds too: its us rows
     // are per-donor sums of the Khatri-Rao rows themselves, a plain batched product, see scan_pass step 6)
-    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && (k2 >= 32 || k2 == 1 || (fold_env && atoi(fold_env) > 1)) &&
-        !(fold_env && atoi(fold_env) == 0)) {
+    if ((double)kfold <= 1.25 * (double)bg->cols && bg->cols + (m_pad - m) <= bg->ldh && (k2 >= 32 || k2 == 1 || fold_form > 1) && fold_form != 0) {
         const long kdim = round_up(kfold, GEMM_BK), ldq = bg->ldq, ld_t = round_up(groups, 128);
         ScopedBuf hKdT, probs_dev;
         CRM_TRY(hKdT.ensure(sizeof(double) * m_pad * ld_t));
@@ -940,6 +939,26 @@ namespace crm {
 // path (the donor-level sums can only form [W, g]'K^-1[W, g] in the raw basis: eps / share instead of eps / sqrt(share))
 constexpr double COLLINEAR_TAU = 1e-2;
 
+// Fit records of the flat-optimum probes (include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM): delta moved by one stopping
+// tolerance of the reference's search on x = logit(delta) (brent-search: tol = 1e-6 |x| + 1e-6), unit scale -- the
+// assembly derives the scale at that delta itself (assemble.hip: fit.scale < 0).
+__global__ void flat_probe_fit_kernel(const crm::NullFitOut* __restrict__ fit, int count, double sign,
+                                      crm::NullFitOut* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    crm::NullFitOut f = fit[b];
+    const double tiny = 2.220446049250313e-16;
+    const double d = fmin(fmax(f.delta, tiny), 1.0 - tiny);
+    const double x = log(d) - log1p(-d);
+    const double tol = 1e-6 * fabs(x) + 1e-6;
+    const double dp = fmin(fmax(1.0 / (1.0 + exp(-(x + sign * tol))), tiny), 1.0 - tiny);
+    f.delta = dp;
+    f.v0 = 1.0 - dp;
+    f.v1 = dp;
+    f.scale = -1.0;
+    out[b] = f;
+}
+
 struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: count*k0, F: count*k0*k0)
     double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
     int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
@@ -1209,7 +1228,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // best form) followed by a re-ordering of its rows, unless P would be large (> 8 GB): then as a Khatri-Rao contraction
     // over all cells with the transposed store (64-wide tiles when k1 <= 64: 50 of 64 columns at config 3)
     const long ldP = round_up((long)(bg->kin ? bg->kin_k1 : 0) * k0, 128);
-    const bool e1_pairs = kfold && sizeof(double) * (double)np * (double)ldP <= 8.0 * (1ull << 30) && !getenv("CRM_KIN_E1_KR");
+    const bool e1_pairs = kfold && sizeof(double) * (double)np * (double)ldP <= 8.0 * (1ull << 30);
     if (kfold) {
         const long tiles6 = e1_pairs ? ((long)BLK + GEMM_BM - 1) / GEMM_BM * (ldP / 128) : ((long)BLK * k0 + GEMM_BM - 1) / GEMM_BM;
         const long slots6 = e1_pairs || bg->kin_k1 > 64 ? 512 : 768;
@@ -1322,7 +1341,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // E1 = E, the reference's default (and no context permutation): the pair features E1_a o E0_i are the symmetric
     // E_a E_i that the scan holds anyway for E0'diag(g^2)E0 (EE: k0 (k0 + 1) / 2 columns) -- half the product
     bool e1_sym = false;
-    if (e1_pairs && bg->kin_k1 == k0 && d_EE && !getenv("CRM_KIN_E1_GENERAL")) {
+    if (e1_pairs && bg->kin_k1 == k0 && d_EE) {
         int h_flag = 0;
         int* d_flag = reinterpret_cast<int*>(d_near);
         CRM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
@@ -1488,7 +1507,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         int cut_ks = 1;
         GemmProblem cut_probs[CRM_MAX_RHO];
         double* cut_dst[CRM_MAX_RHO];
-        if (fastT && !getenv("CRM_ROT_NO_CUT")) {
+        if (fastT) {
             const long slots = 2L * ctx_cus(ctx), mtl = (nb + GEMM_BM - 1) / GEMM_BM;
             long tiles[CRM_MAX_RHO], total = 0;
             int order[CRM_MAX_RHO];
@@ -1535,7 +1554,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
             NullFitArgs fa{};
-            fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0; fa.exact = ctx->nullfit_exact ? 1 : 0;
+            fa.nrho = nrho; fa.c = c; fa.restricted = 1; fa.n = n; fa.polish = ctx->polish ? 1 : 0; fa.exact = (ctx->nullfit_exact || form("nullfit_exact", 0)) ? 1 : 0;
             for (int i = 0; i < nrho; i++) {
                 NullFitRho& R = fa.rho[i];
                 R.T = ctx->ws_T.as<double>() + (size_t)i * BLK * ldT; R.ldT = ldT;
@@ -1674,7 +1693,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         int tail_split = 1, tail_maxn = 0;
         bool tail_of[CRM_MAX_RHO] = {false};
         if (!collapsed && !via_H && kr_split == 1 && ctx->tune.glds && ctx->tune.bn != 64 && ctx->tune.bn != 160 &&
-            !getenv("CRM_KR_NO_TAIL")) {
+            !form("kr_no_tail", 0)) {
             long tail_row_tiles = 0, main_tiles = 0;
             for (int i = 0; i < nrho; i++) {
                 if (cnt[i] == 0) continue;
@@ -2008,6 +2027,39 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             if (o.F) CRM_HIP(hipMemcpyAsync(o.F + done * k0 * k0, ctx->ws_F.ptr, sizeof(double) * nb * k0 * k0, hipMemcpyDeviceToHost, st));
             if (o.ifault) CRM_HIP(hipMemcpyAsync(o.ifault + done, d_if, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             if (o.liu) CRM_HIP(hipMemcpyAsync(o.liu + done, d_liu, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+            // flat-optimum probes (info calls only): the score test again with delta one stopping tolerance of the
+            // reference's search to either side; how far Q and p move says whether the search's last comparison matters
+            std::vector<char> flat;
+            if (o.flags) {
+                std::vector<double> q0(nb), p0(nb), q1(nb), p1(nb), lam0((size_t)nb * k0);
+                CRM_HIP(hipMemcpyAsync(lam0.data(), d_lam, sizeof(double) * (size_t)nb * k0, hipMemcpyDeviceToHost, st));
+                CRM_HIP(hipMemcpyAsync(q0.data(), d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+                CRM_HIP(hipMemcpyAsync(p0.data(), d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+                ScopedBuf probe;
+                CRM_TRY(probe.ensure(sizeof(NullFitOut) * (size_t)nb + 64));
+                flat.assign(nb, 0);
+                for (int side = 0; side < 2; side++) {
+                    hipLaunchKernelGGL(flat_probe_fit_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, aa.fit, nb,
+                                       side == 0 ? 1.0 : -1.0, probe.as<NullFitOut>());
+                    CRM_HIP(hipGetLastError());
+                    AssembleArgs ap = aa;
+                    ap.fit = probe.as<NullFitOut>();
+                    CRM_TRY(launch_assemble(st, ap, nb, ctx->ws_Gext.as<double>(), slow_ws));
+                    CRM_TRY(launch_eig_davies(st, ctx->ws_F.as<double>(), d_Q, nb, k0, d_lam, d_pv, d_if, d_liu, true, slow_ws));
+                    CRM_HIP(hipMemcpyAsync(q1.data(), d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+                    CRM_HIP(hipMemcpyAsync(p1.data(), d_pv, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+                    CRM_HIP(hipStreamSynchronize(st));
+                    for (int b = 0; b < nb; b++) {
+                        // (Q against max(Q, its expectation under the null = tr F): a score vector that nearly vanishes,
+                        // p ~ 1, leaves Q itself ill-conditioned)
+                        double trace = 0.0;
+                        for (int j = 0; j < k0; j++) trace += lam0[(size_t)b * k0 + j];
+                        const bool q_moves = std::fabs(q1[b] - q0[b]) > 5e-7 * std::max(std::fabs(q0[b]), trace);
+                        const bool p_moves = std::fabs(p1[b] - p0[b]) > 5e-6 * std::fabs(p0[b]);
+                        if (q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) flat[b] = 1;
+                    }
+                }
+            }
             int rmax = 0;
             for (int i = 0; i < nrho; i++) rmax = std::max(rmax, bg->r[i]);
             const bool saturated = (long)rmax + c + 1 >= n;
@@ -2018,6 +2070,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     int fl = saturated ? CRM_MODEL_SATURATED : 0;
                     if (!(f.delta > 1e-8)) fl |= CRM_MODEL_DELTA_AT_ZERO;
                     if (!f.use_g) fl |= CRM_MODEL_G_IN_SPAN_W;
+                    if (!flat.empty() && flat[b]) fl |= CRM_MODEL_FLAT_OPTIMUM;
                     o.flags[done + b] = fl;
                 }
                 if (o.rho1) o.rho1[done + b] = rho;

@@ -184,10 +184,18 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *                  divided by delta (mode A with at least as many contexts as cells is the extreme case);
  *   DELTA_AT_ZERO  the null fit at rho* ended at delta <= 1e-8: the likelihood was flat or still rising towards delta = 0
  *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
- *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X). */
+ *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X);
+ *   FLAT_OPTIMUM   the reference stops its null fit with Brent's search at rtol = atol = 1e-6 on logit(delta)
+ *                  (_cellregmap.py:351-352); the search's last comparison is decided by the last bits of a flat objective,
+ *                  so two faithful runs can stop one tolerance apart.  Set where that matters: the library evaluates the
+ *                  score test again with delta moved by one such tolerance either way (scale re-estimated, Q, F and the
+ *                  p-value recomputed) and raises the flag when Q moves by more than 5e-7 (relative to
+ *                  max(Q, tr F)) or p by more than 5e-6 (relative) -- half the tolerances statistics (1e-6) and p-values (1e-5) are held to.  Variants without
+ *                  the flag reproduce to those tolerances whichever way the search's last comparison falls. */
 #define CRM_MODEL_SATURATED 1
 #define CRM_MODEL_DELTA_AT_ZERO 2
 #define CRM_MODEL_G_IN_SPAN_W 4
+#define CRM_MODEL_FLAT_OPTIMUM 8
 
 /* Several phenotypes against one panel in one pass ("genes" that share the background, W and E0):
  * everything that does not depend on y -- G'Q0(rho), the Khatri-Rao contraction per (variant, rho)

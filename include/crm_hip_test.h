@@ -10,6 +10,16 @@
 extern "C" {
 #endif
 
+/* Kernel forms kept beside the default one (process-wide; reset != 0 returns the form to its default):
+ *   "gram_staged" 1       score-statistic Gram through the register-staged kernel instead of the direct-to-LDS one
+ *   "kr_no_tail" 1        the Khatri-Rao contraction of a block in one launch of 128-column tiles whatever the spectrum
+ *   "nullfit_per_wave" 1  null fits with one independent wavefront per (variant, grid point), not the LDS-shared queue
+ *   "kin_fold" 0 / 2      never fold the donor-level kinship factor into the mixing matrices / fold with few columns too
+ *   "eigh_one_stage" 1    the constructor tridiagonalises every grid point on its own (eigh_trd.hip) instead of the
+ *                         two-stage family solver (eigh2_band.hip, eigh2_chase.hip)
+ *   "nullfit_exact" 1     null-fit likelihood with IEEE division and one log per spectrum entry
+ * These replace the environment switches of earlier versions; the GPU suite flips every one of them. */
+int crm_test_set_form(const char* name, int value, int reset);
 /* Contraction kernel variant for subsequent launches on this context: tile_width 0 = chosen per
  * launch, 64 or 128 forced; lds_dma = 1 lets 128-wide launches use the direct-to-LDS kernel. */
 int crm_test_set_contraction(crm_ctx* ctx, int tile_width, int lds_dma);

@@ -93,3 +93,21 @@ def pytest_unconfigure(config):
     if _trace_fh is not None:
         _trace_fh.close()
         _trace_fh = None
+
+
+@pytest.fixture
+def kernel_form():
+    """Switch a kernel form of the library for the duration of a test (include/crm_hip_test.h: crm_test_set_form):
+    ``kernel_form("gram_staged", 1)``; every form set through the fixture returns to its default afterwards."""
+    from cellregmap_amd import _lib
+
+    lib = _lib.load()
+    touched = []
+
+    def set_form(name, value=1, reset=False):
+        _lib.check(lib.crm_test_set_form(name.encode(), int(value), 1 if reset else 0))
+        touched.append(name)
+
+    yield set_form
+    for name in touched:
+        lib.crm_test_set_form(name.encode(), 0, 1)

@@ -261,7 +261,7 @@ def test_interaction_scan_with_seventy_covariate_columns():
     (136, 1, "C", "0"),          # ... the direct contraction against H
     (150, 3, "B", None),         # mode B (hK alone)
 ])
-def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch):
+def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch, kernel_form):
     """More than 128 contexts / more than 144 rows of contexts + covariates + 2: the slower forms of the
     Khatri-Rao, Gram, finalisation and eigenvalue kernels under the whole scan, against the oracle."""
     from cellregmap_amd import CellRegMap, GenotypePanel
@@ -271,7 +271,7 @@ def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch):
 
     lib, ctx = _lib.load(), _engine._context(0)
     if route == "1":     # (read when the structure is announced; the seed below keeps this background out of the cache)
-        monkeypatch.setenv("CRM_KIN_FOLD", "0")
+        kernel_form("kin_fold", 0)
     donors, cells = (3, 400) if mode == "C" else (8, 100)      # mode C: 136 + 3 x 136 = 544 columns for 1200 cells
     co = _cohort(donors, cells, k0, 5, seed=41 + k0 + (1000 if route == "1" else 0))
     rng = np.random.default_rng(k0 + c)
@@ -485,9 +485,9 @@ def test_cached_eigen_workspace_is_reused_and_can_be_released():
 
 
 @pytest.mark.parametrize("shape", [(8, 30, 5, 40), (6, 40, 37, 24), (10, 20, 60, 12)])
-def test_gram_kernel_forms_agree(shape, monkeypatch):
+def test_gram_kernel_forms_agree(shape, kernel_form):
     """The score-statistic Gram through direct-to-LDS loads (default for k0 + c + 2 <= 64) against the register-staged
-    kernel (CRM_GRAM_STAGED=1; also what wider problems and unaligned rows use): same Q and F to rounding.  The shapes
+    kernel (crm_test_set_form("gram_staged"); also what wider problems and unaligned rows use): same Q and F to rounding.  The shapes
     cover 2 and 4 row blocks, spectra that are not multiples of the 64-column chunk, and one (k0 = 60) that only the
     staged kernel serves."""
     import cellregmap_amd as crm
@@ -498,7 +498,7 @@ def test_gram_kernel_forms_agree(shape, monkeypatch):
     obj = crm.CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
     panel = crm.GenotypePanel(c.G, groups=None)
     pv, _, st = obj.scan_interaction(panel, return_stats=True)
-    monkeypatch.setenv("CRM_GRAM_STAGED", "1")
+    kernel_form("gram_staged", 1)
     pv2, _, st2 = obj.scan_interaction(panel, return_stats=True)
     scale = np.maximum(np.abs(st2["Q"]), np.trace(st2["F"], axis1=1, axis2=2))
     assert np.all(np.abs(st["Q"] - st2["Q"]) <= 1e-11 * scale)
@@ -507,9 +507,9 @@ def test_gram_kernel_forms_agree(shape, monkeypatch):
     assert np.all(np.abs(pv - pv2) <= 1e-6 * pv2 + 1e-13)
 
 
-def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(monkeypatch):
+def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(kernel_form):
     """r = 2064 = 16 x 128 + 16: the last 144 columns of the Khatri-Rao contraction go through a launch of 160-column tiles
-    (scan.hip; CRM_KR_NO_TAIL=1 keeps the single launch over seventeen columns of 128-column tiles).  Both forms must give the
+    (scan.hip; the form "kr_no_tail" keeps the single launch over seventeen columns of 128-column tiles).  Both forms must give the
     same statistics to rounding, and the oracle's on a few variants."""
     import cellregmap_amd as crm
     from cellregmap_amd.synth import make_cohort
@@ -529,9 +529,9 @@ def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(monkeypatch):
     pv, info, st = obj.scan_interaction(panel, return_stats=True)
     used = lib.crm_test_tail_launches(ctx)
     assert used > before                                  # the form under test ran ...
-    monkeypatch.setenv("CRM_KR_NO_TAIL", "1")
+    kernel_form("kr_no_tail", 1)
     pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
-    monkeypatch.delenv("CRM_KR_NO_TAIL")
+    kernel_form("kr_no_tail", 0, reset=True)
     assert lib.crm_test_tail_launches(ctx) == used        # ... and the knob really switches it off
     assert np.array_equal(info["rho1"], info1["rho1"])
     scale = np.maximum(np.abs(st1["Q"]), np.trace(st1["F"], axis1=1, axis2=2))
@@ -543,9 +543,9 @@ def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(monkeypatch):
     assert np.all(np.abs(pv[pick] - opv) <= 1e-5 * opv + 1e-13), np.c_[pv[pick], opv]
 
 
-def test_null_fit_forms_are_bit_identical(monkeypatch):
+def test_null_fit_forms_are_bit_identical(kernel_form):
     """Null fits by LDS-sharing workgroups that draw variants from a queue (default from 1024 variants on, one covariate
-    column) against one independent wavefront per (variant, grid point) (CRM_NULLFIT_PER_WAVE=1): the arithmetic and its
+    column) against one independent wavefront per (variant, grid point) (the form "nullfit_per_wave"): the arithmetic and its
     order are the same, so every output must agree bit for bit -- including which variants land where in the queue."""
     import cellregmap_amd as crm
     from cellregmap_amd.synth import make_cohort
@@ -556,9 +556,9 @@ def test_null_fit_forms_are_bit_identical(monkeypatch):
         rng = np.random.default_rng(2)
         panel = crm.GenotypePanel(c.G + 0.05 * rng.normal(size=c.G.shape), groups=None)
         pv, info, st = obj.scan_interaction(panel, return_stats=True)
-        monkeypatch.setenv("CRM_NULLFIT_PER_WAVE", "1")
+        kernel_form("nullfit_per_wave", 1)
         pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
-        monkeypatch.delenv("CRM_NULLFIT_PER_WAVE")
+        kernel_form("nullfit_per_wave", 0, reset=True)
         assert np.array_equal(pv, pv1, equal_nan=True)
         for k in info:
             assert np.array_equal(info[k], info1[k], equal_nan=True), k
@@ -587,7 +587,7 @@ def test_wide_panel_on_a_small_cohort_against_the_oracle():
 
 
 @pytest.mark.parametrize("variants", [1024, 1025, 4096])
-def test_queue_drawn_null_fits_cover_every_variant(monkeypatch, variants):
+def test_queue_drawn_null_fits_cover_every_variant(kernel_form, variants):
     """The LDS-sharing null-fit workgroups draw (variant, grid point) work from a queue with one ticket per wavefront
     (_cellregmap.py:345-357 fits all 11 grid points of every variant).  At the first size that uses the queue, one past it
     and a full 4096-variant block: the scan must complete -- launch_nullfit poisons the trial records and
@@ -602,9 +602,9 @@ def test_queue_drawn_null_fits_cover_every_variant(monkeypatch, variants):
     panel = crm.GenotypePanel(c.G + 0.05 * rng.normal(size=c.G.shape), groups=None)
     pv, info, st = obj.scan_interaction(panel, return_stats=True)
     assert np.all(np.isfinite(st["lml"])) and np.all(np.isfinite(pv))
-    monkeypatch.setenv("CRM_NULLFIT_PER_WAVE", "1")
+    kernel_form("nullfit_per_wave", 1)
     pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
-    monkeypatch.delenv("CRM_NULLFIT_PER_WAVE")
+    kernel_form("nullfit_per_wave", 0, reset=True)
     assert np.array_equal(pv, pv1)
     for k in ("delta", "lml", "scale", "Q"):
         assert np.array_equal(st[k], st1[k]), k

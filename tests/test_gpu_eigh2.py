@@ -84,3 +84,42 @@ def test_family_solver_against_lapack(dim, k1, deficient):
         assert np.abs(lam[q] - ref).max() <= 2e-13 * scale
         assert np.abs(Z[q].T @ Z[q] - np.eye(dim)).max() <= 5e-12
         assert np.abs(A @ Z[q] - Z[q] * lam[q]).max() <= 1e-12 * scale
+
+
+def test_constructor_forms_agree_at_config2(kernel_form):
+    """BASELINE config 2's background through the two-stage family solver (the default from order 1024 on: 1 020 columns
+    + 44 of padding) and with every grid point tridiagonalised on its own (the form "eigh_one_stage"): the same ranks and
+    spectra, and scans that agree to the polished null fit's accuracy.  Also flips "nullfit_exact" on the way."""
+    from cellregmap_amd import CellRegMap, get_L_values
+    from cellregmap_amd.synth import make_config
+
+    c = make_config("cfg2", n_variants=96)
+    Ls = get_L_values(c.hK, c.E)
+    lib = _lib.load()
+    ctx = _engine._context(0)
+    _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+    try:
+        res = {}
+        for form in ("two-stage", "one-stage"):
+            _engine._bg_cache.clear()
+            kernel_form("eigh_one_stage", 1 if form == "one-stage" else 0)
+            crm = CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+            ranks = [crm._bg.rank(i) for i in range(len(crm._rho1))]
+            S0 = crm._bg.read(4, c.y.size)[1]
+            pv, info = crm.scan_interaction(c.G)
+            res[form] = (ranks, S0, pv, info["rho1"])
+            del crm
+        kernel_form("eigh_one_stage", 0, reset=True)
+        a, b = res["two-stage"], res["one-stage"]
+        assert a[0] == b[0]
+        assert np.abs(a[1] - b[1]).max() <= 1e-12 * a[1].max()
+        assert np.array_equal(a[3], b[3])
+        assert np.all(np.abs(a[2] - b[2]) <= 1e-8 * b[2])
+        # the likelihood in the reference's own operations (IEEE division, one log per entry): same answers
+        _engine._bg_cache.clear()
+        kernel_form("nullfit_exact", 1)
+        pv_exact, _ = CellRegMap(c.y, c.E, W=c.W, Ls=Ls).scan_interaction(c.G)
+        assert np.all(np.abs(pv_exact - a[2]) <= 1e-8 * a[2])
+    finally:
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+        _engine._bg_cache.clear()

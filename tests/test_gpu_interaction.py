@@ -289,14 +289,14 @@ def test_mode_b_on_the_kinship_structure_route(hook):
 
 
 @pytest.mark.parametrize("mode", ["B", "C"])
-def test_folded_route_with_an_E1_of_its_own(mode, monkeypatch):
+def test_folded_route_with_an_E1_of_its_own(mode, kernel_form):
     """E1 given and different from E (other columns, another count): the folded form's E1 rows then come from the general
     pair features E1_a o E0_i (k1 k0 columns), not from the symmetric ones the scan shares with E0'diag(g^2)E0 when E1 is E
     itself.  Against the oracle and against the direct route."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
     from oracle.crm import OracleCellRegMap, khatri_rao_halves
 
-    monkeypatch.setenv("CRM_KIN_FOLD", "2")      # (mode C folds by itself from 32 columns of us on)
+    kernel_form("kin_fold", 2)      # (mode C folds by itself from 32 columns of us on)
     rng = np.random.default_rng(17 if mode == "B" else 18)
     donors, k0, k1, p = 9, 5, 3, 40
     donor = np.repeat(np.arange(donors), rng.integers(12, 40, size=donors))
@@ -326,7 +326,7 @@ def test_folded_route_with_an_E1_of_its_own(mode, monkeypatch):
 
 
 @pytest.mark.parametrize("route", [2, 0, "folded"])
-def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
+def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch, kernel_form):
     """Several phenotypes can ask for more (variant, rho*) pairs than the pair-ordered buffers hold (min(11, genes) per
     variant in the worst case): the block keeps its size for the stages before -- the per-phenotype null fits above all --
     and the pair stage runs over sub-ranges of its variants (scan.hip: pair_cap).  With the buffers cut down to the
@@ -339,7 +339,7 @@ def test_pair_stage_over_sub_ranges_of_a_block(route, monkeypatch):
     folded = route == "folded"
     if folded:     # the kinship-structure route with the donor-level factor folded into the mixing matrices (forced: the
         route = 2  # library folds by itself from 32 columns of us on); another seed keeps this background out of the cache
-        monkeypatch.setenv("CRM_KIN_FOLD", "2")
+        kernel_form("kin_fold", 2)
     c = make_cohort(8, 30, 4, 700, seed=44 if folded else 43)
     rng = np.random.default_rng(9)
     n = c.y.size
@@ -782,7 +782,7 @@ def test_constructor_in_phases_with_exchanged_grid_points(mode):
 
 @pytest.mark.parametrize("hook,shape", [("none", "small"), ("E", "small"), ("G", "small"), ("none", "wide"),
                                         ("none", "full"), ("G", "full")])
-def test_kinship_structure_route_equals_the_direct_route(hook, shape, monkeypatch):
+def test_kinship_structure_route_equals_the_direct_route(hook, shape, monkeypatch, kernel_form):
     """Mode C through get_L_values with an "expanded" kinship factor (rows of a donor-level factor repeated for the cells
     of each donor, ragged donors, a DENSE donor-level factor): the dense scan of general genotypes forms
     Q0(rho*)'(g o E0) = Mix(rho*)' [H'(g o E0)] with H'(g o E0) built donor by donor (crm_background_set_kinship_groups)
@@ -809,7 +809,7 @@ def test_kinship_structure_route_equals_the_direct_route(hook, shape, monkeypatc
     idx = rng.permutation(n)
     hooks = {} if hook == "none" else ({"idx_E": idx} if hook == "E" else {"idx_G": idx})
     if shape == "full":   # (the library folds by itself from 32 columns of us on: few columns do better unfolded)
-        monkeypatch.setenv("CRM_KIN_FOLD", "2")
+        kernel_form("kin_fold", 2)
     crm = CellRegMap(y, E, W=W, Ls=get_L_values(hK, E))
     lib, ctx = _lib.load(), _engine._context(0)
     panel = GenotypePanel(G, groups=None)
