@@ -176,13 +176,18 @@ def _announce_kinship_groups(bg, halves):
     rc = _lib.load().crm_background_set_kinship_groups(bg.handle, _lib.ptr(group), hKd.shape[0], _lib.ptr(hKd),
                                                        hKd.shape[1], _lib.ptr(us), us.shape[1])
     if rc != 0:
-        # The announcement is an optimisation: a structure the library refuses (or scratch memory it cannot get) leaves the
-        # background as it is, scanning by the direct route (include/crm_hip.h).  Say so, do not fail the constructor.
+        # The announcement is an optimisation: a structure the library declines (CRM_ERR_UNSUPPORTED) or scratch memory it
+        # cannot get leaves the background as it is, scanning by the direct route (include/crm_hip.h) -- say so, do not
+        # fail the constructor.  Anything else (the library's own check of the announcement against its half factor,
+        # CRM_ERR_ARG; a HIP error) is a defect of the detection above or of the device state and is raised.
         import warnings
 
         msg = _lib.load().crm_last_error()
-        warnings.warn("kinship structure not used (libcrm_hip status %d: %s); scans take the direct route"
-                      % (rc, msg.decode() if msg else ""), RuntimeWarning, stacklevel=3)
+        text = msg.decode() if msg else ""
+        if rc != -3 and "out of memory" not in text.lower():
+            raise _lib.CrmError(f"libcrm_hip error {rc}: {text}")
+        warnings.warn("kinship structure not used (libcrm_hip status %d: %s); scans take the direct route" % (rc, text),
+                      RuntimeWarning, stacklevel=3)
 
 
 def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
@@ -803,7 +808,8 @@ class CellRegMap:
 
     def _streamed_panels(self, G, groups="auto"):
         """Generator over ``(first, last, panel)``: the column chunks of a host matrix, uploaded one after the other by a
-        second thread (at most two ahead of the consumer) on the library's upload stream, outside the context's lock.  The
+        second thread on the library's upload stream, outside the context's lock -- at most three chunks on the device
+        at a time: the one being scanned, one waiting, one being built.  The
         first chunk -- the only one nothing hides -- is one block of the scan when the chunk is a multiple of it; every
         chunk looks for the donor structure by itself, as one panel would.  An error of the uploading thread (the
         reference's ValueError on non-finite entries) is raised here; closing the generator stops the thread."""
@@ -813,7 +819,7 @@ class CellRegMap:
         chunk = _stream_chunk()
         first = 4096 if chunk % 4096 == 0 else (chunk // 2 if chunk % 256 == 0 else chunk)
         bounds = [(0, min(p, first))] + [(j0, min(p, j0 + chunk)) for j0 in range(first, p, chunk)]
-        ready = queue.Queue(maxsize=2)
+        ready = queue.Queue(maxsize=1)
         stop = threading.Event()
 
         def upload():
@@ -866,7 +872,10 @@ class CellRegMap:
     def _scan_streamed(self, lib, G, k0, idx_E, idx_G, return_stats, progress, groups="auto"):
         """A host matrix of many variants goes to the device in column chunks from a second thread while this one scans
         the chunks that have arrived: PCIe beside the scan, and device memory for three chunks instead of the whole
-        matrix.  The chunks are whole blocks of the scan, so the results are those of the one-panel scan."""
+        matrix.  Every chunk is scanned as a panel of its own: where the chunk bounds fall on the block bounds of the
+        one-panel scan (the default 8192-variant chunks at the BASELINE configurations: blocks of 4096) the results are
+        identical bit for bit, otherwise -- other block sizes, donor structure found in some chunks only -- they agree
+        to the rounding of a different summation order."""
         n, p = G.shape
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         progress, bar = self._one_bar(progress, p)
@@ -877,6 +886,7 @@ class CellRegMap:
             for j0, j1, panel in panels:
                 with _progress(self._device, progress, j1 - j0, offset=j0, grand_total=p):
                     parts.append(self._scan_interaction(lib, gene, panel, j1 - j0, k0, iE, iG, return_stats))
+                panel = None      # (released before the next chunk is taken from the queue)
         finally:
             panels.close()
             if bar is not None:

@@ -31,8 +31,10 @@ struct NullFitArgs {
     int nrho, c, restricted;
     int polish;        // secant refinement of the optimum on the analytic derivative
     int exact;         // spectrum pass with IEEE division and one log per entry (the reference's own operations)
-    int probe;         // test hook: evaluate the objective at probe_x only (register kernels)
+    int probe;         // evaluate the objective at one point instead of searching (register kernels): 1 at probe_x (test
+                       // hook), 2 at probe_xv[variant] (the flat-optimum flag's look at the objective around the optimum)
     double probe_x;
+    const double* probe_xv;
     long n;            // cells (unpadded)
     const double* WW;  // [c x c]
     const double* Wy;  // [c]

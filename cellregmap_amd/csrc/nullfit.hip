@@ -407,7 +407,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
     if (a.probe) {
         // test hook (crm_test_null_fit_probe): the objective at one given x instead of the search, so that the
         // likelihood itself can be compared with the oracle's at the same point
-        (void)f(a.probe_x);
+        (void)f(a.probe == 2 ? a.probe_xv[b] : a.probe_x);
         if (lane == 0) {
             NullFitTrial t;
             t.lml = cur_lml; t.delta = cur_delta; t.scale = cur_scale; t.use_g = use_g ? 1 : 0; t.nfev = nfev;

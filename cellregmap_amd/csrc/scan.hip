@@ -156,6 +156,15 @@ int crm_background_set_kinship_groups(crm_background* bg, const int* group, long
     CRM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     bg->kin = false;   // (a second announcement that fails must not leave the first one's buffers in use)
+    struct Undo {      // ... nor keep its own: whatever it allocated goes back unless it ends with bg->kin set
+        crm_background* b;
+        ~Undo() {
+            if (b->kin) return;
+            b->kin_fold = false;
+            for (DevBuf* x : {&b->kin_map, &b->kin_Y, &b->kin_hKd}) x->release();
+            for (int i = 0; i < b->nrho; i++) b->MixK[i].release();
+        }
+    } undo{bg};
     // cells in donor order, every donor's run padded to whole stages of the contraction
     std::vector<long> count(groups, 0);
     for (long i = 0; i < n; i++) count[group[i]]++;
@@ -340,6 +349,89 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     g->lde = round_up(k0, 16);
     int rc = CRM_OK;
     auto fail = [&](int code) { crm_gene_destroy(g); return code; };
+    // host-side inner products
+    std::vector<double> WW((size_t)c * c, 0.0), Wy(c, 0.0);
+    auto inner_products = [&](const double* Wm) {
+        std::fill(WW.begin(), WW.end(), 0.0);
+        std::fill(Wy.begin(), Wy.end(), 0.0);
+        for (long i = 0; i < n; i++)
+            for (int a = 0; a < c; a++) {
+                Wy[a] += Wm[i * c + a] * y[i];
+                for (int b = a; b < c; b++) WW[a * c + b] += Wm[i * c + a] * Wm[i * c + b];
+            }
+        for (int a = 0; a < c; a++)
+            for (int b = 0; b < a; b++) WW[a * c + b] = WW[b * c + a];
+    };
+    auto is_diagonal = [&]() {
+        for (int a = 0; a < c; a++)
+            for (int b = a + 1; b < c; b++)
+                if (std::fabs(WW[a * c + b]) > 1e-13 * std::sqrt(WW[a * c + a] * WW[b * c + b])) return false;
+        return true;
+    };
+    g->yy = 0.0;
+    for (long i = 0; i < n; i++) g->yy += y[i] * y[i];
+    inner_products(W);
+    // The orthogonalisation of the variants against W (blockops.hip: launch_ortho_block) and the null fits work in a basis
+    // of span(W) with mutually orthogonal columns -- U diag(s) of the thin SVD, the basis glimix-core's LMM holds its
+    // covariates in, which is what the Python host passes.  Columns that are not orthogonal are brought there here: the
+    // scans depend on W through its column space only.  W <- W V with V the eigenvectors of W'W by a cyclic Jacobi
+    // iteration, repeated on the result: a pass leaves the columns orthogonal to ~eps cond(W)^2, and on a nearly diagonal
+    // Gram matrix Jacobi resolves the small singular values to high relative accuracy, so two or three passes reach the
+    // 1e-13 the diagonal test asks for up to cond(W) ~ 1e7 -- beyond which the reference's own rank rule
+    // (numpy_sugar.economic_svd: singular values below sqrt(eps)) is what decides.
+    std::vector<double> Wo;
+    const double* Wuse = W;
+    for (int pass = 0; pass < 4 && !is_diagonal(); pass++) {
+        std::vector<double> A(WW), V((size_t)c * c, 0.0);
+        for (int a = 0; a < c; a++) V[a * c + a] = 1.0;
+        for (int sweep = 0; sweep < 60; sweep++) {
+            double offd = 0.0, diag = 0.0;
+            for (int a = 0; a < c; a++)
+                for (int b = 0; b < c; b++) (a == b ? diag : offd) += A[a * c + b] * A[a * c + b];
+            if (offd <= 1e-32 * diag) break;
+            for (int pi = 0; pi < c - 1; pi++)
+                for (int qi = pi + 1; qi < c; qi++) {
+                    const double apq = A[pi * c + qi];
+                    if (apq == 0.0) continue;
+                    const double theta = (A[qi * c + qi] - A[pi * c + pi]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                    for (int k = 0; k < c; k++) {
+                        const double akp = A[k * c + pi], akq = A[k * c + qi];
+                        A[k * c + pi] = cs * akp - sn * akq;
+                        A[k * c + qi] = sn * akp + cs * akq;
+                    }
+                    for (int k = 0; k < c; k++) {
+                        const double apk = A[pi * c + k], aqk = A[qi * c + k];
+                        A[pi * c + k] = cs * apk - sn * aqk;
+                        A[qi * c + k] = sn * apk + cs * aqk;
+                    }
+                    for (int k = 0; k < c; k++) {
+                        const double vkp = V[k * c + pi], vkq = V[k * c + qi];
+                        V[k * c + pi] = cs * vkp - sn * vkq;
+                        V[k * c + qi] = sn * vkp + cs * vkq;
+                    }
+                }
+        }
+        std::vector<double> Wn((size_t)n * c);
+        std::vector<double> row(c);
+        for (long i = 0; i < n; i++) {
+            for (int a = 0; a < c; a++) row[a] = Wuse[i * c + a];
+            for (int b = 0; b < c; b++) {
+                double acc = 0.0;
+                for (int a = 0; a < c; a++) acc += row[a] * V[a * c + b];
+                Wn[i * c + b] = acc;
+            }
+        }
+        Wo.swap(Wn);
+        Wuse = Wo.data();
+        inner_products(Wuse);
+    }
+    if (!is_diagonal()) {
+        set_error("gene: the covariates could not be brought to mutually orthogonal columns (W'W stays coupled beyond 1e-13 "
+                  "after four passes): pass an orthogonal basis of span(W), e.g. U diag(s) of its thin SVD");
+        return fail(CRM_ERR_NUMERIC);
+    }
     // [y | W] packed as one operand (column 0 = y) for the rotations, plus separate views
     const long ldyw = 128;
     if ((rc = g->yW.ensure(sizeof(double) * np * ldyw)) != CRM_OK) return fail(rc);
@@ -348,7 +440,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
         std::vector<double> pack((size_t)n * (1 + c));
         for (long i = 0; i < n; i++) {
             pack[i * (1 + c)] = y[i];
-            for (int j = 0; j < c; j++) pack[i * (1 + c) + 1 + j] = W[i * c + j];
+            for (int j = 0; j < c; j++) pack[i * (1 + c) + 1 + j] = Wuse[i * c + j];
         }
         if ((rc = upload_padded(ctx->stream, g->yW.as<double>(), ldyw, np, pack.data(), 1 + c, n, 1 + c)) != CRM_OK)
             return fail(rc);
@@ -356,95 +448,22 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     }
     g->ld_yw = ldyw;
     if ((rc = upload_padded(ctx->stream, g->E0.as<double>(), g->lde, np, E0, k0, n, k0)) != CRM_OK) return fail(rc);
-    // host-side inner products
-    g->yy = 0.0;
-    std::vector<double> WW((size_t)c * c, 0.0), Wy(c, 0.0);
-    for (long i = 0; i < n; i++) {
-        g->yy += y[i] * y[i];
-        for (int a = 0; a < c; a++) {
-            Wy[a] += W[i * c + a] * y[i];
-            for (int b = a; b < c; b++) WW[a * c + b] += W[i * c + a] * W[i * c + b];
-        }
-    }
-    for (int a = 0; a < c; a++)
-        for (int b = 0; b < a; b++) WW[a * c + b] = WW[b * c + a];
-    // What the orthogonalisation of the variants against W needs (blockops.hip: launch_ortho_block): (W'W)^-1 and the
-    // eigen-decomposition W'W = V diag(d^2) V'.  Mutually orthogonal columns -- what the Python host passes: U diag(s) of
-    // the thin SVD, the basis glimix-core's LMM works in -- need no arithmetic; anything else goes through a cyclic
-    // Jacobi iteration on the c x c Gram matrix, which resolves W's small singular values only down to ~1e-7 of the
-    // largest: beyond that, or below the reference's own rank rule (numpy_sugar.economic_svd: sqrt(eps)), the call is
-    // refused and the caller asked for a basis of span(W) -- the scans depend on W through its column space only.
+    // What the orthogonalisation of the variants against W needs: (W'W)^-1 = diag(1 / s^2), V = I, d^2 = s^2
     {
         constexpr double EPS = 2.220446049250313e-16;
         std::vector<double> proj((size_t)2 * c * c + c, 0.0);
         double* inv = proj.data();
         double* V = inv + (size_t)c * c;
         double* d2 = V + (size_t)c * c;
-        bool diagonal = true;
-        for (int a = 0; a < c && diagonal; a++)
-            for (int b = a + 1; b < c; b++)
-                if (std::fabs(WW[a * c + b]) > 1e-13 * std::sqrt(WW[a * c + a] * WW[b * c + b])) { diagonal = false; break; }
-        if (diagonal) {
-            for (int a = 0; a < c; a++) {
-                if (!(WW[a * c + a] >= EPS)) {
-                    set_error("gene: covariate column %d has norm %.3g, below the reference's rank rule (sqrt(eps)): pass a "
-                              "basis of span(W)", a, std::sqrt(std::max(WW[a * c + a], 0.0)));
-                    return fail(CRM_ERR_NUMERIC);
-                }
-                V[a * c + a] = 1.0;
-                d2[a] = WW[a * c + a];
-                inv[a * c + a] = 1.0 / WW[a * c + a];
-            }
-        } else {
-            std::vector<double> A(WW);
-            for (int a = 0; a < c; a++) V[a * c + a] = 1.0;
-            for (int sweep = 0; sweep < 60; sweep++) {
-                double offd = 0.0, diag = 0.0;
-                for (int a = 0; a < c; a++)
-                    for (int b = 0; b < c; b++) (a == b ? diag : offd) += A[a * c + b] * A[a * c + b];
-                if (offd <= 1e-32 * diag) break;
-                for (int pi = 0; pi < c - 1; pi++)
-                    for (int qi = pi + 1; qi < c; qi++) {
-                        const double apq = A[pi * c + qi];
-                        if (apq == 0.0) continue;
-                        const double theta = (A[qi * c + qi] - A[pi * c + pi]) / (2.0 * apq);
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-                        for (int k = 0; k < c; k++) {
-                            const double akp = A[k * c + pi], akq = A[k * c + qi];
-                            A[k * c + pi] = cs * akp - sn * akq;
-                            A[k * c + qi] = sn * akp + cs * akq;
-                        }
-                        for (int k = 0; k < c; k++) {
-                            const double apk = A[pi * c + k], aqk = A[qi * c + k];
-                            A[pi * c + k] = cs * apk - sn * aqk;
-                            A[qi * c + k] = sn * apk + cs * aqk;
-                        }
-                        for (int k = 0; k < c; k++) {
-                            const double vkp = V[k * c + pi], vkq = V[k * c + qi];
-                            V[k * c + pi] = cs * vkp - sn * vkq;
-                            V[k * c + qi] = sn * vkp + cs * vkq;
-                        }
-                    }
-            }
-            double lmax = 0.0, lmin = INFINITY;
-            for (int a = 0; a < c; a++) {
-                d2[a] = A[a * c + a];
-                lmax = std::max(lmax, d2[a]);
-                lmin = std::min(lmin, d2[a]);
-            }
-            if (!(lmin >= EPS) || !(lmin > 1e-13 * lmax)) {
-                set_error("gene: the covariates are rank deficient or too ill-conditioned for columns that are not mutually "
-                          "orthogonal (eigenvalues of W'W from %.3g to %.3g): pass an orthogonal basis of span(W), e.g. "
-                          "U diag(s) of its thin SVD", lmin, lmax);
+        for (int a = 0; a < c; a++) {
+            if (!(WW[a * c + a] >= EPS)) {
+                set_error("gene: the covariates are rank deficient by the reference's rule (a singular value of %.3g, below "
+                          "sqrt(eps)): pass a basis of span(W)", std::sqrt(std::max(WW[a * c + a], 0.0)));
                 return fail(CRM_ERR_NUMERIC);
             }
-            for (int a = 0; a < c; a++)
-                for (int b = 0; b < c; b++) {
-                    double acc = 0.0;
-                    for (int k = 0; k < c; k++) acc += V[a * c + k] * V[b * c + k] / d2[k];
-                    inv[a * c + b] = acc;
-                }
+            V[a * c + a] = 1.0;
+            d2[a] = WW[a * c + a];
+            inv[a * c + a] = 1.0 / WW[a * c + a];
         }
         if ((rc = g->Wproj.ensure(sizeof(double) * proj.size())) != CRM_OK) return fail(rc);
         CRM_HIP(hipMemcpyAsync(g->Wproj.ptr, proj.data(), sizeof(double) * proj.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -1550,6 +1569,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * n_main, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, n_main, nb, (int)ldq, fastT ? kdim : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
+        std::vector<NullFitArgs> fit_args;     // (kept for the flat-optimum probes of info calls)
+        std::vector<double> flat_obj;
         trace_push("crm null fits");
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
@@ -1573,6 +1594,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             fa.probe = ctx->probe_on ? 1 : 0; fa.probe_x = ctx->probe_x;
             CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));
+            if (outs[gi].flags) {
+                if (fit_args.size() < (size_t)ng) fit_args.resize(ng);
+                fit_args[gi] = fa;
+            }
         }
         trace_pop();
         if (ctx->probe_on) {   // test hook: keep the (variant, grid point) records of this block and stop here
@@ -1601,6 +1626,43 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     return CRM_ERR_NUMERIC;
                 }
             }
+        // Flat-optimum flag, first half (info calls only; include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM): how much the objective
+        // itself changes one stopping tolerance of the reference's search away from where the fit stopped, relative to its
+        // value.  Brent's last comparisons f(x +- tol) <= f(x) are decided by rounding noise -- and the stopping point by a
+        // whole tolerance -- only where that change is within the noise of the likelihood (a few 1e-14 of its value between
+        // two faithful implementations).  -1: not measured (the wider null-fit kernels).
+        for (int gi = 0; gi < ng; gi++) {
+            if (!outs[gi].flags) continue;
+            if (flat_obj.empty()) flat_obj.assign((size_t)BLK * ng, -1.0);
+            for (int b = 0; b < nb; b++) flat_obj[(size_t)gi * BLK + b] = -1.0;
+            if (c > CRM_MAX_COV) continue;
+            std::vector<double> hx(nb), drop(nb, INFINITY);
+            std::vector<NullFitTrial> h_trial((size_t)nb * nrho);
+            ScopedBuf dxv, dscratch;
+            CRM_TRY(dxv.ensure(sizeof(double) * nb));
+            CRM_TRY(dscratch.ensure(sizeof(NullFitOut) * (size_t)nb));
+            NullFitArgs fa = fit_args[gi];
+            fa.probe = 2; fa.probe_xv = dxv.as<double>(); fa.out = dscratch.as<NullFitOut>(); fa.polish = 0;
+            for (int side = 0; side < 2; side++) {
+                for (int b = 0; b < nb; b++) {
+                    const double tiny = 2.220446049250313e-16;
+                    const double d = std::min(std::max(h_fit[(size_t)gi * BLK + b].delta, tiny), 1.0 - tiny);
+                    const double x = std::log(d) - std::log1p(-d);
+                    hx[b] = x + (side == 0 ? 1.0 : -1.0) * (1e-6 * std::fabs(x) + 1e-6);
+                }
+                CRM_HIP(hipMemcpyAsync(dxv.ptr, hx.data(), sizeof(double) * nb, hipMemcpyHostToDevice, st));
+                CRM_TRY(launch_nullfit(st, fa, nb, false, nullptr));
+                CRM_HIP(hipMemcpyAsync(h_trial.data(), d_trial, sizeof(NullFitTrial) * h_trial.size(), hipMemcpyDeviceToHost, st));
+                CRM_HIP(hipStreamSynchronize(st));
+                for (int b = 0; b < nb; b++) {
+                    const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
+                    const double there = h_trial[(size_t)b * nrho + f.rho_index].lml;
+                    const double rel = (f.lml - there) / std::fabs(f.lml);      // > 0: the optimum is higher
+                    drop[b] = std::min(drop[b], rel == rel ? rel : -INFINITY);
+                }
+            }
+            for (int b = 0; b < nb; b++) flat_obj[(size_t)gi * BLK + b] = drop[b];
+        }
         // ---- the pair stage, over sub-ranges [sb0, sb0 + nsb) of the block (one sub-range unless several phenotypes ask for
         //      more (variant, rho*) pairs than the pair-ordered buffers hold).  Inside, the block-order names below stand for
         //      the sub-range: the same code serves a whole block and a part of it.
@@ -2056,7 +2118,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                         for (int j = 0; j < k0; j++) trace += lam0[(size_t)b * k0 + j];
                         const bool q_moves = std::fabs(q1[b] - q0[b]) > 5e-7 * std::max(std::fabs(q0[b]), trace);
                         const bool p_moves = std::fabs(p1[b] - p0[b]) > 5e-6 * std::fabs(p0[b]);
-                        if (q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) flat[b] = 1;
+                        // ... and it only matters where the search cannot tell the two points apart (first half, above)
+                        const double drop = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
+                        const bool undecided = !(drop > 2e-13);
+                        if ((q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) && undecided) flat[b] = 1;
                     }
                 }
             }

@@ -124,9 +124,9 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
  * (the per-object state of CellRegMap: _y, _W, _E0; _cellregmap.py:64-79).
  * W: best passed as U diag(s) of its thin SVD with the singular values below sqrt(eps) dropped (numpy_sugar.economic_svd,
  * the basis glimix-core's LMM holds its covariates in; the scans depend on W through its column space only) -- mutually
- * orthogonal columns need no arithmetic here.  Other full-rank W is accepted and served through (W'W)^-1; W that is rank
- * deficient by that rule, or too ill-conditioned for the Gram-matrix route (eigenvalues of W'W spanning more than 1e13),
- * is refused with CRM_ERR_NUMERIC.  The scans then orthogonalise every block of variants against W in the cell axis and
+ * orthogonal columns need no arithmetic here.  Other W is brought to that form inside the call (W <- W V, V from repeated
+ * Jacobi passes on W'W; exact to the working precision up to cond(W) ~ 1e7, where the reference's rank rule takes over);
+ * only W that is rank deficient by that rule is refused with CRM_ERR_NUMERIC.  The scans then orthogonalise every block of variants against W in the cell axis and
  * apply the reference's rank rules to [W, g] (economic_svd in the null fits, lstsq in the projection of the score test).
  * c <= 128, k0 <= 256, and in the interaction scan k0 + c + 2 <= 288 (past 128 contexts or 144 rows: slower kernel forms). */
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
@@ -186,12 +186,15 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
  *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X);
  *   FLAT_OPTIMUM   the reference stops its null fit with Brent's search at rtol = atol = 1e-6 on logit(delta)
- *                  (_cellregmap.py:351-352); the search's last comparison is decided by the last bits of a flat objective,
- *                  so two faithful runs can stop one tolerance apart.  Set where that matters: the library evaluates the
- *                  score test again with delta moved by one such tolerance either way (scale re-estimated, Q, F and the
- *                  p-value recomputed) and raises the flag when Q moves by more than 5e-7 (relative to
- *                  max(Q, tr F)) or p by more than 5e-6 (relative) -- half the tolerances statistics (1e-6) and p-values (1e-5) are held to.  Variants without
- *                  the flag reproduce to those tolerances whichever way the search's last comparison falls. */
+ *                  (_cellregmap.py:351-352).  Where the likelihood changes by less than 2e-13 of its value over one such
+ *                  tolerance, the search's last comparisons are decided by rounding noise and two faithful runs can stop
+ *                  a whole tolerance apart.  The flag is raised where that happens AND matters: the library evaluates the
+ *                  likelihood one tolerance to either side of where its fit stopped, and the score test there as well
+ *                  (scale re-estimated, Q, F and the p-value recomputed); flagged are the variants whose likelihood is
+ *                  flat in that sense and whose Q moves by more than 5e-7 (relative to max(Q, tr F)) or whose p moves by
+ *                  more than 5e-6 (relative) -- half the tolerances statistics (1e-6) and p-values (1e-5) are held to.
+ *                  Variants without the flag reproduce to those tolerances; with more than 8 covariate columns the
+ *                  likelihood is not probed and the second condition alone decides. */
 #define CRM_MODEL_SATURATED 1
 #define CRM_MODEL_DELTA_AT_ZERO 2
 #define CRM_MODEL_G_IN_SPAN_W 4

@@ -201,9 +201,9 @@ def test_many_covariates_in_the_interaction_scan():
 
 def test_covariates_as_given_through_the_c_abi(monkeypatch):
     """The Python host hands W to the library as U diag(s) of its thin SVD (mutually orthogonal columns).  A C caller may
-    pass W as it is: crm_gene_create then works through (W'W)^-1 and the eigen-decomposition of W'W (cyclic Jacobi on the
-    c x c Gram matrix) for the projection of the variants and the reference's rank rule.  Same span, same statistics --
-    with the optimum pinned, to 1e-9; a rank-deficient W passed raw is refused with the remedy in the message."""
+    pass W as it is: crm_gene_create then brings it to orthogonal columns itself (W V, V from repeated Jacobi passes on the
+    c x c Gram matrix).  Same span, same statistics -- with the optimum pinned, to 1e-9, also for columns that are
+    correlated to one part in 1e7; a rank-deficient W passed raw is refused with the remedy in the message."""
     from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib
 
     c = _cohort(9, 25, 4, 30, seed=40)
@@ -228,9 +228,22 @@ def test_covariates_as_given_through_the_c_abi(monkeypatch):
     assert_allclose(st2["lml"] - st["lml"], (st2["lml"] - st["lml"])[0], atol=1e-8)   # (log|X'X| differs by the basis: a constant)
     assert_allclose(st2["Q"], st["Q"], rtol=1e-9)
     assert np.all(np.abs(pv2 - pv) <= 2e-6 * pv + P_ATOL)
+    # nearly collinear columns (cond(W) ~ 1e7): accepted raw since 0.5.0, the same answers as through the host's SVD basis
+    Will = np.concatenate([W, W[:, [1]] + 1e-7 * rng.normal(size=(c.y.size, 1))], axis=1)
+    assert np.linalg.cond(Will) > 1e6
+    _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+    try:
+        monkeypatch.undo()
+        pv3, info3, st3 = CellRegMap(c.y, c.E, W=Will, hK=c.hK).scan_interaction(panel, return_stats=True)
+        monkeypatch.setattr(CellRegMap, "_fixed_effect_basis", lambda self: self._W)
+        pv4, info4, st4 = CellRegMap(c.y, c.E, W=Will, hK=c.hK).scan_interaction(panel, return_stats=True)
+    finally:
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+    assert np.array_equal(info3["rho1"], info4["rho1"])
+    assert_allclose(st4["Q"], st3["Q"], rtol=1e-7)
+    assert np.all(np.abs(pv4 - pv3) <= 2e-6 * pv3 + P_ATOL)
     Wdef = np.concatenate([W, W[:, [1]] - W[:, [2]]], axis=1)                           # rank 4, five columns, passed raw
-    monkeypatch.setattr(CellRegMap, "_fixed_effect_basis", lambda self: self._W)
-    with pytest.raises(_lib.CrmError, match="orthogonal basis of span"):
+    with pytest.raises(_lib.CrmError, match="basis of span"):
         CellRegMap(c.y, c.E, W=Wdef, hK=c.hK).scan_interaction(panel)
 
 
@@ -426,7 +439,7 @@ def test_davies_info_is_surfaced():
     pv, _ = crm.scan_interaction(c.G)
     pv2, info = crm.scan_interaction_info(c.G)
     assert np.array_equal(pv, pv2)
-    assert set(info) == {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"} and info["ifault"].dtype == np.int32
+    assert set(info) == {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate", "flat_optimum"} and info["ifault"].dtype == np.int32
     assert not info["degenerate"].any() and not info["model_flags"].any()      # a well-posed problem
     _, _, ost = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G, return_stats=True)
     for j in range(20):
