@@ -1629,8 +1629,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         // Flat-optimum flag, first half (info calls only; include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM): how much the objective
         // itself changes one stopping tolerance of the reference's search away from where the fit stopped, relative to its
         // value.  Brent's last comparisons f(x +- tol) <= f(x) are decided by rounding noise -- and the stopping point by a
-        // whole tolerance -- only where that change is within the noise of the likelihood (a few 1e-14 of its value between
-        // two faithful implementations).  -1: not measured (the wider null-fit kernels).
+        // whole tolerance -- only where that change is within the noise of the likelihood (up to 5e-14 of its value between
+        // two faithful implementations; tools/diag/flat_flag_study.py: the scans that do land beyond
+        // the tolerances have a change of at most 4.4e-14).  -1: not measured (the wider null-fit kernels).
         for (int gi = 0; gi < ng; gi++) {
             if (!outs[gi].flags) continue;
             if (flat_obj.empty()) flat_obj.assign((size_t)BLK * ng, -1.0);
@@ -2092,7 +2093,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // flat-optimum probes (info calls only): the score test again with delta one stopping tolerance of the
             // reference's search to either side; how far Q and p move says whether the search's last comparison matters
             std::vector<char> flat;
+            std::vector<double> probe_rec;
             if (o.flags) {
+                probe_rec.assign((size_t)nb * 3, 0.0);
                 std::vector<double> q0(nb), p0(nb), q1(nb), p1(nb), lam0((size_t)nb * k0);
                 CRM_HIP(hipMemcpyAsync(lam0.data(), d_lam, sizeof(double) * (size_t)nb * k0, hipMemcpyDeviceToHost, st));
                 CRM_HIP(hipMemcpyAsync(q0.data(), d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
@@ -2120,10 +2123,18 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                         const bool p_moves = std::fabs(p1[b] - p0[b]) > 5e-6 * std::fabs(p0[b]);
                         // ... and it only matters where the search cannot tell the two points apart (first half, above)
                         const double drop = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
-                        const bool undecided = !(drop > 2e-13);
+                        const bool undecided = !(drop > 1e-13);
+                        probe_rec[(size_t)b * 3] = drop;
+                        probe_rec[(size_t)b * 3 + 1] = std::max(probe_rec[(size_t)b * 3 + 1],
+                                                                std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace));
+                        probe_rec[(size_t)b * 3 + 2] = std::max(probe_rec[(size_t)b * 3 + 2], std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]));
                         if ((q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) && undecided) flat[b] = 1;
                     }
                 }
+            }
+            if (o.flags && ng == 1) {   // (diagnostics: what the probes measured, crm_test_null_fit_probe_read)
+                if (done == 0) ctx->probe_out.clear();
+                ctx->probe_out.insert(ctx->probe_out.end(), probe_rec.begin(), probe_rec.end());
             }
             int rmax = 0;
             for (int i = 0; i < nrho; i++) rmax = std::max(rmax, bg->r[i]);
