@@ -87,6 +87,7 @@ struct crm_gene {
     crm_ctx* ctx = nullptr;  // (kept separately: destruction must not depend on the background's lifetime)
     int c = 0, k0 = 0;
     long ld_yw = 0, ldw = 0, lde = 0;
+    std::vector<double> W_host;   // the covariates as used (orthogonal columns), n x c: crm_gene_create_like sums W'y from it
     crm::DevBuf yW;   // [n_pad x ld_yw]: column 0 = y, columns 1..c = W
     crm::DevBuf E0;   // [n_pad x lde]
     crm::DevBuf WW, Wy;

@@ -310,6 +310,69 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
 }
 
 // ---- gene -----------------------------------------------------------------------------------
+extern "C++" {
+// rotations t = Q0(rho)' [y, W] of a gene for every grid point: rows of a [(1+c) x ldq] matrix per grid point
+static int gene_rotations(crm_gene* g) {
+    crm_background* bg = g->bg;
+    crm_ctx* ctx = g->ctx;
+    const int c = g->c;
+    const long np = bg->n_pad, ldyw = g->ld_yw;
+    int rc = CRM_OK;
+    auto fail = [&](int code) { return code; };
+    const int nrho = bg->nrho;
+    const long ldq = bg->ldq;
+    const long slab = (long)(1 + c) * ldq;
+    if (bg->fast_T && ctx->fast_gene_rot) {
+        // Q0(rho) = H Mix(rho):  t = Mix(rho)' (H'[y, W]) -- no Q0 needed
+        ScopedBuf thw;
+        const long ldh = bg->ldh;
+        if ((rc = thw.ensure(sizeof(double) * ldh * 128)) != CRM_OK) return fail(rc);
+        if ((rc = g->rot.ensure(sizeof(double) * slab * nrho)) != CRM_OK) return fail(rc);
+        if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4))) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemsetAsync(thw.ptr, 0, sizeof(double) * ldh * 128, ctx->stream));
+        CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho, ctx->stream));
+        std::vector<GemmProblem> pr(nrho + 1);
+        GemmProblem p0{};
+        p0.X = bg->H.as<double>(); p0.ldx = ldh; p0.Y = g->yW.as<double>(); p0.ldy = ldyw;
+        p0.C = thw.as<double>(); p0.ldc = 128; p0.M = (int)bg->cols; p0.N = 1 + c;
+        pr[0] = p0;
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = thw.as<double>(); p.ldx = 128; p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+            p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
+            p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            pr[1 + i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, pr.data(), sizeof(GemmProblem) * (nrho + 1), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, (int)bg->cols, 1 + c, np, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>() + 1, nrho, 1 + c, (int)ldq, ldh, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        CRM_HIP(hipStreamSynchronize(ctx->stream));
+        return CRM_OK;
+    }
+    if ((rc = crm_background_require_q0(bg, -1)) != CRM_OK) return fail(rc);
+    const int ks = pick_split(np, (ldq / GEMM_BN) * nrho);
+    if ((rc = g->rot.ensure(sizeof(double) * slab * nrho * ks)) != CRM_OK) return fail(rc);
+    std::vector<GemmProblem> probs(nrho);
+    for (int i = 0; i < nrho; i++) {
+        GemmProblem p{};
+        p.X = g->yW.as<double>(); p.ldx = ldyw;
+        p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
+        p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
+        p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+        probs[i] = p;
+    }
+    if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * CRM_MAX_RHO)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, ctx->stream));
+    // splits write slabs nrho*slab apart
+    CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho * ks, ctx->stream));
+    if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), nrho, 1 + c, (int)ldq, np, false, 0, ks, slab * nrho)) != CRM_OK) return fail(rc);
+    if ((rc = launch_reduce_splits(ctx->stream, g->rot.as<double>(), slab * nrho, ks, slab * nrho)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    return CRM_OK;
+}
+
+}  // extern "C++"
+
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out) {
     return crm::guarded_on("crm_gene_create", bg ? bg->ctx : nullptr, [&]() -> int {
@@ -474,57 +537,62 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     CRM_HIP(hipMemcpyAsync(g->WW.ptr, WW.data(), sizeof(double) * c * c, hipMemcpyHostToDevice, ctx->stream));
     CRM_HIP(hipMemcpyAsync(g->Wy.ptr, Wy.data(), sizeof(double) * c, hipMemcpyHostToDevice, ctx->stream));
     CRM_HIP(hipStreamSynchronize(ctx->stream));
-    // rotations t = Q0(rho)' [y, W] for every grid point: rows of a [(1+c) x ldq] matrix
-    const int nrho = bg->nrho;
-    const long ldq = bg->ldq;
-    const long slab = (long)(1 + c) * ldq;
-    if (bg->fast_T && ctx->fast_gene_rot) {
-        // Q0(rho) = H Mix(rho):  t = Mix(rho)' (H'[y, W]) -- no Q0 needed
-        ScopedBuf thw;
-        const long ldh = bg->ldh;
-        if ((rc = thw.ensure(sizeof(double) * ldh * 128)) != CRM_OK) return fail(rc);
-        if ((rc = g->rot.ensure(sizeof(double) * slab * nrho)) != CRM_OK) return fail(rc);
-        if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4))) != CRM_OK) return fail(rc);
-        CRM_HIP(hipMemsetAsync(thw.ptr, 0, sizeof(double) * ldh * 128, ctx->stream));
-        CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho, ctx->stream));
-        std::vector<GemmProblem> pr(nrho + 1);
-        GemmProblem p0{};
-        p0.X = bg->H.as<double>(); p0.ldx = ldh; p0.Y = g->yW.as<double>(); p0.ldy = ldyw;
-        p0.C = thw.as<double>(); p0.ldc = 128; p0.M = (int)bg->cols; p0.N = 1 + c;
-        pr[0] = p0;
-        for (int i = 0; i < nrho; i++) {
-            GemmProblem p{};
-            p.X = thw.as<double>(); p.ldx = 128; p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
-            p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
-            p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-            pr[1 + i] = p;
+    g->W_host.assign(Wuse, Wuse + (size_t)n * c);
+    if ((rc = gene_rotations(g)) != CRM_OK) return fail(rc);
+    *out = g;
+    return CRM_OK;
+    });
+}
+
+// Another phenotype on the cohort of `like`: same background, covariates and contexts -- only y differs.  What a gene
+// keeps of W and E0 (device copies, W'W, the projection onto span(W), the content keys that let a multi-phenotype pass check
+// that its genes agree) is copied on the device instead of being checked, hashed, orthogonalised and uploaded again: binding
+// a phenotype costs its own upload and rotations only (per-gene run_interaction calls of the reference, _cellregmap.py:547-587,
+// over many genes of one cohort).  The results are bit for bit those of crm_gene_create with the same W and E0.
+int crm_gene_create_like(const crm_gene* like, const double* y, crm_gene** out) {
+    return crm::guarded_on("crm_gene_create_like", like ? like->ctx : nullptr, [&]() -> int {
+    if (!like || !y || !out) return CRM_ERR_ARG;
+    *out = nullptr;
+    crm_background* bg = like->bg;
+    crm_ctx* ctx = like->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    const long n = bg->n;
+    const int c = like->c;
+    if (like->W_host.size() != (size_t)n * c) {
+        set_error("gene: the template gene holds no covariates");
+        return CRM_ERR_ARG;
+    }
+    for (long i = 0; i < n; i++)
+        if (!std::isfinite(y[i])) {
+            set_error("gene: non-finite values in the outcome or the covariates");
+            return CRM_ERR_NUMERIC;
         }
-        CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, pr.data(), sizeof(GemmProblem) * (nrho + 1), hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, (int)bg->cols, 1 + c, np, false, 0, 1, 0)) != CRM_OK) return fail(rc);
-        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>() + 1, nrho, 1 + c, (int)ldq, ldh, false, 0, 1, 0)) != CRM_OK) return fail(rc);
-        CRM_HIP(hipStreamSynchronize(ctx->stream));
-        *out = g;
-        return CRM_OK;
+    crm_gene* g = new crm_gene();
+    g->bg = bg; g->ctx = ctx; g->c = c; g->k0 = like->k0;
+    g->e0_key = like->e0_key; g->w_key = like->w_key;
+    g->ldw = like->ldw; g->lde = like->lde; g->ld_yw = like->ld_yw;
+    g->W_host = like->W_host;
+    int rc = CRM_OK;
+    auto fail = [&](int code) { crm_gene_destroy(g); return code; };
+    hipStream_t st = ctx->stream;
+    const DevBuf* src[] = {&like->yW, &like->E0, &like->WW, &like->Wproj};
+    DevBuf* dst[] = {&g->yW, &g->E0, &g->WW, &g->Wproj};
+    for (int q = 0; q < 4; q++) {
+        if ((rc = dst[q]->ensure(src[q]->bytes)) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemcpyAsync(dst[q]->ptr, src[q]->ptr, src[q]->bytes, hipMemcpyDeviceToDevice, st));
     }
-    if ((rc = crm_background_require_q0(bg, -1)) != CRM_OK) return fail(rc);
-    const int ks = pick_split(np, (ldq / GEMM_BN) * nrho);
-    if ((rc = g->rot.ensure(sizeof(double) * slab * nrho * ks)) != CRM_OK) return fail(rc);
-    std::vector<GemmProblem> probs(nrho);
-    for (int i = 0; i < nrho; i++) {
-        GemmProblem p{};
-        p.X = g->yW.as<double>(); p.ldx = ldyw;
-        p.Y = bg->Q0[i].as<double>(); p.ldy = ldq;
-        p.C = g->rot.as<double>() + (long)i * slab; p.ldc = ldq;
-        p.M = 1 + c; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
-        probs[i] = p;
-    }
-    if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * CRM_MAX_RHO)) != CRM_OK) return fail(rc);
-    CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, probs.data(), sizeof(GemmProblem) * nrho, hipMemcpyHostToDevice, ctx->stream));
-    // splits write slabs nrho*slab apart
-    CRM_HIP(hipMemsetAsync(g->rot.ptr, 0, sizeof(double) * slab * nrho * ks, ctx->stream));
-    if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), nrho, 1 + c, (int)ldq, np, false, 0, ks, slab * nrho)) != CRM_OK) return fail(rc);
-    if ((rc = launch_reduce_splits(ctx->stream, g->rot.as<double>(), slab * nrho, ks, slab * nrho)) != CRM_OK) return fail(rc);
-    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    // column 0 of [y | W]
+    CRM_HIP(hipMemcpy2DAsync(g->yW.ptr, sizeof(double) * g->ld_yw, y, sizeof(double), sizeof(double), n, hipMemcpyHostToDevice, st));
+    g->yy = 0.0;
+    std::vector<double> Wy(c, 0.0);
+    const double* Wm = g->W_host.data();
+    for (long i = 0; i < n; i++) g->yy += y[i] * y[i];
+    for (long i = 0; i < n; i++)
+        for (int a = 0; a < c; a++) Wy[a] += Wm[i * c + a] * y[i];
+    if ((rc = g->Wy.ensure(sizeof(double) * c)) != CRM_OK) return fail(rc);
+    CRM_HIP(hipMemcpyAsync(g->Wy.ptr, Wy.data(), sizeof(double) * c, hipMemcpyHostToDevice, st));
+    CRM_HIP(hipStreamSynchronize(st));
+    if ((rc = gene_rotations(g)) != CRM_OK) return fail(rc);
     *out = g;
     return CRM_OK;
     });
@@ -812,15 +880,23 @@ int crm_set_donor_collapse(crm_ctx* ctx, int on) {
 
 namespace crm {
 
-__global__ void donor_sums_kernel(const int* __restrict__ group, long cells, int m, const double* __restrict__ yW,
-                                  long ldw, int c, double* __restrict__ sums) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;  // 0 count, 1 y, 2.. W
-    if (d >= m) return;
+// sums[d][q] over the cells of donor d: q = 0 count, 1 y, 2.. the covariate columns.  One workgroup per (donor, q):
+// its threads stride over the cells and meet in a fixed order (the same bits whatever the launch).
+__global__ __launch_bounds__(256) void donor_sums_kernel(const int* __restrict__ group, long cells, int m,
+                                                         const double* __restrict__ yW, long ldw, int c,
+                                                         double* __restrict__ sums) {
+    __shared__ double part[256];
+    const int d = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
     double acc = 0.0;
-    for (long i = 0; i < cells; i++)
+    for (long i = tid; i < cells; i += 256)
         if (group[i] == d) acc += q == 0 ? 1.0 : yW[i * ldw + (q - 1)];
-    sums[d * DT_SUMS_LD + q] = acc;
+    part[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) part[tid] += part[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) sums[d * DT_SUMS_LD + q] = part[0];
 }
 
 __global__ void permute_group_kernel(const int* __restrict__ group, const int* __restrict__ idx, long n,
@@ -937,7 +1013,7 @@ static int build_donor_tables(crm_gene* gene, const crm_panel* panel, crm_donor_
     }
     CRM_TRY(gene->dt_sums.ensure(sizeof(double) * mp * DT_SUMS_LD));
     CRM_HIP(hipMemsetAsync(gene->dt_sums.ptr, 0, sizeof(double) * mp * DT_SUMS_LD, st));
-    hipLaunchKernelGGL(donor_sums_kernel, dim3((unsigned)((m + 63) / 64), c + 2), dim3(64), 0, st,
+    hipLaunchKernelGGL(donor_sums_kernel, dim3((unsigned)m, c + 2), dim3(256), 0, st,
                        panel->group.as<int>(), n, (int)m, gene->yW.as<double>(), gene->ld_yw, c,
                        gene->dt_sums.as<double>());
     CRM_HIP(hipGetLastError());

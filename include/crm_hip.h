@@ -131,6 +131,11 @@ int crm_background_read(const crm_background* bg, int i, double* Q0, double* S0)
  * c <= 128, k0 <= 256, and in the interaction scan k0 + c + 2 <= 288 (past 128 contexts or 144 rows: slower kernel forms). */
 int crm_gene_create(crm_background* bg, const double* y, const double* W, int c, const double* E0,
                     int k0, crm_gene** out);
+/* Another phenotype y on the cohort of `like` (same background, covariates and contexts): what a gene keeps of W and E0 is
+ * copied on the device instead of being checked, hashed and uploaded again -- the per-gene calls of the reference's
+ * run_interaction over many genes of one cohort (_cellregmap.py:547-587) then cost one upload of y and its rotations each.
+ * Results are bit for bit those of crm_gene_create(bg, y, W, c, E0, k0). */
+int crm_gene_create_like(const crm_gene* like, const double* y, crm_gene** out);
 void crm_gene_destroy(crm_gene* gene);
 
 /* ---- genotype panel resident in HBM: G is n x p, row-major, leading dimension ldg ------ */

@@ -1,11 +1,11 @@
-"""Turn the CSVs of tools/pmc_bench.sh into profiles/r04_pmc_summary.json.
+"""Turn the CSVs of tools/pmc_bench.sh into profiles/r05_pmc_summary.json.
 
 A block of 4096 variants is one large Khatri-Rao launch (gemm_tn_glds_sync_kernel) plus, when the spectrum is a little
 longer than a multiple of the 128-column tile, a second launch of 160-column tiles for the last columns; the counters of
 both are added per block.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 bytes; FETCH_SIZE is doubled for
 16-byte-per-lane streams (the gfx950 correction of MI355X_MICROARCH.md's HBM section).
 
-    python tools/pmc_summary.py gpurun_out/pmc_r04 [gpurun_out/pmc_r04_sync0] > profiles/r04_pmc_summary.json"""
+    python tools/pmc_summary.py gpurun_out/pmc_r05 > profiles/r05_pmc_summary.json"""
 import csv
 import json
 import os
@@ -57,7 +57,7 @@ def variant(d):
 def main():
     dirs = sys.argv[1:]
     kin = os.environ.get("CRM_KIN_ROUTE", "1") != "0"
-    names = ["default", "one workgroup per tile (CRM_CONTRACTION_SYNC=0)"]
+    names = ["default", "second directory"]
     variants = {names[i]: variant(d) for i, d in enumerate(dirs)}
     first = variants[names[0]]
     if kin:
@@ -81,7 +81,7 @@ def main():
         note = ("Q0 set read once 0.82 GB x (share of the rho* groups) + genotype block 0.66 GB + A~ written 8.4 GB "
                 "(SURVEY 8d per-unit figure x 4096)")
     # the kernel form of the profiled build: from the plain bench.py run that tools/pmc_bench.sh makes beside the passes
-    form = {"contraction_sync": True, "tail_launch": True, "library": "0.4.0", "kinship_route": kin, "tile_band": 8}
+    form = {"contraction_sync": True, "tail_launch": True, "library": "0.5.0", "kinship_route": kin, "tile_band": 8}
     try:
         line = open(os.path.join(dirs[0], "bench_plain.json")).read().strip().splitlines()[-1]
         form = json.loads(line)["roofline"]["kernel_form"]
