@@ -1077,6 +1077,31 @@ class CellRegMap:
         return E0 @ ((rho1 * v0) * gE.T @ v)
 
 
+def _bind_genes_like(first, others, batch=64):
+    """Bind the phenotypes of ``others`` (same cohort as ``first``, which is bound) through ``crm_gene_create_batch``."""
+    lib = _lib.load()
+    for a in range(0, len(others), batch):
+        part = others[a:a + batch]
+        for c in part:
+            if not np.all(np.isfinite(c._y)):
+                raise ValueError("There are non-finite values in the outcome.")
+        Y = np.ascontiguousarray(np.stack([c._y for c in part], axis=1), dtype=np.float64)
+        handles = (ctypes.c_void_p * len(part))()
+        _lib.check(lib.crm_gene_create_batch(first._gene, _lib.ptr(Y), Y.shape[1], len(part), handles))
+        n, rmax = first.n_samples, max(first._bg.rank(i) for i in range(len(first._rho1)))
+        for c, h in zip(part, handles):
+            c._gene = ctypes.c_void_p(h)
+            c._ncov = first._ncov
+            c._gene_fin = weakref.finalize(c, _release_gene, lib, c._gene, c._bg)
+        if rmax + first._ncov + 1 >= n:
+            import warnings
+
+            warnings.warn(f"saturated model: the background covariance has rank {rmax} and with the {first._ncov} covariate "
+                          f"column(s) and the variant it spans all {n} cells; the reference's likelihood then divides "
+                          "rounding noise by delta and its results (and these) are not reproducible to the usual "
+                          "tolerances (scan_interaction_info flags such variants)", RuntimeWarning, stacklevel=3)
+
+
 def _cis_runs(cis_index, ngenes, p, dense_limit=1 << 26):
     """Split the variant axis of a panel into maximal runs over which the set of phenotypes that test the
     variant does not change.  ``cis_index[i]``: the variants of phenotype i -- a ``(start, stop)`` pair, a
@@ -1179,8 +1204,11 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None, progr
             raise ValueError("all CellRegMap objects of one pass must hold the same contexts E")
     panel = first._panel(G)
     n, p = panel.shape
-    # (the phenotypes share W and E -- checked above: the first one's copies on the device serve the others)
-    genes = [first._bind_gene()] + [c._bind_gene(like=first) for c in crms[1:]]
+    # (the phenotypes share W and E -- checked above: the first one's copies on the device serve the others, and their
+    # rotations are taken in batches)
+    first._bind_gene()
+    _bind_genes_like(first, [c for c in crms[1:] if c._gene is None and c._bg is first._bg])
+    genes = [c._bind_gene(like=first) for c in crms]
     ng = len(genes)
 
     iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)

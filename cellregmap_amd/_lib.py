@@ -46,6 +46,7 @@ SIGNATURES = {
     "crm_background_read": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),
     "crm_gene_create": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(vp)]),
     "crm_gene_create_like": (ctypes.c_int, [vp, vp, ctypes.POINTER(vp)]),
+    "crm_gene_create_batch": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_int, ctypes.POINTER(vp)]),
     "crm_gene_destroy": (None, [vp]),
     "crm_panel_create": (ctypes.c_int, [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_long,
                                         ctypes.POINTER(vp)]),

@@ -598,6 +598,112 @@ int crm_gene_create_like(const crm_gene* like, const double* y, crm_gene** out) 
     });
 }
 
+extern "C++" {
+__global__ void scatter_column_kernel(const double* __restrict__ src, long lds, int col, double* __restrict__ dst, long ldd, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i * ldd] = src[i * lds + col];
+}
+}  // extern "C++"
+
+// ngenes phenotypes (the columns of Y: n x ngenes, row-major, leading dimension ldy) on the cohort of `like`, bound in one
+// call: what crm_gene_create_like does per phenotype, with the rotations Q0(rho)'y of all of them as ONE product against the
+// half factor and one against every mixing matrix -- those operands (0.8 GB + 11 x 0.2 GB at BASELINE config 3) are read once
+// per batch instead of once per phenotype.  out: ngenes handles; on failure none is left behind.
+int crm_gene_create_batch(const crm_gene* like, const double* Y, long ldy, int ngenes, crm_gene** out) {
+    return crm::guarded_on("crm_gene_create_batch", like ? like->ctx : nullptr, [&]() -> int {
+    if (!like || !Y || !out || ngenes < 1 || ldy < ngenes) return CRM_ERR_ARG;
+    for (int j = 0; j < ngenes; j++) out[j] = nullptr;
+    crm_background* bg = like->bg;
+    crm_ctx* ctx = like->ctx;
+    CRM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long n = bg->n, np = bg->n_pad, ldq = bg->ldq;
+    const int c = like->c, nrho = bg->nrho;
+    if (like->W_host.size() != (size_t)n * c) {
+        set_error("gene: the template gene holds no covariates");
+        return CRM_ERR_ARG;
+    }
+    for (long i = 0; i < n; i++)
+        for (int j = 0; j < ngenes; j++)
+            if (!std::isfinite(Y[i * ldy + j])) {
+                set_error("gene: non-finite values in the outcome or the covariates");
+                return CRM_ERR_NUMERIC;
+            }
+    std::vector<crm_gene*> made;
+    auto fail = [&](int code) {
+        for (crm_gene* g : made) crm_gene_destroy(g);
+        for (int j = 0; j < ngenes; j++) out[j] = nullptr;
+        return code;
+    };
+    int rc = CRM_OK;
+    const long ldY = round_up(ngenes, 128);
+    ScopedBuf dY;
+    if ((rc = dY.ensure(sizeof(double) * np * ldY)) != CRM_OK) return rc;
+    if ((rc = upload_padded(st, dY.as<double>(), ldY, np, Y, ldy, n, ngenes)) != CRM_OK) return rc;
+    const double* Wm = like->W_host.data();
+    for (int j = 0; j < ngenes; j++) {
+        crm_gene* g = new crm_gene();
+        made.push_back(g);
+        g->bg = bg; g->ctx = ctx; g->c = c; g->k0 = like->k0;
+        g->e0_key = like->e0_key; g->w_key = like->w_key;
+        g->ldw = like->ldw; g->lde = like->lde; g->ld_yw = like->ld_yw;
+        g->W_host = like->W_host;
+        const DevBuf* src[] = {&like->yW, &like->E0, &like->WW, &like->Wproj, &like->rot};
+        DevBuf* dst[] = {&g->yW, &g->E0, &g->WW, &g->Wproj, &g->rot};
+        for (int q = 0; q < 5; q++) {
+            if ((rc = dst[q]->ensure(src[q]->bytes)) != CRM_OK) return fail(rc);
+            CRM_HIP(hipMemcpyAsync(dst[q]->ptr, src[q]->ptr, src[q]->bytes, hipMemcpyDeviceToDevice, st));
+        }
+        hipLaunchKernelGGL(scatter_column_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY.as<double>(), ldY, j,
+                           g->yW.as<double>(), g->ld_yw, n);
+        g->yy = 0.0;
+        std::vector<double> Wy(c, 0.0);
+        for (long i = 0; i < n; i++) g->yy += Y[i * ldy + j] * Y[i * ldy + j];
+        for (long i = 0; i < n; i++)
+            for (int a = 0; a < c; a++) Wy[a] += Wm[i * c + a] * Y[i * ldy + j];
+        if ((rc = g->Wy.ensure(sizeof(double) * c)) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemcpyAsync(g->Wy.ptr, Wy.data(), sizeof(double) * c, hipMemcpyHostToDevice, st));
+        CRM_HIP(hipStreamSynchronize(st));     // (Wy lives on this stack frame)
+    }
+    CRM_HIP(hipGetLastError());
+    const long slab = (long)(1 + c) * ldq;
+    if (bg->fast_T && ctx->fast_gene_rot) {
+        // t_y = Mix(rho)' (H'y) for all phenotypes at once; the rows Q0(rho)'W came over with the copy of `like`'s rotations
+        const long ldh = bg->ldh;
+        ScopedBuf thw, rt;
+        if ((rc = thw.ensure(sizeof(double) * ldh * ldY)) != CRM_OK) return fail(rc);
+        if ((rc = rt.ensure(sizeof(double) * (size_t)nrho * ngenes * ldq)) != CRM_OK) return fail(rc);
+        if ((rc = ctx->ws_probs.ensure(sizeof(GemmProblem) * (CRM_MAX_RHO + 4))) != CRM_OK) return fail(rc);
+        CRM_HIP(hipMemsetAsync(thw.ptr, 0, sizeof(double) * ldh * ldY, st));
+        CRM_HIP(hipMemsetAsync(rt.ptr, 0, sizeof(double) * (size_t)nrho * ngenes * ldq, st));
+        std::vector<GemmProblem> pr(nrho + 1);
+        GemmProblem p0{};
+        p0.X = bg->H.as<double>(); p0.ldx = ldh; p0.Y = dY.as<double>(); p0.ldy = ldY;
+        p0.C = thw.as<double>(); p0.ldc = ldY; p0.M = (int)bg->cols; p0.N = ngenes;
+        pr[0] = p0;
+        for (int i = 0; i < nrho; i++) {
+            GemmProblem p{};
+            p.X = thw.as<double>(); p.ldx = ldY; p.Y = bg->Mix[i].as<double>(); p.ldy = ldq;
+            p.C = rt.as<double>() + (size_t)i * ngenes * ldq; p.ldc = ldq;
+            p.M = ngenes; p.N = bg->r[i] > 0 ? bg->r[i] : 1;
+            pr[1 + i] = p;
+        }
+        CRM_HIP(hipMemcpyAsync(ctx->ws_probs.ptr, pr.data(), sizeof(GemmProblem) * (nrho + 1), hipMemcpyHostToDevice, st));
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>(), 1, (int)bg->cols, ngenes, np, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        if ((rc = launch_gemm_tn(ctx, ctx->ws_probs.as<GemmProblem>() + 1, nrho, ngenes, (int)ldq, ldh, false, 0, 1, 0)) != CRM_OK) return fail(rc);
+        for (int j = 0; j < ngenes; j++)     // row 0 of every grid point's [(1 + c) x ldq] block
+            CRM_HIP(hipMemcpy2DAsync(made[j]->rot.ptr, sizeof(double) * slab, rt.as<double>() + (size_t)j * ldq,
+                                     sizeof(double) * (size_t)ngenes * ldq, sizeof(double) * ldq, nrho, hipMemcpyDeviceToDevice, st));
+        CRM_HIP(hipStreamSynchronize(st));
+    } else {
+        for (crm_gene* g : made)
+            if ((rc = gene_rotations(g)) != CRM_OK) return fail(rc);
+    }
+    for (int j = 0; j < ngenes; j++) out[j] = made[j];
+    return CRM_OK;
+    });
+}
+
 void crm_gene_destroy(crm_gene* g) {
     try {
     if (!g) return;

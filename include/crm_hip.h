@@ -136,6 +136,10 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
  * run_interaction over many genes of one cohort (_cellregmap.py:547-587) then cost one upload of y and its rotations each.
  * Results are bit for bit those of crm_gene_create(bg, y, W, c, E0, k0). */
 int crm_gene_create_like(const crm_gene* like, const double* y, crm_gene** out);
+/* ... and `ngenes` of them in one call: Y is n x ngenes (row-major, leading dimension ldy, column j = phenotype j), out
+ * receives ngenes handles (none on failure).  The rotations Q0(rho)'y of the whole batch are one product against the
+ * background's half factor and one against every mixing matrix, so those operands are read once per batch. */
+int crm_gene_create_batch(const crm_gene* like, const double* Y, long ldy, int ngenes, crm_gene** out);
 void crm_gene_destroy(crm_gene* gene);
 
 /* ---- genotype panel resident in HBM: G is n x p, row-major, leading dimension ldg ------ */

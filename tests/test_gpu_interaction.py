@@ -235,6 +235,38 @@ def test_many_phenotypes_in_one_pass_equal_separate_scans(genotypes):
     assert_allclose(pv2, scan_interaction_many(crms, GenotypePanel(c.G))[0], rtol=1e-12)
 
 
+def test_phenotypes_bound_in_a_batch_are_those_bound_one_by_one():
+    """crm_gene_create_batch / crm_gene_create_like (the covariates and contexts of the first phenotype copied on the
+    device, the rotations of a batch as one product) against crm_gene_create per phenotype: the same bits, with several
+    covariate columns and correlated ones (orthogonalised inside the library on the first bind only)."""
+    from cellregmap_amd import CellRegMap, GenotypePanel, get_L_values, scan_interaction_many
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(8, 25, 4, 40, seed=43)
+    rng = np.random.default_rng(9)
+    n = c.y.size
+    W = np.concatenate([c.W, rng.normal(size=(n, 2)) + 0.3], axis=1)
+    Y = np.stack([c.y, c.y[rng.permutation(n)], rng.normal(size=n), c.y + rng.normal(size=n), c.y ** 2], axis=1)
+    Ls = get_L_values(c.hK, c.E)
+    first = CellRegMap(Y[:, 0], c.E, W=W, Ls=Ls)
+    batch = [first] + [CellRegMap(Y[:, i], c.E, W=W, Ls=Ls, background=first._bg) for i in range(1, 5)]
+    alone = [CellRegMap(Y[:, i], c.E, W=W, Ls=Ls, background=first._bg) for i in range(5)]
+    panel = GenotypePanel(c.G, groups=None)
+    pv, info = scan_interaction_many(batch, panel)                  # binds 1 .. 4 in one batch
+    assert all(b._gene is not None for b in batch)
+    one = CellRegMap(Y[:, 3], c.E, W=W, Ls=Ls, background=first._bg)
+    one._bind_gene(like=first)                                      # ... and one through crm_gene_create_like
+    for i, a in enumerate(alone):
+        spv, sinfo = a.scan_interaction(panel)                      # crm_gene_create
+        assert np.array_equal(pv[i], spv)
+        for k in sinfo:
+            assert np.array_equal(info[k][i], sinfo[k])
+    assert np.array_equal(one.scan_interaction(panel)[0], pv[3])
+    with pytest.raises(ValueError, match="non-finite"):
+        bad = CellRegMap(np.where(np.arange(n) == 3, np.nan, c.y), c.E, W=W, Ls=Ls, background=first._bg)
+        scan_interaction_many([first, bad], panel)
+
+
 @pytest.mark.parametrize("hook", ["none", "E", "G"])
 def test_mode_b_on_the_kinship_structure_route(hook):
     """Mode B (hS = [sqrt(rho) E1, sqrt(1 - rho) hK]) with a donor-expanded hK is the same structure with a single column

@@ -31,6 +31,10 @@ t = time.time()
 panel = crm.GenotypePanel(G)
 print(f"panel of {p} variants resident in {time.time() - t:.2f} s (donor-level: {panel.n_groups is not None})", flush=True)
 crm.scan_interaction_many(crms[:2], panel, cis_index=[(0, 64), (32, 96)])          # warm-up
+t = time.time()
+from cellregmap_amd import _engine
+_engine._bind_genes_like(crms[0], crms[2:])
+print(f"{genes - 2} phenotypes bound in one batch from the first one's device copies in {time.time() - t:.3f} s", flush=True)
 
 t = time.time()
 pv, info = crm.scan_interaction_many(crms, panel, cis_index=cis)
