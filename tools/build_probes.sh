@@ -6,4 +6,3 @@ cd "$(dirname "$0")/.."
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip -Lcellregmap_amd -lcrm_hip \
       -Wl,-rpath,'$ORIGIN/../cellregmap_amd' -o tools/gemm_bench
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_clock.hip -o tools/mfma_clock
-hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/symv_stream_probe.hip -o tools/symv_stream_probe
