@@ -417,12 +417,13 @@ def main():
                                 overlap=upload_full_panel if G_full is not None else None, info=exchange)
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, background=bg, **bg_kw)
     else:
-        # one GPU: the panel goes to the device from a second thread while this one runs the constructor (the library copies
-        # on a stream of its own, outside the context's lock: PCIe beside the eleven decompositions)
+        # one GPU: constructor, then the upload (beside each other they cost the same in total -- the constructor's many short
+        # launches slow down while 8 GB cross PCIe -- and the constructor's own figure would not be one; the streamed leg
+        # below hides the upload behind the SCAN instead).  CRM_BENCH_PARALLEL_UPLOAD=1 restores the second thread.
         import threading
 
         up = None
-        if G_full is not None and not os.environ.get("CRM_BENCH_SERIAL_UPLOAD"):
+        if G_full is not None and os.environ.get("CRM_BENCH_PARALLEL_UPLOAD"):
             up = threading.Thread(target=upload_full_panel)
             up.start()
         crm = CellRegMap(cohort.y, cohort.E, W=cohort.W, device=local_rank, **bg_kw)
@@ -432,6 +433,8 @@ def main():
     crm._bind_gene()
     _lib.check(lib.crm_ctx_synchronize(ctx))
     t_ctor = time.perf_counter() - t_start     # (N > 1: includes the panel upload that ran beside the exchange)
+    if world == 1 and G_full is not None and "panel" not in uploaded:
+        upload_full_panel()                    # (inside the end-to-end figure, after the constructor's own)
     ranks = [crm._bg.rank(i) for i in range(len(crm._rho1))]
     gene = crm._gene
     cols = cohort.E.shape[1] + (Ls.us.shape[1] * Ls.hK.shape[1] if args.mode == "C" else cohort.hK.shape[1])
@@ -483,8 +486,8 @@ def main():
                       "gather": gather_note or ("ok" if world > 1 else None),
                       "upload": "beside the constructor (second thread, own stream)" if uploaded.get("overlapped") else
                                 ("beside the exchange of the background" if world > 1 else "after the constructor"),
-                      "note": "the fixed panel of the config sharded over the ranks; end to end = constructor with the "
-                              "panel upload (host float64) beside it + scan + gather, max over ranks"}
+                      "note": "the fixed panel of the config sharded over the ranks; end to end = constructor + panel upload "
+                              "(host float64; N > 1: beside the exchange of the background) + scan + gather, max over ranks"}
         if world == 1 and not os.environ.get("CRM_BENCH_NO_STREAMED"):
             # The Python host's own way with a host matrix: constructor first, then the panel in column chunks from a
             # second thread while the chunks that have arrived are scanned (CellRegMap._scan_streamed) -- the upload
