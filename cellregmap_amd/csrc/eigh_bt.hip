@@ -63,6 +63,43 @@ __global__ __launch_bounds__(BT_NB) void bt_larft_kernel(const double* __restric
     }
 }
 
+// T of two consecutive blocks a, b of BT_NB reflectors as one block of 2 BT_NB:
+//     (I - V_a T_a V_a')(I - V_b T_b V_b') = I - [V_a V_b] [[T_a, -T_a S_ab T_b], [0, T_b]] [V_a V_b]',  S_ab = V_a'V_b,
+// written transposed with leading dimension 2 BT_NB (Ttw[m][l] = T[l][m]).  G: the pair's 2 BT_NB x 2 BT_NB Gram matrix,
+// Tta / Ttb: the halves' transposed T, M1: BT_NB x BT_NB scratch.  One workgroup per pair.
+__global__ __launch_bounds__(256) void bt_merge_kernel(const double* __restrict__ G_all, const double* __restrict__ Tt_all,
+                                                       int nblocks, int npairs, double* __restrict__ M1_all,
+                                                       double* __restrict__ Ttw_all) {
+    constexpr int NB = BT_NB, W2 = 2 * BT_NB;
+    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double* G = G_all + ((size_t)b * npairs + q) * W2 * W2;
+    const double* Tta = Tt_all + ((size_t)b * nblocks + 2 * q) * NB * NB;
+    const double* Ttb = Tta + (size_t)NB * NB;
+    double* M1 = M1_all + ((size_t)b * npairs + q) * NB * NB;
+    double* Ttw = Ttw_all + ((size_t)b * npairs + q) * W2 * W2;
+    // M1 = S_ab T_b  (T_b upper triangular: T_b[k][j] = Ttb[j][k], k <= j)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e - i * NB;
+        double acc = 0.0;
+        for (int k = 0; k <= j; k++) acc += G[(size_t)i * W2 + NB + k] * Ttb[(size_t)j * NB + k];
+        M1[e] = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = tid; e < W2 * W2; e += 256) {
+        const int m = e / W2, l = e - m * W2;       // Ttw[m][l] = T[l][m]
+        double v = 0.0;
+        if (l < NB && m < NB) v = Tta[(size_t)m * NB + l];
+        else if (l >= NB && m >= NB) v = Ttb[(size_t)(m - NB) * NB + (l - NB)];
+        else if (l < NB && m >= NB) {               // X[l][m - NB] = -sum_k T_a[l][k] M1[k][m - NB],  T_a[l][k] = Tta[k][l], k >= l
+            double acc = 0.0;
+            for (int k = l; k < NB; k++) acc += Tta[(size_t)k * NB + l] * M1[(size_t)k * NB + (m - NB)];
+            v = -acc;
+        }
+        Ttw[e] = v;
+    }
+}
+
 }  // namespace
 
 int launch_transpose(hipStream_t st, const double* src, long ld_src, long rows, long cols, double* dst, long ld_dst) {
@@ -119,14 +156,23 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     CRM_TRY(transpose_batch(st, B, Qt, Z, slab, ld, dim, dim));
     CRM_TRY(transpose_batch(st, VB, Vt, Vc, slab, ld, dim, dim));
     const int nblocks = (int)((dim - 1 + BT_NB - 1) / BT_NB);
-    // scratch: S and Tt per (matrix, block), W1 / W2 per matrix, problem records
+    // Blocks of 2 BT_NB reflectors where the matrices are large: the update Z -= V (T (V'Z)) is a product over the
+    // block's reflectors only, i.e. bound by the traffic of Z -- twice the reflectors per pass, half the passes.  The last
+    // block of an odd count stays BT_NB wide.
+    const int npairs = dim >= 2048 ? nblocks / 2 : 0;
+    constexpr int WB = 2 * BT_NB;
+    // scratch: S and Tt per (matrix, block), pair Gram matrices, merge scratch and wide T, W1 / W2 per matrix, problem records
     const size_t tt = (size_t)B * nblocks * BT_NB * BT_NB;
-    const size_t wsz = (size_t)BT_NB * ld + 256;
-    const size_t need = sizeof(double) * (2 * tt + 2 * (size_t)B * wsz) + sizeof(GemmProblem) * (size_t)B * (nblocks + 3);
+    const size_t tw = (size_t)B * std::max(npairs, 1) * WB * WB, tm = (size_t)B * std::max(npairs, 1) * BT_NB * BT_NB;
+    const size_t wsz = (size_t)WB * ld + 256;
+    const size_t need = sizeof(double) * (2 * tt + 2 * tw + tm + 2 * (size_t)B * wsz) + sizeof(GemmProblem) * (size_t)B * (nblocks + 3);
     CRM_TRY(w.small.ensure(need));
     double* S = w.small.as<double>();
     double* Tt = S + tt;
-    double* W1 = Tt + tt;
+    double* Gw = Tt + tt;
+    double* Ttw = Gw + tw;
+    double* M1 = Ttw + tw;
+    double* W1 = M1 + tm;
     double* W2 = W1 + (size_t)B * wsz;
     GemmProblem* d_probs = reinterpret_cast<GemmProblem*>(W2 + (size_t)B * wsz);
     std::vector<GemmProblem> probs((size_t)VB * nblocks);
@@ -141,7 +187,7 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
             g.M = BT_NB; g.N = BT_NB;
             probs[(size_t)b * nblocks + p] = g;
         }
-    CRM_HIP(hipMemsetAsync(S, 0, sizeof(double) * 2 * tt, st));
+    CRM_HIP(hipMemsetAsync(S, 0, sizeof(double) * (2 * tt + 2 * tw + tm), st));
     CRM_HIP(hipMemcpyAsync(d_probs, probs.data(), sizeof(GemmProblem) * probs.size(), hipMemcpyHostToDevice, st));
     CRM_TRY(launch_gemm_tn(ctx, d_probs, (int)probs.size(), BT_NB, BT_NB, dimp, false, 0, 1, 0));
     CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -150,26 +196,43 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
                        w.tau.as<double>(), ld, nblocks, dim, Tt);
     CRM_HIP(hipGetLastError());
     CRM_HIP(hipStreamSynchronize(st));
-    // blocks from the last to the first
+    if (npairs > 0) {
+        // pair Gram matrices [V_a V_b]'[V_a V_b] (their off-diagonal block is what the merge needs), then the wide T
+        std::vector<GemmProblem> pg((size_t)VB * npairs);
+        for (int b = 0; b < VB; b++)
+            for (int q = 0; q < npairs; q++) {
+                GemmProblem g{};
+                g.X = Vc + (size_t)b * slab + (long)q * WB; g.ldx = ld;
+                g.Y = g.X; g.ldy = ld;
+                g.C = Gw + ((size_t)b * npairs + q) * WB * WB; g.ldc = WB;
+                g.M = WB; g.N = WB;
+                pg[(size_t)b * npairs + q] = g;
+            }
+        CRM_HIP(hipMemcpyAsync(d_probs, pg.data(), sizeof(GemmProblem) * pg.size(), hipMemcpyHostToDevice, st));
+        CRM_TRY(launch_gemm_tn(ctx, d_probs, (int)pg.size(), WB, WB, dimp, false, 0, 1, 0));
+        hipLaunchKernelGGL(bt_merge_kernel, dim3(npairs, VB), dim3(256), 0, st, Gw, Tt, nblocks, npairs, M1, Ttw);
+        CRM_HIP(hipGetLastError());
+        CRM_HIP(hipStreamSynchronize(st));
+    }
+    // blocks from the last to the first: (a trailing narrow block,) then the pairs
     GemmProblem* d_p3 = d_probs + (size_t)B * nblocks;
     std::vector<GemmProblem> p3(3 * (size_t)B);
-    for (int p = nblocks - 1; p >= 0; p--) {
-        const long j0 = (long)p * BT_NB;
+    auto apply = [&](long j0, int width, const double* Tblk, size_t t_stride) -> int {
         const long r0 = j0 / 16 * 16;              // the block's vectors vanish above row j0 + 1
         for (int b = 0; b < B; b++) {
             GemmProblem g{};
-            // W1 (BT_NB x dim) = V_p' Z   over the rows r0 .. dimp
+            // W1 (width x dim) = V_p' Z   over the rows r0 .. dimp
             g.X = Vc + (size_t)vb(b) * slab + (size_t)r0 * ld + j0; g.ldx = ld;
             g.Y = Z + (size_t)b * slab + (size_t)r0 * ld; g.ldy = ld;
             g.C = W1 + (size_t)b * wsz; g.ldc = ld;
-            g.M = BT_NB; g.N = (int)dim;
+            g.M = width; g.N = (int)dim;
             p3[b] = g;
             // W2 = T W1  ==  Tt' W1
             GemmProblem h{};
-            h.X = Tt + ((size_t)vb(b) * nblocks + p) * BT_NB * BT_NB; h.ldx = BT_NB;
+            h.X = Tblk + (size_t)vb(b) * t_stride; h.ldx = width;
             h.Y = W1 + (size_t)b * wsz; h.ldy = ld;
             h.C = W2 + (size_t)b * wsz; h.ldc = ld;
-            h.M = BT_NB; h.N = (int)dim;
+            h.M = width; h.N = (int)dim;
             p3[B + b] = h;
             // Z[r0:, :] -= V_p W2  ==  (Vt rows j0 .., columns r0 ..)' W2
             GemmProblem u{};
@@ -181,11 +244,16 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
             p3[2 * B + b] = u;
         }
         CRM_HIP(hipMemcpyAsync(d_p3, p3.data(), sizeof(GemmProblem) * p3.size(), hipMemcpyHostToDevice, st));
-        CRM_TRY(launch_gemm_tn(ctx, d_p3, B, BT_NB, (int)dim, dimp - r0, false, 0, 1, 0));
-        CRM_TRY(launch_gemm_tn(ctx, d_p3 + B, B, BT_NB, (int)dim, BT_NB, false, 0, 1, 0));
-        CRM_TRY(launch_gemm_tn(ctx, d_p3 + 2 * B, B, (int)(dim - r0), (int)dim, BT_NB, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3, B, width, (int)dim, dimp - r0, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3 + B, B, width, (int)dim, width, false, 0, 1, 0));
+        CRM_TRY(launch_gemm_tn(ctx, d_p3 + 2 * B, B, (int)(dim - r0), (int)dim, width, false, 0, 1, 0));
         CRM_HIP(hipStreamSynchronize(st));   // p3 is rewritten for the next block
-    }
+        return CRM_OK;
+    };
+    for (int p = nblocks - 1; p >= 2 * npairs; p--)
+        CRM_TRY(apply((long)p * BT_NB, BT_NB, Tt + (size_t)p * BT_NB * BT_NB, (size_t)nblocks * BT_NB * BT_NB));
+    for (int q = npairs - 1; q >= 0; q--)
+        CRM_TRY(apply((long)q * WB, WB, Ttw + (size_t)q * WB * WB, (size_t)npairs * WB * WB));
     // rows = eigenvectors again
     CRM_HIP(hipMemsetAsync(other, 0, sizeof(double) * (size_t)B * slab, st));
     CRM_TRY(transpose_batch(st, B, Z, other, slab, ld, dim, dim));

@@ -70,8 +70,9 @@ def test_chase_matches_the_prototype(dim, k1):
         assert np.abs(eigvalsh_tridiagonal(d[q], e[q, : dim - 1]) - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("dim,k1,deficient", [(200, 10, 0), (333, 64, 5), (1100, 50, 20), (1600, 20, 0)])
+@pytest.mark.parametrize("dim,k1,deficient", [(200, 10, 0), (333, 64, 5), (1100, 50, 20), (1600, 20, 0), (2400, 50, 7)])
 def test_family_solver_against_lapack(dim, k1, deficient):
+    """(2 400: the back-transformation through stage 1 in blocks of 256 reflectors, with a trailing block of 128.)"""
     C = _family(dim, k1, seed=dim + 2, deficient=deficient)
     rho = [0.0, 0.1, 0.5, 0.9]
     wa, wb = np.sqrt(rho), np.sqrt(1 - np.asarray(rho))
