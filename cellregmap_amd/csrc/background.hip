@@ -137,6 +137,48 @@ int contract(crm_ctx* ctx, const double* X, long ldx, const double* Y, long ldy,
     return CRM_OK;
 }
 
+// C[j, i] = C[i, j] for i < j (one workgroup per 32 x 32 tile above the diagonal)
+__global__ void mirror_upper_kernel(double* __restrict__ C, long ldc, int n) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bi > bj) return;
+    const int i0 = bi * 32, j0 = bj * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < n && j < n) ? C[(long)i * ldc + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + threadIdx.x;     // element (j, i) of the lower triangle
+        if (j < n && i < n && j > i) C[(long)j * ldc + i] = tile[threadIdx.x][r];
+    }
+}
+
+// C = X'X (n x n) for X: cells x n -- only the tiles on or above the diagonal are computed (one problem per column
+// panel of 128, as many row tiles as reach the diagonal), the rest is their mirror image: half the flops of the product.
+int gram_upper_then_mirror(crm_ctx* ctx, const double* X, long ldx, double* C, long ldc, int n, long cells) {
+    const int panels = (n + 127) / 128;
+    if (panels <= 2) return contract(ctx, X, ldx, X, ldx, C, ldc, n, n, cells);
+    std::vector<GemmProblem> pr(panels);
+    for (int j = 0; j < panels; j++) {
+        GemmProblem p{};
+        p.X = X; p.ldx = ldx;
+        p.Y = X + (long)j * 128; p.ldy = ldx;
+        p.C = C + (long)j * 128; p.ldc = ldc;
+        p.M = std::min(n, (j + 1) * 128); p.N = std::min(128, n - j * 128);
+        pr[j] = p;
+    }
+    ScopedBuf d;
+    CRM_TRY(d.ensure(sizeof(GemmProblem) * pr.size()));
+    CRM_HIP(hipMemcpyAsync(d.ptr, pr.data(), sizeof(GemmProblem) * pr.size(), hipMemcpyHostToDevice, ctx->stream));
+    CRM_TRY(launch_gemm_tn(ctx, d.as<GemmProblem>(), panels, n, 128, cells, false, 0, 1, 0));
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(mirror_upper_kernel, grid, dim3(32, 8), 0, ctx->stream, C, ldc, n);
+    CRM_HIP(hipGetLastError());
+    CRM_HIP(hipStreamSynchronize(ctx->stream));
+    return CRM_OK;
+}
+
 int transpose(hipStream_t st, const double* src, long ld_src, long rows, long cols, double* dst, long ld_dst) {
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, src, ld_src, rows, cols, dst, ld_dst);
@@ -289,7 +331,7 @@ static int background_begin(crm_ctx* ctx, long n, const double* E1, int k1, cons
         // Gram matrix of the unscaled half factor, once
         CRM_BG(dC.ensure(sizeof(double) * cp * cp));
         CRM_BG_HIP(hipMemsetAsync(dC.ptr, 0, sizeof(double) * cp * cp, st));   // (its padding is an operand later)
-        CRM_BG(contract(ctx, dH.as<double>(), cp, dH.as<double>(), cp, dC.as<double>(), cp, (int)cols, (int)cols, np));
+        CRM_BG(gram_upper_then_mirror(ctx, dH.as<double>(), cp, dC.as<double>(), cp, (int)cols, np));
     } else {
         // E1 E1' and B B' (n x n), contraction over the column axis = rows of Ht; row blocks are
         // copied into zero-padded scratch so that their counts are multiples of the stage depth
