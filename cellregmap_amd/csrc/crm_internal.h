@@ -17,7 +17,7 @@ constexpr int CRM_MAX_COV_WIDE = 62;  // columns of W of the interaction scan (b
 constexpr int CRM_MAX_COV_XWIDE = 128; // columns of W of the association scans and LMM fits (beyond 62: nullfit_xwide.hip)
 constexpr int CRM_MAX_K0 = 256;   // contexts (columns of E0); past 128 through slower forms of four kernels
 constexpr int CRM_MAX_GRAM_ROWS = 288;   // contexts + covariate columns + 2 in the interaction scan (Gram kernel's LDS image)
-constexpr int DT_SUMS_LD = 64;         // columns of the per-donor sums table (1 + 1 + c)
+constexpr int DT_SUMS_LD = 136;        // columns of the per-donor sums table (1 + 1 + c, c <= CRM_MAX_COV_XWIDE = 128)
 constexpr int BLOCK_SLACK_MAX = 4096;  // groups of a donor-constant panel
 
 struct DevBuf {

@@ -247,9 +247,12 @@ def test_covariates_as_given_through_the_c_abi(monkeypatch):
         CellRegMap(c.y, c.E, W=Wdef, hK=c.hK).scan_interaction(panel)
 
 
-def test_interaction_scan_with_seventy_covariate_columns():
+@pytest.mark.parametrize("genotypes", ["dense", "donor-level"])
+def test_interaction_scan_with_seventy_covariate_columns(genotypes):
     """63 .. 128 fixed-effect columns (as long as contexts + covariates + 2 <= 144): the slower null-fit kernel
-    (nullfit_xwide.hip) under the interaction scan, against the oracle."""
+    (nullfit_xwide.hip) under the interaction scan, against the oracle -- on the dense path and on the donor-collapsed
+    one, whose per-donor sums table holds a column per covariate (it was 64 columns wide until round 5: rows ran into
+    each other from 63 covariates on)."""
     from cellregmap_amd import CellRegMap, GenotypePanel
     from oracle.crm import OracleCellRegMap
 
@@ -258,7 +261,9 @@ def test_interaction_scan_with_seventy_covariate_columns():
     W = np.concatenate([c.W, rng.normal(size=(c.y.size, 69))], axis=1)   # 70 columns
     crm = CellRegMap(c.y, c.E, W=W, hK=c.hK)
     opv, oinfo, ost = OracleCellRegMap(c.y, c.E, W=W, hK=c.hK).scan_interaction(c.G, return_stats=True)
-    pv, info, st = crm.scan_interaction(GenotypePanel(c.G, groups=None), return_stats=True)
+    panel = GenotypePanel(c.G, groups=None if genotypes == "dense" else "auto")
+    assert (panel.n_groups is not None) == (genotypes != "dense")
+    pv, info, st = crm.scan_interaction(panel, return_stats=True)
     assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
     assert_allclose(st["Q"], ost["Q"], rtol=2e-5)          # (verbatim procedure: the oracle-vs-oracle envelope)
     assert np.all(np.abs(pv - opv) <= 5e-5 * opv + P_ATOL), np.c_[pv, opv]
