@@ -195,7 +195,7 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
  *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X);
  *   FLAT_OPTIMUM   the reference stops its null fit with Brent's search at rtol = atol = 1e-6 on logit(delta)
- *                  (_cellregmap.py:351-352).  Where the likelihood changes by less than 1e-13 of its value over one such
+ *                  (_cellregmap.py:351-352).  Where the likelihood changes by less than 3e-13 of its value over one such
  *                  tolerance, the search's last comparisons are decided by rounding noise and two faithful runs can stop
  *                  a whole tolerance apart.  The flag is raised where that happens AND matters: the library evaluates the
  *                  likelihood one tolerance to either side of where its fit stopped, and the score test there as well
