@@ -30,7 +30,7 @@ struct EighWork {
     DevBuf QA, QB;   // eigenvector rows of the tridiagonal (ping-pong over the D&C levels)
     DevBuf d, e, tau, lam;   // [batch][ld]
     DevBuf small;    // panels, partial sums, problem records, D&C descriptors
-    // two-stage solver of a family D(rho) C D(rho) (eigh2_band.hip, eigh2_chase.hip)
+    // two-stage solver of a family D(rho) C D(rho) (eigh2_band.hip, eigh2_chase.hip, eigh2_back.hip)
     bool v_shared = false;   // the reflectors of the back-transformation (Vt, tau: slab 0) serve every matrix of the batch
     DevBuf AB;       // [batch][dimp + 128][128]  lower band storage, column c at offsets row - c (room for the chase's fill)
     DevBuf Vbc;      // [batch][positions][dimp][64]  reflectors of the chase, chain position major
@@ -51,7 +51,9 @@ int eigh_batched(crm_ctx* ctx, EighWork& w, double* lam_host, double** Zt);
 // phases (also reachable one by one through the test hooks)
 int eigh_tridiagonalise(crm_ctx* ctx, EighWork& w);                       // A -> d, e, tau, Vt
 int eigh_dc(crm_ctx* ctx, EighWork& w, double* lam_host, double** Qt);    // d, e -> lam (ascending), rows
-int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt);
+// (z_ready: the eigenvectors already stand as COLUMNS in w.A -- eigh_rows_to_columns -- and Qt only names the free slabs)
+int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt, bool z_ready = false);
+int eigh_rows_to_columns(crm_ctx* ctx, EighWork& w, const double* Qt);    // w.A <- Qt' per matrix (zero padded)
 
 // Two-stage solver for the constructor's family of grid points (eigh2_band.hip / eigh2_chase.hip):
 //   A_q = D_q C D_q,  D_q = diag(wa[q] on the first E2_W coordinates, wb[q] on the rest),  q < w.batch,
@@ -67,7 +69,7 @@ bool eigh2_serves(long dim, int batch);
 int eigh2_to_band(crm_ctx* ctx, EighWork& w);                                   // slab 0 of A -> band (lower), Vt / tau slab 0
 int eigh2_scale_band(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb);   // -> AB of every matrix
 int eigh2_chase(crm_ctx* ctx, EighWork& w);                                     // AB -> d, e, Vbc, taubc
-int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Qt);                    // rows of Qt <- Q2' applied (in place)
+int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Z);                     // columns of Z <- Q2 Z (in place; eigh2_back.hip)
 
 int launch_transpose(hipStream_t st, const double* src, long ld_src, long rows, long cols, double* dst, long ld_dst);
 

@@ -1,7 +1,7 @@
 // Stage 2 of the two-stage eigen-solver of the background constructor: band -> tridiagonal by bulge chasing, per grid
-// point, and the back-transformation of the tridiagonal eigenvectors through the chase's reflectors.
-// (Stage 1, the family argument and the reference lines this replaces: eigh2_band.hip.  numpy statement of both:
-// tools/eigh2_prototype.py -- chase(), back2().)
+// point, and the driver of the whole family solve.  (Stage 1, the family argument and the reference lines this replaces:
+// eigh2_band.hip; the back-transformation through the chase's reflectors: eigh2_back.hip.  numpy statement:
+// tools/eigh2_prototype.py -- chase().)
 //
 // Chase (column-wise elimination; lower band storage AB[c][row - c], half-width w = 64, fill up to 2w - 1):
 //   sweep s annihilates column s below its sub-diagonal with a reflector on rows s+1 .. s+w, then walks down the band:
@@ -14,11 +14,6 @@
 //   loaded sc1, the flag an sc1 store of one lane, a workgroup barrier between the poll and the loads; one workgroup per
 //   CU).  All workgroups of a launch must be co-resident; a wait that runs out (a shared device) raises an abort flag and
 //   the caller falls back to the one-stage solver.
-// Back-transformation: Q2 = prod_s prod_k H(s, k).  H(s + 1, k) overlaps only H(s, k) and H(s, k + 1), so the product can
-//   be regrouped into blocks of 64 consecutive sweeps at one chain position -- compact-WY blocks I - V T V' over windows
-//   of 127 rows -- applied to the eigenvector rows sweep blocks last to first, chain positions ascending
-//   (tools/eigh2_prototype.py: back2).  One workgroup keeps 48 eigenvectors' window in LDS and runs three small products
-//   per block on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64), skipping the parallelogram's zero k-steps.
 #include <chrono>
 
 #include "eigh.h"
@@ -282,241 +277,6 @@ __global__ void e2_diag_kernel(const double* __restrict__ AB, long ab_slab, long
     e[(size_t)b * ld + c] = c + 1 < n ? AB[(size_t)b * ab_slab + c * 128 + 1] : 0.0;
 }
 
-// T of the group (sweep block S, chain position k): reflector j is v(S 64 + j, k) placed at rows j .. j + 63 of the
-// group's window of 127 rows.  S = V'V over the window (V kept in window coordinates in LDS: lanes run along a row), then
-// the dlarft recurrence.
-__global__ __launch_bounds__(256) void e2_group_larft_kernel(const double* __restrict__ V, long v_slab, const double* __restrict__ tau,
-                                                             long tau_slab, long dimp, long n, int npos, double* __restrict__ Tout,
-                                                             long t_slab) {
-    extern __shared__ double lsm[];
-    constexpr int LW = W + 1;
-    double* Vw = lsm;                  // [128][LW]  Vw[c][j] = v_j[c - j]
-    double* Ss = Vw + 128 * LW;        // [64][LW]
-    double* Ts = Ss + W * LW;          // [64][LW]
-    double* taus = Ts + W * LW;        // [64]
-    const int k = blockIdx.x, S = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    if ((long)S * W + 1 + (long)k * W >= n) return;      // no reflector of this group exists
-    const double* Vg = V + (size_t)b * v_slab + ((size_t)k * dimp + (size_t)S * W) * W;
-    for (int e = tid; e < 128 * LW; e += 256) Vw[e] = 0.0;
-    if (tid < W) taus[tid] = tau[(size_t)b * tau_slab + (size_t)k * dimp + (size_t)S * W + tid];
-    __syncthreads();
-    for (int e = tid; e < W * W; e += 256) {
-        const int j = e >> 6, o = e & 63;
-        Vw[(j + o) * LW + j] = Vg[e];
-    }
-    __syncthreads();
-    for (int e = tid; e < W * W; e += 256) {
-        const int j1 = e >> 6, j2 = e & 63;          // (a wavefront shares j1)
-        const int lo = j1 > j2 ? j1 : j2, hi = (j1 < j2 ? j1 : j2) + W;   // rows where both reflectors live
-        double s = 0.0;
-        for (int c = lo; c < hi; c++) s += Vw[c * LW + j1] * Vw[c * LW + j2];
-        Ss[j1 * LW + j2] = s;
-        Ts[j1 * LW + j2] = 0.0;
-    }
-    __syncthreads();
-    for (int i = 0; i < W; i++) {
-        const double ti = taus[i];
-        if (tid < i) {
-            double acc = 0.0;
-            for (int m = tid; m < i; m++) acc += Ts[tid * LW + m] * Ss[m * LW + i];
-            Ts[tid * LW + i] = -ti * acc;
-        }
-        if (tid == i) Ts[i * LW + i] = ti;
-        __syncthreads();
-    }
-    double* Tg = Tout + (size_t)b * t_slab + ((size_t)S * npos + k) * W * W;
-    for (int e = tid; e < W * W; e += 256) Tg[e] = Ts[(e >> 6) * LW + (e & 63)];
-}
-
-// ---- back-transformation through the chase's reflectors --------------------------------------------------------------
-constexpr int BT_ROWS = 48;     // eigenvectors per workgroup
-constexpr int ZS_LD = 132;      // window of 128 coordinates
-constexpr int VC_G = 18;        // zero guard on both sides of a reflector's 64 entries: the products read V[c][j] = Vc[j][c - j]
-constexpr int VC_LD = 101;      // for every c of a k-step, inside the band or not, without a select
-constexpr int TS_LD = 68;
-constexpr int WS_LD = 68;
-
-// The three products of one group on the matrix pipe, for wavefront WV of the workgroup.  FP64 MFMAs and VALU
-// instructions do not overlap on this chip, so the loops carry no address arithmetic: every LDS address is a base
-// formed once per group plus a compile-time offset (hence the wavefront as a template parameter), and the parallelogram's
-// zeros come from guard bands in LDS instead of selects.
-//   W1[e][j]  = sum_c Z[e][c] V[c][j]            wave -> j in [16 WV, 16 WV + 16), k-steps c in [16 WV, 16 WV + 80)
-//   W2[e][j'] = sum_j W1[e][j] T[j'][j]          wave -> j' tile WV, k-steps j >= 16 WV (T upper triangular)
-//   Z[e][c]  -= sum_j W2[e][j] V[c][j]           wave -> two column tiles of c (twenty k-steps together)
-template <int WV>
-__device__ __forceinline__ void bt2_products(double* __restrict__ Zs, const double* __restrict__ Vc, const double* __restrict__ Ts,
-                                             double* __restrict__ Ws, int par, int l15, int lq) {
-    v4d acc[3];
-    double* zh[2];      // logical halves of the window
-    zh[0] = Zs + (par ? 64 : 0);
-    zh[1] = Zs + (par ? 0 : 64);
-    {
-        const double* bB = Vc + (16 * WV + l15) * VC_LD + VC_G + lq - l15;
-        const double* aA0 = zh[0] + l15 * ZS_LD + lq;
-        const double* aA1 = zh[1] + l15 * ZS_LD + lq;
-#pragma unroll
-        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < 20; i++) {
-            const int c0 = 16 * WV + 4 * i;
-            const double* aA = (c0 >> 6) ? aA1 : aA0;
-            const double bv = bB[4 * i];
-#pragma unroll
-            for (int m = 0; m < 3; m++)
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[16 * m * ZS_LD + (c0 & 63)], bv, acc[m], 0, 0, 0);
-        }
-        double* w = Ws + lq * WS_LD + 16 * WV + l15;
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) w[(16 * m + 4 * reg) * WS_LD] = acc[m][reg];
-    }
-    lds_barrier();
-    {
-        const double* bT = Ts + (16 * WV + l15) * TS_LD + 16 * WV + lq;
-        const double* aW = Ws + l15 * WS_LD + 16 * WV + lq;
-#pragma unroll
-        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < 16 - 4 * WV; i++) {
-            const double bv = bT[4 * i];
-#pragma unroll
-            for (int m = 0; m < 3; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[16 * m * WS_LD + 4 * i], bv, acc[m], 0, 0, 0);
-        }
-    }
-    lds_barrier();
-    {
-        double* w = Ws + lq * WS_LD + 16 * WV + l15;
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) w[(16 * m + 4 * reg) * WS_LD] = acc[m][reg];
-    }
-    lds_barrier();
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        constexpr int NTA = WV == 0 ? 0 : WV == 1 ? 1 : WV == 2 ? 4 : 5;
-        constexpr int NTB = WV == 0 ? 3 : WV == 1 ? 2 : WV == 2 ? 7 : 6;
-        const int nt = half == 0 ? NTA : NTB;
-        const int jlo = 16 * nt - 63 > 0 ? 16 * nt - 63 : 0, jhi = 16 * nt + 15 < 63 ? 16 * nt + 15 : 63;
-        const int ks0 = jlo >> 2, steps = (jhi >> 2) - ks0 + 1;
-        const double* bB = Vc + (4 * ks0 + lq) * VC_LD + VC_G + 16 * nt + l15 - 4 * ks0 - lq;
-        const double* aW = Ws + l15 * WS_LD + 4 * ks0 + lq;
-#pragma unroll
-        for (int m = 0; m < 3; m++) acc[m] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (i < steps) {
-                const double bv = bB[i * (4 * VC_LD - 4)];
-#pragma unroll
-                for (int m = 0; m < 3; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[16 * m * WS_LD + 4 * i], bv, acc[m], 0, 0, 0);
-            }
-        }
-        double* z = zh[(16 * nt) >> 6] + lq * ZS_LD + ((16 * nt) & 63) + l15;
-#pragma unroll
-        for (int m = 0; m < 3; m++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) z[(16 * m + 4 * reg) * ZS_LD] -= acc[m][reg];
-    }
-    lds_barrier();
-}
-
-struct Bt2Args {
-    double* Qt; long slab, ld;          // rows = eigenvectors
-    const double* V; long v_slab;
-    const double* T; long t_slab;
-    long n, dimp;
-    int npos, nS, tasks_per_matrix;
-};
-
-// grid: (tasks_per_matrix * batch), 256 threads.  Per sweep block the 128-column window slides down the eigenvectors 64
-// columns per group: the half that leaves is stored, the half that stays keeps its place in LDS (the halves swap roles by
-// parity), and the next group's reflectors, T and 64 new columns are fetched into registers while this group's products
-// run on the matrix pipe.
-__global__ __launch_bounds__(256) void e2_bt2_kernel(Bt2Args a) {
-    extern __shared__ double sm[];
-    double* Zs = sm;                          // [48][ZS_LD]  two halves of 64 columns
-    double* Vc = Zs + BT_ROWS * ZS_LD;        // [64][VC_LD]   Vc[j][o] = v_j[o]
-    double* Ts = Vc + W * VC_LD;              // [64][TS_LD]
-    double* Ws = Ts + W * TS_LD;              // [48][WS_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.x / a.tasks_per_matrix, task = blockIdx.x % a.tasks_per_matrix;
-    const long e0 = (long)task * BT_ROWS;
-    const int ne = (int)min((long)BT_ROWS, a.n - e0);
-    double* Q = a.Qt + (size_t)b * a.slab + (size_t)e0 * a.ld;
-    const double* Vb = a.V + (size_t)b * a.v_slab;
-    const double* Tb = a.T + (size_t)b * a.t_slab;
-    const long n = a.n;
-    auto phys = [](int c, int par) { return (c & 63) | ((((c >> 6) ^ par) & 1) << 6); };
-    for (int e = tid; e < W * VC_LD; e += 256) Vc[e] = 0.0;     // (the guard bands stay zero)
-    for (int S = a.nS - 1; S >= 0; S--) {
-        const long s0 = (long)S * W, c00 = s0 + 1;
-        if (c00 >= n) continue;
-        const int kc = (int)((n - c00 + W - 1) / W);      // groups with a window inside the vectors
-        // ---- the first window of the block, its reflectors and T ------------------------------------------------------------
-        __syncthreads();
-        for (int e = tid; e < BT_ROWS * 128; e += 256) {
-            const int r = e >> 7, c = e & 127;
-            Zs[r * ZS_LD + c] = (r < ne && c00 + c < n) ? Q[(size_t)r * a.ld + c00 + c] : 0.0;
-        }
-        {
-            const v2d* Vg = reinterpret_cast<const v2d*>(Vb + (size_t)s0 * W);
-            const v2d* Tg = reinterpret_cast<const v2d*>(Tb + (size_t)S * a.npos * W * W);
-            for (int q = 0; q < 8; q++) {
-                const int e2 = (tid + 256 * q) * 2;
-                const v2d x = Vg[tid + 256 * q], y = Tg[tid + 256 * q];
-                Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63)] = x[0]; Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63) + 1] = x[1];
-                Ts[(e2 >> 6) * TS_LD + (e2 & 63)] = y[0]; Ts[(e2 >> 6) * TS_LD + (e2 & 63) + 1] = y[1];
-            }
-        }
-        __syncthreads();
-        for (int k = 0; k < kc; k++) {
-            const long c0 = c00 + (long)k * W;
-            const int par = k & 1;
-            const bool more = k + 1 < kc;
-            // ---- (i) the next group's data on its way into registers ------------------------------------------------------
-            v2d pv[8], pt[8];
-            double pz[12];
-            if (more) {
-                const v2d* Vg = reinterpret_cast<const v2d*>(Vb + ((size_t)(k + 1) * a.dimp + (size_t)s0) * W);
-                const v2d* Tg = reinterpret_cast<const v2d*>(Tb + ((size_t)S * a.npos + k + 1) * W * W);
-#pragma unroll
-                for (int q = 0; q < 8; q++) { pv[q] = Vg[tid + 256 * q]; pt[q] = Tg[tid + 256 * q]; }
-#pragma unroll
-                for (int q = 0; q < 12; q++) {
-                    const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
-                    pz[q] = (r < ne && c0 + 128 + cc < n) ? Q[(size_t)r * a.ld + c0 + 128 + cc] : 0.0;
-                }
-            }
-            // ---- (ii) the three products ------------------------------------------------------------------------------------
-            switch (wave) {
-                case 0: bt2_products<0>(Zs, Vc, Ts, Ws, par, l15, lq); break;
-                case 1: bt2_products<1>(Zs, Vc, Ts, Ws, par, l15, lq); break;
-                case 2: bt2_products<2>(Zs, Vc, Ts, Ws, par, l15, lq); break;
-                default: bt2_products<3>(Zs, Vc, Ts, Ws, par, l15, lq); break;
-            }
-            // ---- (iii) the half that leaves the window goes home; (iv) its place takes the columns that enter ---------------
-#pragma unroll
-            for (int q = 0; q < 12; q++) {
-                const int e = tid + 256 * q, r = e >> 6, cc = e & 63;
-                double* z = Zs + r * ZS_LD + phys(cc, par);
-                if (r < ne && c0 + cc < n) Q[(size_t)r * a.ld + c0 + cc] = *z;
-                if (more) *z = pz[q];
-                else if (r < ne && c0 + 64 + cc < n) Q[(size_t)r * a.ld + c0 + 64 + cc] = Zs[r * ZS_LD + phys(64 + cc, par)];
-            }
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int e2 = (tid + 256 * q) * 2;
-                    Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63)] = pv[q][0]; Vc[(e2 >> 6) * VC_LD + VC_G + (e2 & 63) + 1] = pv[q][1];
-                    Ts[(e2 >> 6) * TS_LD + (e2 & 63)] = pt[q][0]; Ts[(e2 >> 6) * TS_LD + (e2 & 63) + 1] = pt[q][1];
-                }
-            }
-            lds_barrier();
-        }
-    }
-}
-
 }  // namespace
 
 static inline int chase_positions(long n) { return (int)((n - 1 + W - 1) / W); }   // chain positions 0 .. npos - 1
@@ -562,31 +322,6 @@ int eigh2_chase(crm_ctx* ctx, EighWork& w) {
     return CRM_OK;
 }
 
-int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Qt) {
-    hipStream_t st = ctx->stream;
-    const long n = w.dim, dimp = w.dimp;
-    if (n <= 2) return CRM_OK;
-    const int B = w.batch, npos = chase_positions(n);
-    const int nS = (int)((n - 2 + W - 1) / W);
-    const long t_slab = (long)nS * npos * W * W;
-    CRM_TRY(w.Tbc.ensure(sizeof(double) * (size_t)t_slab * B));
-    const size_t lds_t = sizeof(double) * (4 * W * (W + 1) + W);
-    CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&e2_group_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-    hipLaunchKernelGGL(e2_group_larft_kernel, dim3(npos, nS, B), dim3(256), lds_t, st, w.Vbc.as<double>(), (long)npos * dimp * W,
-                       w.taubc.as<double>(), (long)npos * dimp, dimp, n, npos, w.Tbc.as<double>(), t_slab);
-    Bt2Args a{};
-    a.Qt = Qt; a.slab = w.slab; a.ld = w.ld;
-    a.V = w.Vbc.as<double>(); a.v_slab = (long)npos * dimp * W;
-    a.T = w.Tbc.as<double>(); a.t_slab = t_slab;
-    a.n = n; a.dimp = dimp; a.npos = npos; a.nS = nS;
-    a.tasks_per_matrix = (int)((n + BT_ROWS - 1) / BT_ROWS);
-    const size_t lds = sizeof(double) * (BT_ROWS * ZS_LD + W * VC_LD + W * TS_LD + BT_ROWS * WS_LD);
-    CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&e2_bt2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(e2_bt2_kernel, dim3((unsigned)(a.tasks_per_matrix * B)), dim3(256), lds, st, a);
-    CRM_HIP(hipGetLastError());
-    return CRM_OK;
-}
-
 int eigh2_family(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb, double* lam_host, double** Zt) {
     const bool trace = getenv("CRM_TRACE_SETUP") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -616,13 +351,14 @@ int eigh2_family(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb, 
     lap("divide & conquer");
     {
         TraceRange r("crm eigh2 back-transformation (chase)");
-        CRM_TRY(eigh2_back_chase(ctx, w, Qt));
+        CRM_TRY(eigh_rows_to_columns(ctx, w, Qt));
+        CRM_TRY(eigh2_back_chase(ctx, w, w.A.as<double>()));
     }
     lap("back-transformation 2");
     {
         TraceRange r("crm eigh2 back-transformation (band)");
         w.v_shared = true;
-        const int rc = eigh_back_transform(ctx, w, Qt, Zt);
+        const int rc = eigh_back_transform(ctx, w, Qt, Zt, true);
         w.v_shared = false;
         CRM_TRY(rc);
     }

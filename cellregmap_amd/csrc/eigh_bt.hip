@@ -135,7 +135,13 @@ void eigh_free(EighWork& w) {
 }
 
 // Qt: rows = eigenvectors of the tridiagonal (sorted); returns *Zt: rows = eigenvectors of A.
-int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) {
+int eigh_rows_to_columns(crm_ctx* ctx, EighWork& w, const double* Qt) {
+    hipStream_t st = ctx->stream;
+    CRM_HIP(hipMemsetAsync(w.A.ptr, 0, sizeof(double) * (size_t)w.batch * w.slab, st));
+    return transpose_batch(st, w.batch, Qt, w.A.as<double>(), w.slab, w.ld, w.dim, w.dim);
+}
+
+int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out, bool z_ready) {
     hipStream_t st = ctx->stream;
     const long dim = w.dim, ld = w.ld, dimp = w.dimp, slab = w.slab;
     const int B = w.batch;
@@ -151,9 +157,8 @@ int eigh_back_transform(crm_ctx* ctx, EighWork& w, double* Qt, double** Zt_out) 
     double* Z = w.A.as<double>();
     double* Vc = w.Vc.as<double>();
     const double* Vt = w.Vt.as<double>();
-    CRM_HIP(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)B * slab, st));
+    if (!z_ready) CRM_TRY(eigh_rows_to_columns(ctx, w, Qt));
     CRM_HIP(hipMemsetAsync(Vc, 0, sizeof(double) * (size_t)VB * slab, st));
-    CRM_TRY(transpose_batch(st, B, Qt, Z, slab, ld, dim, dim));
     CRM_TRY(transpose_batch(st, VB, Vt, Vc, slab, ld, dim, dim));
     const int nblocks = (int)((dim - 1 + BT_NB - 1) / BT_NB);
     // Blocks of 2 BT_NB reflectors where the matrices are large: the update Z -= V (T (V'Z)) is a product over the
