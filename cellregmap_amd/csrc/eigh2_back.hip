@@ -19,6 +19,9 @@
 // the window slides 64 coordinates: the upper four tiles are stored, the lower four take their place (register renaming
 // by parity) and four new tiles arrive from a prefetch issued a group earlier.  Eight wavefronts per workgroup, one
 // workgroup per CU: two wavefronts per SIMD cover each other's operand latencies.
+#include <algorithm>
+#include <vector>
+
 #include "eigh.h"
 
 namespace crm {
@@ -80,7 +83,6 @@ __global__ __launch_bounds__(256) void e2_group_larft_kernel(const double* __res
 
 // ---- the back-transformation ---------------------------------------------------------------------------------------------
 constexpr int R_WAVES = 8;
-constexpr int R_E = 16 * R_WAVES;   // eigenvectors per workgroup
 constexpr int R_VG = 18;            // zero guard on both sides of a reflector's 64 entries: the products read V[c][j] =
 constexpr int R_VLD = 101;          // Vs[j][c - j] for every c of a k-step, inside the band or not, without a select
 constexpr int R_VSZ = W * R_VLD;
@@ -102,7 +104,8 @@ struct BackArgs {
     const double* V; long v_slab;
     const double* T; long t_slab;
     long n, dimp;
-    int npos, nS, tasks_per_matrix;
+    int npos, nS;
+    const int* tasks;                   // per workgroup: matrix, first tile of sixteen eigenvectors, tiles (<= R_WAVES)
 };
 
 // One group on the window lo (coordinates c0 .. c0 + 63) / hi (c0 + 64 .. c0 + 127).  `more`: the sweep block goes on --
@@ -197,14 +200,14 @@ __device__ __forceinline__ void r_group(v4d (&lo)[4], v4d (&hi)[4], const double
     lds_barrier();
 }
 
-// grid: (tasks_per_matrix * batch), 512 threads, 2 * R_BUF doubles of dynamic LDS
+// grid: one workgroup per task, 512 threads, 2 * R_BUF doubles of dynamic LDS
 __global__ __launch_bounds__(512) void e2_back_kernel(BackArgs a) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.x / a.tasks_per_matrix, task = blockIdx.x % a.tasks_per_matrix;
+    const int b = a.tasks[3 * blockIdx.x], tile0 = a.tasks[3 * blockIdx.x + 1], tiles = a.tasks[3 * blockIdx.x + 2];
     const long n = a.n;
-    const long e0 = (long)task * R_E + 16 * wave;
-    const bool active = e0 < n;                       // (a wavefront of zero columns only helps with the copies)
+    const long e0 = 16L * (tile0 + (wave < tiles ? wave : 0));
+    const bool active = wave < tiles;                 // (a wavefront without a tile only helps with the copies)
     // rows < n of this matrix: loads past the end return zero, stores there are dropped
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(a.Z + (size_t)b * a.slab, 0, (int)(unsigned)((size_t)n * a.ld * 8), 0x00020000);
@@ -267,6 +270,30 @@ __global__ __launch_bounds__(512) void e2_back_kernel(BackArgs a) {
 
 static inline int chase_positions(long n) { return (int)((n - 1 + W - 1) / W); }   // chain positions 0 .. npos - 1
 
+// Tasks of e2_back_kernel: (matrix, first tile of sixteen eigenvectors, tiles <= R_WAVES) per workgroup.  A wavefront's tile
+// costs the same wherever it is, and a CU runs one workgroup at a time, two wavefronts per SIMD: whole rounds of
+// eight-tile workgroups first; what is left goes out as four-tile workgroups (one wavefront per SIMD: half the time of a
+// round) when a single round of those takes it.
+static std::vector<int> back_tasks(int B, long n, long cus) {
+    const long nt = (n + 15) / 16;
+    const long full = (long)B * nt / (R_WAVES * cus) * cus;          // eight-tile workgroups of the whole rounds
+    std::vector<int> tasks, tail;
+    auto put = [](std::vector<int>& v, int b, long t0, long count) { v.push_back(b); v.push_back((int)t0); v.push_back((int)count); };
+    for (int b = 0; b < B; b++) {
+        const long mine = std::min(nt / R_WAVES, full / B + (b < full % B ? 1 : 0));
+        for (long q = 0; q < mine; q++) put(tasks, b, q * R_WAVES, R_WAVES);
+        for (long t0 = mine * R_WAVES; t0 < nt; t0 += 4) put(tail, b, t0, std::min(4L, nt - t0));
+    }
+    if ((long)tail.size() / 3 > cus) {    // too many for one short round: eight-tile workgroups throughout
+        tasks.clear();
+        tail.clear();
+        for (int b = 0; b < B; b++)
+            for (long t0 = 0; t0 < nt; t0 += R_WAVES) put(tasks, b, t0, std::min<long>(R_WAVES, nt - t0));
+    }
+    tasks.insert(tasks.end(), tail.begin(), tail.end());
+    return tasks;
+}
+
 // Z: [batch] x slab, column e (of matrix b) = eigenvector e of the tridiagonal; Z <- Q2 Z in place.
 int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Z) {
     hipStream_t st = ctx->stream;
@@ -275,7 +302,13 @@ int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Z) {
     const int B = w.batch, npos = chase_positions(n);
     const int nS = (int)((n - 2 + W - 1) / W);
     const long t_slab = (long)nS * npos * W * W;
-    CRM_TRY(w.Tbc.ensure(sizeof(double) * (size_t)t_slab * B));
+    hipDeviceProp_t prop;
+    CRM_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    const std::vector<int> tasks = back_tasks(B, n, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    const size_t t_bytes = sizeof(double) * (size_t)t_slab * B;
+    CRM_TRY(w.Tbc.ensure(t_bytes + sizeof(int) * tasks.size()));
+    int* d_tasks = reinterpret_cast<int*>(w.Tbc.as<char>() + t_bytes);
+    CRM_HIP(hipMemcpyAsync(d_tasks, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice, st));
     const size_t lds_t = sizeof(double) * (4 * W * (W + 1) + W);
     CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&e2_group_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
     hipLaunchKernelGGL(e2_group_larft_kernel, dim3(npos, nS, B), dim3(256), lds_t, st, w.Vbc.as<double>(), (long)npos * dimp * W,
@@ -285,11 +318,12 @@ int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Z) {
     a.V = w.Vbc.as<double>(); a.v_slab = (long)npos * dimp * W;
     a.T = w.Tbc.as<double>(); a.t_slab = t_slab;
     a.n = n; a.dimp = dimp; a.npos = npos; a.nS = nS;
-    a.tasks_per_matrix = (int)((n + R_E - 1) / R_E);
+    a.tasks = d_tasks;
     const size_t lds = sizeof(double) * 2 * R_BUF;
     CRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&e2_back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(e2_back_kernel, dim3((unsigned)(a.tasks_per_matrix * B)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(e2_back_kernel, dim3((unsigned)(tasks.size() / 3)), dim3(512), lds, st, a);
     CRM_HIP(hipGetLastError());
+    CRM_HIP(hipStreamSynchronize(st));     // (the task table is a host vector)
     return CRM_OK;
 }
 
