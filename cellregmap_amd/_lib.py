@@ -92,6 +92,7 @@ SIGNATURES = {
                                               vp, vp, vp, vp]),
     "crm_test_eigh": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp]),
     "crm_test_eigh2": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp]),
+    "crm_test_back_tasks": (ctypes.c_int, [ctypes.c_int, ctypes.c_long, ctypes.c_int, vp, ctypes.c_int, c_int_p]),
     "crm_test_dc_plan": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, c_double_p, vp, vp, vp,
                                         c_int_p, vp]),
     "crm_test_eigvalsh": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),

@@ -328,3 +328,16 @@ int eigh2_back_chase(crm_ctx* ctx, EighWork& w, double* Z) {
 }
 
 }  // namespace crm
+
+// ---- test hook (host only: no GPU touched): the task table of the back-transformation ------------------------------------
+extern "C" int crm_test_back_tasks(int batch, long dim, int cus, int* tasks, int capacity, int* count) {
+    return crm::guarded("crm_test_back_tasks", [&]() -> int {
+    if (batch < 1 || dim < 1 || cus < 1 || !tasks || !count) return CRM_ERR_ARG;
+    const std::vector<int> t = crm::back_tasks(batch, dim, cus);
+    *count = (int)(t.size() / 3);
+    if ((int)t.size() > capacity) return CRM_ERR_ARG;
+    std::copy(t.begin(), t.end(), tasks);
+    return CRM_OK;
+    });
+}
+

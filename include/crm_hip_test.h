@@ -98,6 +98,11 @@ int crm_test_eigh2(crm_ctx* ctx, int nq, int dim, const double* C, const double*
 int crm_test_dc_plan(const double* lam, const double* z, int n1, int n, double beta, int* k, double* rho, int* rows,
                      double* dl, double* w, int* nrot, double* rots);
 
+/* Host-only: the task table of the back-transformation through the chase's reflectors (cellregmap_amd/csrc/eigh2_back.hip)
+ * for `batch` matrices of order `dim` on a device of `cus` compute units: count triples (matrix, first tile of sixteen
+ * eigenvectors, tiles <= 8) in launch order.  CRM_ERR_ARG when capacity (ints) is too small; *count is set either way. */
+int crm_test_back_tasks(int batch, long dim, int cus, int* tasks, int capacity, int* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,35 @@ def test_one_band_serves_every_grid_point():
         d = np.r_[np.full(k1, np.sqrt(rho)), np.full(n - k1, np.sqrt(1 - rho))]
         scaled_then_reduced, _ = proto.stage1(C * np.outer(d, d), k1, w)
         assert np.abs(scaled_then_reduced - band * np.outer(d, d)).max() <= 1e-12 * np.abs(band).max()
+
+
+def test_back_transformation_tasks_cover_every_tile_once():
+    """eigh2_back.hip: back_tasks -- whole rounds of eight-tile workgroups, the rest as four-tile workgroups when one round of
+    those takes it.  Whatever the sizes: every tile of sixteen eigenvectors of every matrix exactly once, at most eight per
+    workgroup (host-only hook, no GPU)."""
+    import ctypes
+
+    from cellregmap_amd import _lib
+
+    lib = _lib.load()
+    for batch, dim, cus in [(10, 5064, 256), (10, 10064, 256), (10, 1064, 256), (1, 1100, 256), (3, 2400, 256), (11, 1024, 256),
+                            (10, 16448, 256), (2, 3, 256), (1, 16, 4), (7, 1999, 64), (10, 5064, 304), (1, 17, 1)]:
+        cap = 3 * (batch * ((dim + 15) // 16) + 8)
+        tasks = np.zeros(cap, np.int32)
+        count = ctypes.c_int()
+        _lib.check(lib.crm_test_back_tasks(batch, dim, cus, _lib.ptr(tasks), cap, ctypes.byref(count)))
+        t = tasks[: 3 * count.value].reshape(-1, 3)
+        nt = (dim + 15) // 16
+        seen = np.zeros((batch, nt), int)
+        for b, t0, n in t:
+            assert 1 <= n <= 8 and 0 <= b < batch and t0 + n <= nt
+            seen[b, t0:t0 + n] += 1
+        assert (seen == 1).all(), (batch, dim, cus)
+        if (batch, dim, cus) == (10, 10064, 256):     # three whole rounds of eight tiles, then 44 short workgroups
+            assert len(t) == 812 and (t[:768, 2] == 8).all() and (t[768:, 2] <= 4).all()
+        if (batch, dim, cus) == (10, 5064, 256):      # 290 short workgroups would not fit one round: eight tiles throughout
+            assert len(t) == 400 and (t[:, 2] == 8).sum() == 390
+    # too small a buffer is refused with the count reported
+    count = ctypes.c_int()
+    small = np.zeros(3, np.int32)
+    assert lib.crm_test_back_tasks(10, 5064, 256, _lib.ptr(small), 3, ctypes.byref(count)) != 0 and count.value == 400
