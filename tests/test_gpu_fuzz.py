@@ -144,4 +144,6 @@ def test_fuzz_verbatim_procedure():
     flagged = same & (a[:, 8] != 0)
     assert np.all(a[flagged, 0] < 2e-5), s
     assert np.all(a[flagged, 2] <= 5e-5 * a[flagged, 5] + P_ATOL), s
-    assert s["share_flat_optimum"] < 0.6, s       # (flat likelihoods are the rule at a 1e-6 search: tools/diag/flat_flag_study.py)
+    # (flat likelihoods are the rule at a 1e-6 search -- 54 ... 60 % of a stream carry the flag, tools/diag/flat_flag_study.py;
+    # the bound only says that the flag is not raised everywhere)
+    assert s["share_flat_optimum"] < 0.7, s
