@@ -45,20 +45,22 @@ def algorithmic_flops(n, r_list, r_star, k0, c):
 
 def executed_flops(n, cols, r_list, r_star, k0, c, fast_rotation, kin=None):
     """What the engine executes per variant-test.  fast_rotation: the rotations go through the mixing matrices,
-    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones.  kin = (k1, k2, donors_padded, m, folded): the
+    T(rho) = Mix(rho)'(H'g) -- one n-length product plus eleven cols-length ones.  kin = (k1, k2, donors_padded, m, folded, pairs): the
     background knows the donor structure of its kinship factor, so H'g and H'(g o E0) are formed donor by donor
     (2 n (k1 + k2) flops per product column plus the contraction over the donors with the donor-level factor) and
     Q0(rho*)'(g o E0) is taken as Mix(rho*)'[H'(g o E0)]: 2 cols r* k0 instead of 2 n r* k0."""
     R = float(sum(r_list))
     if kin is not None:
-        k1, k2, dpad, m, folded = kin
+        k1, k2, dpad, m, folded, pairs = kin
         if folded:   # the contraction over the donors sits in the mixing matrices: their products are k1 + donors k2 long
             per_column = 2.0 * n * (k1 + k2)
             cols = folded
         else:
             per_column = 2.0 * n * (k1 + k2) + 2.0 * dpad * m * k2    # donor sums + contraction over the donors
         rot = per_column + 2.0 * cols * R
-        contraction = per_column * k0 + 2.0 * cols * r_star * k0
+        # H'(g o E0): per-donor sums and E1 rows -- or, when every context set is the scan's own, ONE product per donor
+        # against the k0 (k0 + 1) / 2 symmetric pair features (scan.hip: donor pairs)
+        contraction = (2.0 * n * pairs if pairs else per_column * k0) + 2.0 * cols * r_star * k0
     else:
         rot = 2.0 * n * cols + 2.0 * cols * R if fast_rotation else 2.0 * n * R
         contraction = 2.0 * n * r_star * k0
@@ -683,7 +685,8 @@ def main():
     if kin_groups:
         k2_, m_ = (Ls.us.shape[1], Ls.hK.shape[1]) if args.mode == "C" else (0, 0)
         folded = lib.crm_background_kinship_folded(crm._bg.handle)
-        kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_, (cohort.E.shape[1] + kin_groups * k2_) if folded else 0)
+        pairs = k0 * (k0 + 1) // 2 if lib.crm_test_donor_pair_blocks(ctx) > 0 else 0
+        kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_, (cohort.E.shape[1] + kin_groups * k2_) if folded else 0, pairs)
     f_exe = executed_flops(n, cols, ranks, rstar, k0, c_cov, fast_rotation=True, kin=kin)
     per_rank_rate = value / world
 

@@ -52,9 +52,19 @@ class HadamardHalves(Sequence):
     indexing / iterating yields the same arrays as the reference's list, but ``CellRegMap`` hands the
     two factors to the device and never materialises the n x (k*m) concatenation on the host."""
 
-    def __init__(self, us, hK):
+    def __init__(self, us, hK, contexts=None):
         self.us = np.ascontiguousarray(us, dtype=float)
         self.hK = np.ascontiguousarray(hK, dtype=float)
+        # What the device is handed in the place of ``us``.  us = U S = E V with V orthogonal when E has full column rank,
+        # so [diag(E[:, i]) hK for i] is the same covariance sum_i L_i L_i' = K o EE' in another basis of the same column
+        # space (H -> H blockdiag(I, V (x) I): same Gram spectrum, same Q0 S0 Q0').  In that basis the per-donor sums of the
+        # kinship-structure route against the kinship term's contexts are sums against the scan's own contexts -- symmetric
+        # when E2 = E, the reference's default -- which halves their product (csrc/scan.hip: donor pairs).
+        self.device_us = self.us
+        if contexts is not None:
+            E = np.ascontiguousarray(contexts, dtype=float)
+            if E.shape == self.us.shape:
+                self.device_us = E
 
     def __len__(self):
         return self.us.shape[1]
@@ -82,7 +92,7 @@ def get_L_values(hK, E):
             _us_cache.popitem(last=False)
     else:
         _us_cache.move_to_end(key)
-    return HadamardHalves(us, np.asarray(hK, float))
+    return HadamardHalves(us, np.asarray(hK, float), contexts=E)
 
 
 class _Background:
@@ -164,7 +174,7 @@ def _announce_kinship_groups(bg, halves):
     ``halves``: the factored halves of mode C, or -- mode B, ``hS = [sqrt(rho) E1, sqrt(1 - rho) hK]`` -- the kinship factor
     itself, which is the same structure with a single column of ones in the place of ``us``."""
     if isinstance(halves, HadamardHalves):
-        hK, us = halves.hK, halves.us
+        hK, us = halves.hK, halves.device_us
     else:
         hK = np.ascontiguousarray(halves, dtype=float)
         us = np.ones((hK.shape[0], 1))
@@ -192,12 +202,12 @@ def _announce_kinship_groups(bg, halves):
 
 def _make_background_hadamard(E1, halves, rho, device, rel_tol, cache):
     lib = _lib.load()
-    key = (device, "hadamard", _digest(E1, halves.us, halves.hK), tuple(np.asarray(rho, float)), rel_tol)
+    key = (device, "hadamard", _digest(E1, halves.device_us, halves.hK), tuple(np.asarray(rho, float)), rel_tol)
     if cache and key in _bg_cache:
         _bg_cache.move_to_end(key)
         return _bg_cache[key]
     ctx = _context(device)
-    E1c, us, hK, rho = _lib.f64(E1), halves.us, halves.hK, _lib.f64(rho)
+    E1c, us, hK, rho = _lib.f64(E1), halves.device_us, halves.hK, _lib.f64(rho)
     h = ctypes.c_void_p()
     finder = None
     if cache:
@@ -283,7 +293,7 @@ class BackgroundBuilder:
     def _begin(self, lib, E1c, B, nrho, flags, rel_tol, h, device):
         if isinstance(B, HadamardHalves):
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
-                                                B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.us), B.us.shape[1],
+                                                B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.device_us), B.us.shape[1],
                                                 _lib.ptr(B.hK), B.hK.shape[1], nrho, _lib.ptr(self.rho), _lib.ptr(flags),
                                                 float(rel_tol), ctypes.byref(h)))
         else:

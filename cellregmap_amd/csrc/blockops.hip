@@ -519,6 +519,92 @@ int launch_pair_rows_sym(hipStream_t st, const double* C, long ldc, int variants
     return CRM_OK;
 }
 
+// ---- per-donor sums of the folded kinship-structure form from the symmetric pair features (scan.hip, step 6) ----------
+// P[d][b][pair(j, i)] = sum over the cells of donor d of g_b E_j E_i (j <= i; one batched product against E (x) E in donor
+// order) holds everything of S_d = sum_c g_c e_c e_c' when the contexts of the kinship term are the scan's own (the
+// reference's default E2 = E).  A workgroup takes four variants and a range of donors and walks them:
+//     S[(k1 + d k0 + j), b k0 + i] = P[d][b][pair(min(j, i), max(j, i))]      4 k0 contiguous doubles per row of S
+// and its sum over the donors -- the E1 rows' G'(E (x) E) over all cells when E1 = E as well -- goes to Psum[split][b][pair].
+constexpr int DP_VARIANTS = 4, DP_MAX_SLOTS = 32;   // 4 * npair <= 256 * slots and 4 * k0 <= 256: k0 <= 63
+
+template <int DP_SLOTS>     // entries of the four pair rows per thread (registers: as few as the context count needs)
+__global__ __launch_bounds__(256) void donor_pairs_expand_kernel(const double* __restrict__ P, long p_slab, long ldp, int donors,
+                                                                  int variants, int k0, int k1, double* __restrict__ S, long lds,
+                                                                  double* __restrict__ Psum, long psum_slab) {
+    extern __shared__ double tile[];              // [DP_VARIANTS][npair]
+    const int npair = k0 * (k0 + 1) / 2, total = DP_VARIANTS * npair;
+    const int v0 = blockIdx.x * DP_VARIANTS, tid = threadIdx.x;
+    const int per = (donors + gridDim.y - 1) / gridDim.y;
+    const int d0 = blockIdx.y * per, d1 = min(donors, d0 + per);
+    if (d0 >= d1) return;
+    // reading: entry e = tid + 256 q of the four variants' pair rows, the same for every donor
+    double acc[DP_SLOTS], x[DP_SLOTS];
+    int src[DP_SLOTS];
+#pragma unroll
+    for (int q = 0; q < DP_SLOTS; q++) {
+        const int e = tid + 256 * q, v = e / npair, pr = e - v * npair;
+        acc[q] = 0.0;
+        src[q] = e < total && v0 + v < variants ? (int)((long)(v0 + v) * ldp + pr) : -1;   // (< 2^31: rows x 2 048 at most)
+    }
+    auto fetch = [&](int d) {
+        const double* __restrict__ Pd = P + (size_t)d * p_slab;
+#pragma unroll
+        for (int q = 0; q < DP_SLOTS; q++)
+            if (tid + 256 * q < total) x[q] = src[q] >= 0 ? Pd[src[q]] : 0.0;
+    };
+    // writing: thread t < 4 k0 owns column t of the four variants' run in every row j of the donor: (variant, i) fixed
+    const int row_len = DP_VARIANTS * k0;
+    const int vw = tid / k0, iw = tid - vw * k0;
+    const bool writer = tid < row_len && v0 + vw < variants;
+    const int base_i = iw * k0 - iw * (iw - 1) / 2 - iw;          // pair(i, j) = base_i + j for j >= i
+    const double* __restrict__ mine = tile + vw * npair;
+    fetch(d0);
+    for (int d = d0; d < d1; d++) {
+#pragma unroll
+        for (int q = 0; q < DP_SLOTS; q++)
+            if (tid + 256 * q < total) { acc[q] += x[q]; tile[tid + 256 * q] = x[q]; }
+        __syncthreads();
+        if (d + 1 < d1) fetch(d + 1);      // (in flight while this donor's rows are written)
+        if (writer) {
+            double* __restrict__ Sd = S + (size_t)(k1 + (long)d * k0) * lds + (long)v0 * k0 + tid;
+            for (int j = 0; j < k0; j++) {
+                const int pidx = j <= iw ? j * k0 - j * (j - 1) / 2 + (iw - j) : base_i + j;
+                Sd[(long)j * lds] = mine[pidx];
+            }
+        }
+        __syncthreads();
+    }
+    double* __restrict__ out = Psum + (size_t)blockIdx.y * psum_slab;
+#pragma unroll
+    for (int q = 0; q < DP_SLOTS; q++)
+        if (tid + 256 * q < total && src[q] >= 0) out[src[q]] = acc[q];
+}
+
+bool donor_pairs_serves(int k0) { return k0 >= 2 && DP_VARIANTS * (k0 * (k0 + 1) / 2) <= 256 * DP_MAX_SLOTS && DP_VARIANTS * k0 <= 256; }
+
+int launch_donor_pairs_expand(hipStream_t st, const double* P, long p_slab, long ldp, int donors, int variants, int k0, int k1,
+                              double* S, long lds, double* Psum, long psum_slab, int splits) {
+    if (variants <= 0 || donors <= 0) return CRM_OK;
+    if (!donor_pairs_serves(k0) || splits < 1) {
+        set_error("donor pairs: k0=%d outside the supported range", k0);
+        return CRM_ERR_UNSUPPORTED;
+    }
+    const size_t lds_bytes = sizeof(double) * DP_VARIANTS * (size_t)(k0 * (k0 + 1) / 2);
+    dim3 grid((unsigned)((variants + DP_VARIANTS - 1) / DP_VARIANTS), (unsigned)splits);
+    const int slots = (DP_VARIANTS * (k0 * (k0 + 1) / 2) + 255) / 256;
+#define CRM_DP_LAUNCH(SL)                                                                                                        \
+    hipLaunchKernelGGL(donor_pairs_expand_kernel<SL>, grid, dim3(256), lds_bytes, st, P, p_slab, ldp, donors, variants, k0, k1, \
+                       S, lds, Psum, psum_slab)
+    if (slots <= 4) CRM_DP_LAUNCH(4);
+    else if (slots <= 8) CRM_DP_LAUNCH(8);
+    else if (slots <= 16) CRM_DP_LAUNCH(16);
+    else if (slots <= 24) CRM_DP_LAUNCH(24);
+    else CRM_DP_LAUNCH(32);
+#undef CRM_DP_LAUNCH
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 // dst[k, j] = src[k, j] * scale[k * ld_scale]  (j < cols): the contexts times the single column of us, donor order
 __global__ void scale_rows_kernel(const double* __restrict__ src, long ld_src, const double* __restrict__ scale, long ld_scale,
                                   int cols, double* __restrict__ dst, long ld_dst) {

@@ -99,6 +99,7 @@ struct crm_gene {
     crm::DevBuf kinEp;    // the (permuted) contexts in the donor order of the background's kinship structure
     crm::DevBuf kinP;     // pair products E1_a o E0_i of the folded kinship-structure form (E1 rows of step 6)
     crm::DevBuf kinUE;    // us o E0 in donor order (folded form with a single column of us: mode B)
+    crm::DevBuf kinEE;    // E (x) E (pairs j <= j') in donor order (folded form whose kinship contexts are the scan's own)
     long ld_ep = 0, ld_ye = 0, ld_ee = 0;
     // donor tables of the collapsed path (valid for one grouped panel and the identity permutation)
     unsigned long e0_key = 0;    // content hash of E0 (key of the background's shared donor tables)

@@ -712,7 +712,7 @@ void crm_gene_destroy(crm_gene* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->dt_own.release();
     for (auto* b : {&g->yW, &g->E0, &g->WW, &g->Wy, &g->Wproj, &g->rot, &g->Ep, &g->YE, &g->EE, &g->idx, &g->dt_Z1, &g->dt_sums,
-                    &g->dt_Zt, &g->kinEp, &g->kinP, &g->kinUE})
+                    &g->dt_Zt, &g->kinEp, &g->kinP, &g->kinUE, &g->kinEE})
         b->release();
     delete g;
     } catch (...) {  // (nothing may unwind into the caller; a destroy has no status to return)
@@ -1555,6 +1555,44 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_TRY(g0->kinP.ensure(sizeof(double) * (size_t)np * ldP));
         CRM_TRY(launch_pair_features(st, bg->H.as<double>(), bg->ldh, bg->kin_k1, d_Ep, g0->ld_ep, k0, np, g0->kinP.as<double>(), ldP));
     }
+    // The kinship term's contexts are E as well (the reference's default E2 = E): the per-donor sums S_d = sum_c g_c e_c e_c'
+    // are symmetric -- one batched product per donor against E (x) E in donor order, half the flops of the Khatri-Rao form and
+    // a plain product, then a pass that writes the rows of S (blockops.hip: donor_pairs_expand_kernel); the E1 rows are the
+    // sum of those products over the donors, so their product over all cells goes as well.  Taken where its time is the
+    // smaller one (many tiny donors: the pass over S costs more than the products save).
+    bool donor_pairs = false;
+    const long ldPd = round_up((long)npair, 128);
+    const long pd_rows = std::max<long>(BLK, max_pairs) + 128, pd_slab = pd_rows * ldPd;
+    int donor_pair_splits = 1;
+    if (kfold && e1_sym && bg->kin_k2 == k0 && donor_pairs_serves(k0) && form("donor_pairs", 1)) {
+        const double peak = 78.6e12, hbm = 4.0e12;
+        const double t_kr = 2.0 * bg->kin_rows * (double)k0 * k0 / (0.6 * peak) + 2.0 * (double)np * npair / (0.92 * peak);
+        const double t_pairs = 2.0 * bg->kin_rows * (double)npair / (0.8 * peak) +
+                               (double)bg->kin_groups * (2.0 * npair + (double)k0 * k0) * sizeof(double) / hbm;
+        const bool fits = sizeof(double) * (double)bg->kin_groups * (double)pd_slab <= 8.0 * (1ull << 30);
+        if (fits && (t_pairs < t_kr || form("donor_pairs", 1) >= 2)) {
+            int h_flag = 0;
+            int* d_flag = reinterpret_cast<int*>(d_near);
+            CRM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+            CRM_TRY(launch_same_columns(st, bg->kin_Y.as<double>(), bg->kin_ldy, g0->kinEp.as<double>(), g0->ld_ep, bg->kin_rows, k0, d_flag));
+            CRM_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            donor_pairs = h_flag == 0;
+        }
+        if (donor_pairs) {
+            CRM_TRY(g0->kinEE.ensure(sizeof(double) * (size_t)bg->kin_rows * g0->ld_ee));
+            CRM_TRY(launch_gather_rows(st, d_EE, g0->ld_ee, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ee, g0->kinEE.as<double>(),
+                                       g0->ld_ee));
+            CRM_TRY(ctx->ws_Pd.ensure(sizeof(double) * (size_t)bg->kin_groups * pd_slab));
+            // the expansion pass: four variants per workgroup, three workgroups per CU -- donor ranges fill its rounds
+            const long wgs = (std::max<long>(BLK, 1) + 3) / 4;
+            while ((wgs * donor_pair_splits) % 768 != 0 && wgs * donor_pair_splits < 4 * 768 && donor_pair_splits < 8 &&
+                   donor_pair_splits < bg->kin_groups)
+                donor_pair_splits++;
+            CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)std::max<long>(donor_pair_splits, fold_split6) *
+                                      (size_t)std::max<long>(pd_slab, (std::max<long>(BLK, max_pairs) + 128) * ldP)));
+        }
+    }
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit((size_t)BLK * ng);
     std::vector<int> h_pos((size_t)BLK * ng), h_ord(max_pairs);
@@ -2073,10 +2111,27 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                 kp[groups + slices++] = p;
             }
             GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+            if (donor_pairs) {     // per donor G_d' (E (x) E)_d, then the rows of S and the E1 rows from it
+                for (long d = 0; d < groups; d++) {
+                    GemmProblem& p = kp[d];
+                    p.E = nullptr; p.lde = 0; p.k0 = 0;
+                    p.Y = g0->kinEE.as<double>() + bg->kin_row0[d] * g0->ld_ee; p.ldy = g0->ld_ee;
+                    p.C = ctx->ws_Pd.as<double>() + (size_t)d * pd_slab; p.ldc = ldPd;
+                    p.M = ncol; p.N = npair;
+                }
+            }
             CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * (size_t)(groups + std::max(slices, 1)), hipMemcpyHostToDevice, st));
-            if (k2 == 1) CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, ncol, k0, maxlen, false, 0, 1, 0));
+            if (donor_pairs) {
+                CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, ncol, npair, maxlen, false, 0, 1, 0));
+                CRM_TRY(launch_donor_pairs_expand(st, ctx->ws_Pd.as<double>(), pd_slab, ldPd, (int)groups, ncol, k0, k1, S, ld_ah,
+                                                  ctx->ws_AH.as<double>(), pd_slab, donor_pair_splits));
+                CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), (long)ncol * ldPd, donor_pair_splits, pd_slab));
+                CRM_TRY(launch_pair_rows_sym(st, ctx->ws_AH.as<double>(), ldPd, ncol, k0, S, ld_ah));
+                ctx->donor_pair_blocks++;
+            } else if (k2 == 1) CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, ncol, k0, maxlen, false, 0, 1, 0));
             else CRM_TRY(launch_kr_transposed(ctx, d_kp, (int)groups, ncol * k0, k2, maxlen, k0));
-            if (e1_pairs) {
+            if (donor_pairs) {
+            } else if (e1_pairs) {
                 const long p_slab = (long)(std::max<long>(BLK, max_pairs) + 128) * ldP;
                 CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, ncol, e1_sym ? npair : k1 * k0, np, false, 0, fold_split6, p_slab));
                 CRM_TRY(launch_reduce_splits(st, ctx->ws_AH.as<double>(), (long)ncol * ldP, fold_split6, p_slab));
@@ -2425,6 +2480,8 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
 long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
 
 long crm_test_dense_repeats(const crm_ctx* ctx) { return ctx ? ctx->dense_repeats : -1; }
+
+long crm_test_donor_pair_blocks(const crm_ctx* ctx) { return ctx ? ctx->donor_pair_blocks : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
     return crm::guarded_on("crm_test_set_shared_h", ctx, [&]() -> int {

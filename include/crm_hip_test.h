@@ -58,6 +58,10 @@ long crm_test_tail_launches(const crm_ctx* ctx);
 /* Variants that scans on the donor-collapsed path repeated on the dense path because they were nearly collinear with the
  * covariates (scan.hip: COLLINEAR_TAU; the dense path orthogonalises the block against W in the cell axis). */
 long crm_test_dense_repeats(const crm_ctx* ctx);
+/* Blocks of this context's scans whose per-donor sums H'(g o E0) came from one batched product against the symmetric pair
+ * features E (x) E (scan.hip: donor pairs -- the kinship term's contexts are the scan's own; form "donor_pairs": 0 never,
+ * 1 where its estimated time is the smaller one, 2 always). */
+long crm_test_donor_pair_blocks(const crm_ctx* ctx);
 /* The same product stored transposed: CT (N x (B*k0)). */
 int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                            const double* E, const double* Y, double* CT);

@@ -740,3 +740,48 @@ def test_scans_from_several_threads_on_one_device_are_serialised_by_the_library(
     assert not errors, errors
     for (pv, info), (spv, sinfo) in zip(got, serial):
         assert np.array_equal(pv, spv) and np.array_equal(info["rho1"], sinfo["rho1"])
+
+
+@pytest.mark.parametrize("donors,cells,k0,variants", [(6, 120, 7, 37), (12, 90, 20, 130), (5, 300, 50, 64)])
+def test_per_donor_sums_from_the_symmetric_pair_features(donors, cells, k0, variants, kernel_form):
+    """The kinship term's contexts are the scan's own (run_interaction's default E2 = E): the folded kinship-structure form
+    takes the per-donor sums S_d = sum_c g_c e_c e_c' from one batched product against E (x) E in donor order and the E1
+    rows as their sum over the donors (scan.hip: donor pairs; blockops.hip: donor_pairs_expand_kernel) instead of the
+    Khatri-Rao launch per donor plus the E1 rows' own product.  Both forms must give the same statistics to rounding --
+    odd context counts, variant counts that are no multiple of the four a workgroup takes -- and the oracle's."""
+    import cellregmap_amd as crm
+    from cellregmap_amd import _engine, _lib
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    c = make_cohort(donors, cells, k0, variants, seed=300 + k0)
+    rng = np.random.default_rng(k0)
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes: the dense path
+    kernel_form("kin_fold", 2)                            # (read when the structure is announced: folded with few contexts too)
+    Ls = crm.get_L_values(c.hK, c.E)
+    assert Ls.device_us is not Ls.us and np.array_equal(Ls.device_us, c.E)   # the device gets the contexts' own basis
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+    lib, ctx = _lib.load(), _engine._context(0)
+    assert lib.crm_background_kinship_folded(obj._bg.handle) > 0
+    panel = crm.GenotypePanel(G, groups=None)
+    _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
+    try:
+        kernel_form("donor_pairs", 2)                     # always (the cost model would leave small cohorts to the old form)
+        before = lib.crm_test_donor_pair_blocks(ctx)
+        pv, info, st = obj.scan_interaction(panel, return_stats=True)
+        used = lib.crm_test_donor_pair_blocks(ctx)
+        assert used > before                              # the form under test ran ...
+        kernel_form("donor_pairs", 0)
+        pv0, info0, st0 = obj.scan_interaction(panel, return_stats=True)
+        assert lib.crm_test_donor_pair_blocks(ctx) == used   # ... and the knob really switches it off
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
+    assert np.array_equal(info["rho1"], info0["rho1"])
+    scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
+    assert np.all(np.abs(st["Q"] - st0["Q"]) <= 1e-10 * scale)
+    fs = np.abs(st0["F"]).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(st["F"] - st0["F"]) <= 1e-10 * fs)
+    assert np.all(np.abs(pv - pv0) <= 1e-6 * pv0 + 1e-13)
+    sel = np.arange(0, variants, max(1, variants // 6))
+    opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, sel])
+    assert np.all(np.abs(pv[sel] - opv) <= 5e-5 * opv + 1e-13), np.c_[pv[sel], opv]
