@@ -633,10 +633,12 @@ def main():
 
         run_multi(min(mb, 4096))   # warm-up: work buffers at the size of a full block (4096 variants), Q0 of the selected grid points
         fence()
+        no_pair0 = lib.crm_test_tests_without_pair(ctx)
         t0 = time.perf_counter()
         run_multi(mb)
         fence()
         t_multi = max_over_ranks(time.perf_counter() - t0)
+        no_pair = lib.crm_test_tests_without_pair(ctx) - no_pair0
         # config 4's one collective: the (genes x variants) results of every shard on every rank -- 5 arrays per gene,
         # packed into ONE all_gather (cellregmap_amd/distributed.py: gather_many_results; RCCL over xGMI when the group is nccl)
         t_gather4, gather4_note = 0.0, None
@@ -661,6 +663,10 @@ def main():
                    "scan_s": round(t_multi, 3), "gather_s": round(t_gather4, 4) if dist is not None else None,
                    "gather": gather4_note, "gathered_bytes_per_rank": 8 * 5 * len(crms) * mb if dist is not None else None,
                    "distinct_rho_per_variant": float(np.mean([len(set(mrho[:, j])) for j in range(min(mb, 4096))])),
+                   "tests_without_kinship_term": {"share": round(no_pair / max(len(crms) * mb, 1), 4),
+                                                  "note": "fits that end with (v0 / v1) max S0 <= 1e-10 (delta at its upper clamp: the odd "
+                                                          "phenotypes of this leg are permuted, i.e. have no random effect); the rotated test "
+                                                          "direction enters their Q and F with weights <= 1e-10 and is not formed"},
                    "max_rel_dp_gene0_vs_single_gene_scan": float(np.max(np.abs(mpv[0, :min(mb, p_need)] - pv_dense[:min(mb, p_need)]) /
                                                                    np.maximum(pv_dense[:min(mb, p_need)], 1e-300))) if same_panel else
                                                              float(np.max(np.abs(mpv[0] - fpv) / np.maximum(fpv, 1e-300))),

@@ -77,6 +77,7 @@ SIGNATURES = {
     "crm_test_tail_launches": (ctypes.c_long, [vp]),
     "crm_test_dense_repeats": (ctypes.c_long, [vp]),
     "crm_test_donor_pair_blocks": (ctypes.c_long, [vp]),
+    "crm_test_tests_without_pair": (ctypes.c_long, [vp]),
     "crm_test_set_contraction_sync": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_sync_fallbacks": (ctypes.c_long, [vp]),
     "crm_test_overruns": (ctypes.c_long, []),

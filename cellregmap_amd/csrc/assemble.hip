@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
     const int r = R.r;
     const double ratio = fit.v0 / fit.v1;
     const long pos = a.sorted_pos[b];
-    const double* __restrict__ Arows = a.A + pos * a.k0 * a.ldA;
+    const double* __restrict__ Arows = pos >= 0 ? a.A + pos * a.k0 * a.ldA : a.A_none;
+    const long a_stride = pos >= 0 ? a.ldA : 0;      // (no position: every row is the row of zeros)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void gram_ext_kernel(AssembleArgs a, double* _
             const int row = wave + 4 * i;
             double x = 0.0;
             if (okj && row < KT) {
-                const double* __restrict__ p = row < k0 ? Arows + (long)row * a.ldA : tail_ptr[row - k0];
+                const double* __restrict__ p = row < k0 ? Arows + (long)row * a_stride : tail_ptr[row - k0];
                 x = p[j];
             }
             v[i] = x * sdv;
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) void gram_ext_dma_kernel(AssembleArgs a, doubl
     const int r = R.r;
     const double ratio = fit.v0 / fit.v1;
     const long pos = a.sorted_pos[b];
-    const double* __restrict__ Arows = a.A + pos * a.k0 * a.ldA;
+    const double* __restrict__ Arows = pos >= 0 ? a.A + pos * a.k0 * a.ldA : a.A_none;
+    const long a_stride = pos >= 0 ? a.ldA : 0;      // (no position: every row is the row of zeros)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void gram_ext_dma_kernel(AssembleArgs a, doubl
     // row -> pointer (rows past KT read row 0: their outputs are never stored)
     auto row_ptr = [&](int row) -> const double* {
         if (row >= KT) row = 0;
-        if (row < k0) return Arows + (long)row * a.ldA;
+        if (row < k0) return Arows + (long)row * a_stride;
         const int t = row - k0;
         return t < c ? R.tW + (long)t * R.ldW : (t == c ? R.T + (long)b * R.ldT : R.ty);
     };

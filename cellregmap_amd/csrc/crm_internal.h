@@ -99,6 +99,7 @@ struct crm_ctx {
     long dense_repeats = 0;   // variants a collapsed scan repeated on the dense path (nearly collinear with W)
     long tail_launches = 0;   // blocks whose last columns took the 160-column-tile launch (crm_test_tail_launches)
     long donor_pair_blocks = 0;   // blocks whose per-donor sums came from the symmetric pair features (crm_test_donor_pair_blocks)
+    long tests_without_pair = 0;  // (phenotype, variant) tests whose fit has no kinship term to speak of: no A~ formed for them
     crm::EighWork* eigh_ws = nullptr;
     bool eigh_ws_busy = false;
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)
@@ -112,8 +113,9 @@ struct crm_ctx {
     crm::DevBuf ws_Tcut;   // rotations: the few small products taken out of the batched launch (cut along the contraction axis)
     crm::DevBuf ws_Gk, ws_S, ws_S2;   // kinship-structure route: the block in donor order, the per-donor sums (step 6 / step 3)
     crm::DevBuf ws_Pd;                // ... the per-donor products against the symmetric pair features (step 6, donor pairs)
+    crm::DevBuf ws_Anone;             // a row of zeros: A~ of the tests whose fit has no kinship term (AssembleArgs::A_none)
     std::vector<crm::DevBuf*> all_bufs() {
-        return {&sync_counters, &ws_xwide, &ws_Tcut, &ws_S, &ws_S2, &ws_Gk, &ws_Pd, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gx, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
+        return {&sync_counters, &ws_xwide, &ws_Tcut, &ws_S, &ws_S2, &ws_Gk, &ws_Pd, &ws_Anone, &ws_AH, &ws_XG, &ws_TH, &ws_T, &ws_A, &ws_Gb, &ws_Gx, &ws_Gs, &ws_G2, &ws_GG, &ws_Gt, &ws_Z, &ws_small, &ws_probs, &ws_F, &ws_Gext};
     }
 };
 

@@ -158,9 +158,10 @@ struct AssembleRho {
 struct AssembleArgs {
     AssembleRho rho[CRM_MAX_RHO];
     const NullFitOut* fit;    // [variants] block order
-    const int* sorted_pos;    // [variants] position of variant b inside the rho*-sorted A~ buffer
+    const int* sorted_pos;    // [variants] position of variant b inside the rho*-sorted A~ buffer; < 0: none was formed
     const double* A;          // [variants*k0 x ldA]  rows (pos*k0 + j) = Q0(rho*)' (gtest o E_j)
     long ldA;
+    const double* A_none;     // ldA zeros: the rows of a variant without a position (scan.hip: no kinship term in its fit)
     int k0, c;
     long n;
     // n-length reductions, block order

@@ -1315,6 +1315,29 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // ---- workspaces ----------------------------------------------------------------------------
     CRM_TRY(ctx->ws_T.ensure(sizeof(double) * (size_t)nrho * BLK * ldT));
     CRM_TRY(ctx->ws_A.ensure(sizeof(double) * (size_t)max_pairs * k0 * ldA));
+    CRM_TRY(ctx->ws_Anone.ensure(sizeof(double) * (size_t)ldA));
+    CRM_HIP(hipMemsetAsync(ctx->ws_Anone.ptr, 0, sizeof(double) * (size_t)ldA, st));
+    // A fit that ends with (practically) no kinship term -- delta at the upper clamp, v0 = 2.2e-16 scale: a phenotype without
+    // a random effect, half of an eQTL run -- has K0 = v1 (I + (v0 / v1) Q0 S0 Q0'): where (v0 / v1) max S0 <= 1e-10 the
+    // rotated test direction A~ enters Q and F with weights d_j <= 1e-10, below the tolerance of the test by four orders of
+    // magnitude, while its product is most of a step.  Such tests get no (variant, rho*) pair: their Gram reads rows of zeros
+    // (AssembleArgs::A_none).  rho* of such a fit is decided by rounding (the likelihood is flat in rho), so over many
+    // phenotypes these are also the fits that would scatter a variant's pairs over the whole grid.
+    if ((int)bg->s0_max.size() != nrho) {
+        bg->s0_max.assign(nrho, 0.0);
+        std::vector<double> spec;
+        for (int i = 0; i < nrho; i++) {
+            if (bg->r[i] <= 0) continue;
+            spec.resize(bg->r[i]);
+            CRM_HIP(hipMemcpyAsync(spec.data(), bg->S0[i].ptr, sizeof(double) * bg->r[i], hipMemcpyDeviceToHost, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            bg->s0_max[i] = *std::max_element(spec.begin(), spec.end());
+        }
+    }
+    const bool skip_pairs = form("pairs_without_kinship_term", 1) == 0 ? false : true;
+    auto no_kinship_term = [&](const NullFitOut& f) {
+        return skip_pairs && f.v1 > 0.0 && f.v0 >= 0.0 && f.v0 * bg->s0_max[f.rho_index] <= 1e-10 * f.v1;
+    };
     CRM_TRY(ctx->ws_Gb.ensure(sizeof(double) * (size_t)np * ldb));
     CRM_TRY(ctx->ws_Gs.ensure(sizeof(double) * (size_t)np * ldp));
     CRM_TRY(ctx->ws_G2.ensure(sizeof(double) * (size_t)np * ldb));
@@ -1899,7 +1922,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             int take = 0;
             for (; sb0 + take < nb_blk; take++) {
                 unsigned seen = 0;
-                for (int gi = 0; gi < ng; gi++) seen |= 1u << h_fit_blk[(size_t)gi * BLK + sb0 + take].rho_index;
+                for (int gi = 0; gi < ng; gi++) {
+                    const NullFitOut& f = h_fit_blk[(size_t)gi * BLK + sb0 + take];
+                    if (!no_kinship_term(f)) seen |= 1u << f.rho_index;
+                }
                 const int here = __builtin_popcount(seen);
                 if (take > 0 && pairs + here > pair_cap) break;
                 pairs += here;
@@ -1915,8 +1941,17 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         NullFitOut* const d_fit = d_fit_blk + sb0;
         const int blk_cols = (int)(ldb - sb0);      // columns of the block buffers from the sub-range's first one on
         std::fill(pair_of.begin(), pair_of.end(), -1);
+        long with_pair = 0;
         for (int gi = 0; gi < ng; gi++)
-            for (int b = 0; b < nb; b++) pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b] = 0;
+            for (int b = 0; b < nb; b++) {
+                const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
+                if (no_kinship_term(f)) continue;
+                pair_of[(size_t)f.rho_index * BLK + b] = 0;
+                with_pair++;
+            }
+        ctx->tests_without_pair += (long)ng * nb - with_pair;
+        // (a sub-range without any pair keeps its first test's: the launches below always have something to do)
+        if (with_pair == 0) pair_of[(size_t)h_fit[0].rho_index * BLK] = 0;
         int cnt[CRM_MAX_RHO] = {0}, start[CRM_MAX_RHO + 1] = {0};
         int npairs = 0;
         for (int i = 0; i < nrho; i++) {
@@ -1931,8 +1966,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
         start[nrho] = npairs;
         for (int gi = 0; gi < ng; gi++)
-            for (int b = 0; b < nb; b++)
-                h_pos[(size_t)gi * BLK + b] = pair_of[(size_t)h_fit[(size_t)gi * BLK + b].rho_index * BLK + b];
+            for (int b = 0; b < nb; b++) {
+                const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
+                h_pos[(size_t)gi * BLK + b] = no_kinship_term(f) ? -1 : pair_of[(size_t)f.rho_index * BLK + b];
+            }
         CRM_HIP(hipMemcpyAsync(d_pos, h_pos.data(), sizeof(int) * (size_t)BLK * ng, hipMemcpyHostToDevice, st));
         CRM_HIP(hipMemcpyAsync(d_ord, h_ord.data(), sizeof(int) * npairs, hipMemcpyHostToDevice, st));
         double* Gs = ctx->ws_Gs.as<double>();
@@ -2308,6 +2345,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             aa.fit = d_fit + (size_t)gi * BLK; aa.sorted_pos = d_pos + (size_t)gi * BLK;
             aa.A = ctx->ws_A.as<double>(); aa.ldA = ldA; aa.k0 = k0; aa.c = c; aa.n = n;
+            aa.A_none = ctx->ws_Anone.as<double>();
             aa.Z1 = dZ1g; aa.ldZ1 = ldZ1; aa.Z2 = dZ2; aa.ldZ2 = ldZ2; aa.Z3 = dZ3; aa.ldZ3 = ldZ3;
             aa.WW = g->WW.as<double>(); aa.Wy = g->Wy.as<double>(); aa.yy = g->yy;
             aa.gg = d_gg; aa.gy = d_gy + (size_t)gi * BLK; aa.gW = d_gW; aa.ld_gW = ld_gW;
@@ -2482,6 +2520,8 @@ long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launche
 long crm_test_dense_repeats(const crm_ctx* ctx) { return ctx ? ctx->dense_repeats : -1; }
 
 long crm_test_donor_pair_blocks(const crm_ctx* ctx) { return ctx ? ctx->donor_pair_blocks : -1; }
+
+long crm_test_tests_without_pair(const crm_ctx* ctx) { return ctx ? ctx->tests_without_pair : -1; }
 
 int crm_test_set_shared_h(crm_ctx* ctx, int mode) {
     return crm::guarded_on("crm_test_set_shared_h", ctx, [&]() -> int {

@@ -62,6 +62,10 @@ long crm_test_dense_repeats(const crm_ctx* ctx);
  * features E (x) E (scan.hip: donor pairs -- the kinship term's contexts are the scan's own; form "donor_pairs": 0 never,
  * 1 where its estimated time is the smaller one, 2 always). */
 long crm_test_donor_pair_blocks(const crm_ctx* ctx);
+/* (phenotype, variant) tests of this context's scans whose selected fit has no kinship term to speak of --
+ * (v0 / v1) max S0(rho*) <= 1e-10: delta at its upper clamp -- and for which no rotated test direction A~ was formed
+ * (scan.hip; form "pairs_without_kinship_term" = 0 forms it for every test). */
+long crm_test_tests_without_pair(const crm_ctx* ctx);
 /* The same product stored transposed: CT (N x (B*k0)). */
 int crm_test_contract_kr_t(crm_ctx* ctx, long cells, int B, int k0, int N, const double* G,
                            const double* E, const double* Y, double* CT);

@@ -785,3 +785,49 @@ def test_per_donor_sums_from_the_symmetric_pair_features(donors, cells, k0, vari
     sel = np.arange(0, variants, max(1, variants // 6))
     opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, sel])
     assert np.all(np.abs(pv[sel] - opv) <= 5e-5 * opv + 1e-13), np.c_[pv[sel], opv]
+
+
+def test_fits_without_a_kinship_term_need_no_rotated_test_direction(kernel_form):
+    """A phenotype without a random effect ends its null fits at the upper clamp of delta: v0 = 2.2e-16 scale, K0 = v1 I up to
+    1e-10 -- the rotated test direction A~ = Q0(rho*)'(g o E0) enters Q and F with weights below 1e-10 and is not formed
+    (scan.hip: no_kinship_term; the Gram kernels read rows of zeros).  Against the form that forms it for every test: the
+    same rho*, Q and F to 1e-9, p to 1e-7; the oracle's p-values; and, scanned together with a phenotype that has a random
+    effect, bit for bit what each phenotype gets on its own."""
+    import cellregmap_amd as crm
+    from cellregmap_amd import _engine, _lib
+    from cellregmap_amd.synth import make_cohort
+    from oracle import crm as ocrm
+
+    c = make_cohort(8, 150, 12, 96, seed=77)
+    rng = np.random.default_rng(5)
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)
+    y_flat = c.y[rng.permutation(c.y.size)]              # the kinship structure is gone: delta -> 1
+    Ls = crm.get_L_values(c.hK, c.E)
+    plain = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+    flat = crm.CellRegMap(y_flat, c.E, W=c.W, Ls=Ls, background=plain._bg)
+    lib, ctx = _lib.load(), _engine._context(0)
+    panel = crm.GenotypePanel(G, groups=None)
+    before = lib.crm_test_tests_without_pair(ctx)
+    pv, info, st = flat.scan_interaction(panel, return_stats=True)
+    skipped = lib.crm_test_tests_without_pair(ctx) - before
+    assert skipped >= 10, skipped                         # a good part of its fits end at the clamp ...
+    at_clamp = (info["e2"] + info["g2"]) <= 1e-13 * info["eps2"]
+    assert at_clamp.sum() >= skipped
+    kernel_form("pairs_without_kinship_term", 0)
+    mark = lib.crm_test_tests_without_pair(ctx)
+    pv0, info0, st0 = flat.scan_interaction(panel, return_stats=True)
+    assert lib.crm_test_tests_without_pair(ctx) == mark   # ... and the knob forms every A~
+    kernel_form("pairs_without_kinship_term", 0, reset=True)
+    assert np.array_equal(info["rho1"], info0["rho1"])
+    scale = np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2))
+    assert np.all(np.abs(st["Q"] - st0["Q"]) <= 1e-9 * scale)
+    fs = np.abs(st0["F"]).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(st["F"] - st0["F"]) <= 1e-9 * fs)
+    assert np.all(np.abs(pv - pv0) <= 1e-7 * pv0 + 1e-13)
+    sel = np.arange(0, G.shape[1], 12)
+    opv, _ = ocrm.OracleCellRegMap(y_flat, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, sel])
+    assert np.all(np.abs(pv[sel] - opv) <= 5e-5 * opv + 1e-13), np.c_[pv[sel], opv]
+    # both phenotypes in one pass
+    both, _ = crm.scan_interaction_many([plain, flat], panel)
+    pv_plain, _ = plain.scan_interaction(panel)
+    assert np.array_equal(both[0], pv_plain) and np.array_equal(both[1], pv)
