@@ -18,6 +18,10 @@ extern "C" {
  *   "eigh_one_stage" 1    the constructor tridiagonalises every grid point on its own (eigh_trd.hip) instead of the
  *                         two-stage family solver (eigh2_band.hip, eigh2_chase.hip)
  *   "nullfit_exact" 1     null-fit likelihood with IEEE division and one log per spectrum entry
+ *   "donor_pairs" 0 / 2   per-donor sums of the kinship-structure route never / always from the symmetric pair features
+ *                         (default 1: where the kinship term's contexts are the scan's own and a cost model says so)
+ *   "pairs_without_kinship_term" 0   form the rotated test direction for every test, also where the fit has no kinship
+ *                         term to speak of (default: not formed where (v0 / v1) max S0 <= 1e-10)
  * These replace the environment switches of earlier versions; the GPU suite flips every one of them. */
 int crm_test_set_form(const char* name, int value, int reset);
 /* Contraction kernel variant for subsequent launches on this context: tile_width 0 = chosen per
