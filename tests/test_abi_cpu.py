@@ -59,6 +59,17 @@ def test_get_L_values_is_the_hadamard_factorisation():
     Ls = get_L_values(hK, E)
     lhs = sum(L @ L.T for L in Ls)
     assert np.allclose(lhs, (hK @ hK.T) * (E @ E.T), atol=1e-10)
+    # what the device is handed in the place of U S: the contexts themselves -- the same covariance in another basis of
+    # the same column space (cellregmap_amd/_engine.py: HadamardHalves.device_us); the list the caller sees is unchanged
+    assert Ls.device_us is not Ls.us and np.array_equal(Ls.device_us, E)
+    U, S, _ = np.linalg.svd(E, full_matrices=False)
+    assert np.allclose(np.abs(Ls.us), np.abs(U * S), atol=1e-12)
+    dev = sum((Ls.device_us[:, [i]] * hK) @ (Ls.device_us[:, [i]] * hK).T for i in range(E.shape[1]))
+    assert np.allclose(dev, lhs, atol=1e-10)
+    # contexts of deficient rank: U S has fewer columns than E and stays what the device gets
+    E_def = np.concatenate([E, E[:, :1] + E[:, 1:2]], axis=1)
+    Ld = get_L_values(hK, E_def)
+    assert Ld.us.shape[1] == 3 and Ld.device_us is Ld.us
 
 
 def test_no_gpu_means_loud_failure():
