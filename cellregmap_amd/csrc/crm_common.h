@@ -132,6 +132,8 @@ int launch_gemm_tn_glds(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int 
 // Khatri-Rao contraction storing C' (N x M, leading dimension ldc): always the LDS-DMA kernel
 int launch_kr_transposed(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m, int max_n, long cells,
                          int k0);
+// C = X'Y for problems with N <= 16 columns (X with an even leading dimension, 16-byte aligned): one pass over X
+int launch_skinny_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, long cells);
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride);
 int launch_reduce_splits_band(hipStream_t st, double* C, long rows, long ld, int col0, int ncols, int ksplit,
                               long split_stride);

@@ -422,6 +422,69 @@ int launch_gemm_tn(crm_ctx* ctx, const GemmProblem* probs_dev, int nz, int max_m
     return CRM_OK;
 }
 
+// ---- C = X'Y for a narrow Y (N <= 16 columns) -------------------------------------------------------------------------
+// The last few columns of a product whose width is a little more than a multiple of the 128-column tile (scan.hip: the
+// spectrum's 5 000 = 39 tiles + 8) would cost a whole column of tiles -- 1/40 of the launch -- in the tiled kernels.  Here
+// they are one pass over X: a wavefront takes 32 columns of X (16-byte loads: columns m, m + 1 per lane, four rows per
+// instruction) as the A operands of two v_mfma_f64_16x16x4_f64 per k-step against the same four rows of Y; bound by the
+// traffic of X.  grid (ceil(max_m / 128), problems), 256 threads.
+typedef double sk_v4d __attribute__((ext_vector_type(4)));
+typedef double sk_v2d __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const GemmProblem* __restrict__ probs, long cells_total) {
+    const GemmProblem P = probs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const long m0 = (long)blockIdx.x * 128 + 32 * wave;
+    if (m0 >= P.M) return;
+    const long cells = P.cells > 0 ? P.cells : cells_total;
+    const long m = m0 + 2 * l15;                       // this lane's two columns of X (ldx even, X 16-byte aligned)
+    const bool two = m + 1 < P.M, one = m < P.M, nok = l15 < P.N;
+    const double* __restrict__ x = P.X + (long)lq * P.ldx + m;
+    const double* __restrict__ y = P.Y + (long)lq * P.ldy + l15;
+    sk_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int U = 8;                               // k-steps per trip, every load issued before the first MFMA
+    long k = 0;
+    for (; k + 4 * U <= cells; k += 4 * U) {
+        sk_v2d a[U];
+        double b[U];
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const double* xr = x + (k + 4 * q) * P.ldx;
+            a[q] = two ? *reinterpret_cast<const sk_v2d*>(xr) : (sk_v2d){one ? xr[0] : 0.0, 0.0};
+            b[q] = nok ? y[(k + 4 * q) * P.ldy] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b[q], acc1, 0, 0, 0);
+        }
+    }
+    for (; k < cells; k += 4) {
+        const bool kok = k + lq < cells;
+        const double* xr = x + k * P.ldx;
+        const double a0 = kok && one ? xr[0] : 0.0, a1 = kok && two ? xr[1] : 0.0;
+        const double b = kok && nok ? y[k * P.ldy] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+    }
+    // accumulator rows are the A operand's row index: row (lq + 4 reg) <-> columns m0 + 2 (lq + 4 reg) (+ 1) of X
+    if (l15 < P.N) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const long row = m0 + 2 * (lq + 4 * reg);
+            if (row < P.M) P.C[row * P.ldc + l15] = acc0[reg];
+            if (row + 1 < P.M) P.C[(row + 1) * P.ldc + l15] = acc1[reg];
+        }
+    }
+}
+
+int launch_skinny_tn(hipStream_t st, const GemmProblem* probs_dev, int nz, int max_m, long cells) {
+    if (nz <= 0 || max_m <= 0) return CRM_OK;
+    hipLaunchKernelGGL(skinny_tn_kernel, dim3((unsigned)((max_m + 127) / 128), (unsigned)nz), dim3(256), 0, st, probs_dev, cells);
+    CRM_HIP(hipGetLastError());
+    return CRM_OK;
+}
+
 int launch_reduce_splits(hipStream_t st, double* C, long count, int ksplit, long split_stride) {
     if (ksplit <= 1 || count <= 0) return CRM_OK;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,

@@ -2009,7 +2009,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         // would pay a whole last column of tiles -- 1 / 40 of the launch -- for those few columns: the last 128 + rem
         // columns (rem <= 32) go into a second launch of 160-column tiles instead, cut along the cell axis to fill its
         // rounds (38 x 128 + 160 = 5024 columns computed instead of 5120).
-        std::vector<GemmProblem> tails;
+        std::vector<GemmProblem> tails, spectrum_tails;
         int tail_split = 1, tail_maxn = 0;
         bool tail_of[CRM_MAX_RHO] = {false};
         if (!collapsed && !via_H && kr_split == 1 && ctx->tune.glds && ctx->tune.bn != 64 && ctx->tune.bn != 160 &&
@@ -2075,6 +2075,19 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     t.Y = p.Y + p.N; t.C = p.C + p.N; t.N = rem;
                     tails.push_back(t);
                 }
+            }
+            // The mixing-matrix products of the kinship-structure route: a spectrum a little longer than a multiple of the
+            // 128-column tile (config 3: r = 5000 = 39 tiles + 8 columns) would pay a whole last column of tiles -- 1 / 40 of
+            // the launch -- for those few columns; they go through one pass over the operand instead (launch_skinny_tn).
+            if (via_H && kin_route && !collapsed && p.N >= 1024 && p.N % 128 > 0 && p.N % 128 <= 16 && p.ldx % 2 == 0 &&
+                (reinterpret_cast<uintptr_t>(p.X) & 15) == 0 && !form("kr_no_tail", 0)) {
+                GemmProblem t = p;
+                const int rem = p.N % 128;
+                kr_flops -= 2.0 * (double)(kfold ? bg->kin_k1 + bg->kin_groups * (long)bg->kin_k2 : bg->cols) * (double)rem *
+                            (double)k0 * (double)cnt[i];      // (the timed launch is the tiled one alone)
+                p.N -= rem;
+                t.Y = p.Y + p.N; t.C = p.C + p.N; t.N = rem;
+                spectrum_tails.push_back(t);
             }
             max_m = std::max(max_m, p.M);
             max_n = std::max(max_n, p.N);
@@ -2277,6 +2290,12 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_HIP(hipEventRecord(ctx->timed[ctx->timed_used].second, st));
             ctx->timed_used++;
             ctx->kr_flops += kr_flops;
+        }
+        if (!spectrum_tails.empty()) {
+            CRM_HIP(hipMemcpyAsync(d_probs + nz, spectrum_tails.data(), sizeof(GemmProblem) * spectrum_tails.size(), hipMemcpyHostToDevice, st));
+            CRM_TRY(launch_skinny_tn(st, d_probs + nz, (int)spectrum_tails.size(), max_m, kdim));
+            ctx->tail_launches++;
+            CRM_HIP(hipStreamSynchronize(st));   // (the records live on this stack frame)
         }
         // 7. elementwise products for the side contractions
         double* G2 = ctx->ws_G2.as<double>();

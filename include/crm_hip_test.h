@@ -12,7 +12,8 @@ extern "C" {
 
 /* Kernel forms kept beside the default one (process-wide; reset != 0 returns the form to its default):
  *   "gram_staged" 1       score-statistic Gram through the register-staged kernel instead of the direct-to-LDS one
- *   "kr_no_tail" 1        the Khatri-Rao contraction of a block in one launch of 128-column tiles whatever the spectrum
+ *   "kr_no_tail" 1        the product over the spectrum (Khatri-Rao contraction, or the mixing-matrix product of the
+ *                         kinship-structure route) of a block in one launch of 128-column tiles whatever the spectrum
  *   "nullfit_per_wave" 1  null fits with one independent wavefront per (variant, grid point), not the LDS-shared queue
  *   "kin_fold" 0 / 2      never fold the donor-level kinship factor into the mixing matrices / fold with few columns too
  *   "eigh_one_stage" 1    the constructor tridiagonalises every grid point on its own (eigh_trd.hip) instead of the

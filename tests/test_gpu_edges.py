@@ -525,10 +525,12 @@ def test_gram_kernel_forms_agree(shape, kernel_form):
     assert np.all(np.abs(pv - pv2) <= 1e-6 * pv2 + 1e-13)
 
 
-def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(kernel_form):
-    """r = 2064 = 16 x 128 + 16: the last 144 columns of the Khatri-Rao contraction go through a launch of 160-column tiles
-    (scan.hip; the form "kr_no_tail" keeps the single launch over seventeen columns of 128-column tiles).  Both forms must give the
-    same statistics to rounding, and the oracle's on a few variants."""
+@pytest.mark.parametrize("route", [0, 2])
+def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(route, kernel_form):
+    """r = 2064 = 16 x 128 + 16.  Direct route (0): the last 144 columns of the Khatri-Rao contraction go through a launch of
+    160-column tiles; kinship-structure route (2): the last 16 columns of the mixing-matrix product through one pass over
+    the operand (gemm_tn.hip: skinny_tn_kernel).  The form "kr_no_tail" keeps the single launch over seventeen columns of
+    128-column tiles.  Both forms must give the same statistics to rounding, and the oracle's on a few variants."""
     import cellregmap_amd as crm
     from cellregmap_amd.synth import make_cohort
     from oracle import crm as ocrm
@@ -543,14 +545,18 @@ def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(kernel_form):
     assert max(obj._bg.rank(i) for i in range(11)) == 2064
     lib, ctx = _lib.load(), _engine._context(0)
     panel = crm.GenotypePanel(G, groups=None)
-    before = lib.crm_test_tail_launches(ctx)
-    pv, info, st = obj.scan_interaction(panel, return_stats=True)
-    used = lib.crm_test_tail_launches(ctx)
-    assert used > before                                  # the form under test ran ...
-    kernel_form("kr_no_tail", 1)
-    pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
-    kernel_form("kr_no_tail", 0, reset=True)
-    assert lib.crm_test_tail_launches(ctx) == used        # ... and the knob really switches it off
+    _lib.check(lib.crm_test_set_kinship_route(ctx, route))
+    try:
+        before = lib.crm_test_tail_launches(ctx)
+        pv, info, st = obj.scan_interaction(panel, return_stats=True)
+        used = lib.crm_test_tail_launches(ctx)
+        assert used > before                                  # the form under test ran ...
+        kernel_form("kr_no_tail", 1)
+        pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
+        kernel_form("kr_no_tail", 0, reset=True)
+        assert lib.crm_test_tail_launches(ctx) == used        # ... and the knob really switches it off
+    finally:
+        _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
     assert np.array_equal(info["rho1"], info1["rho1"])
     scale = np.maximum(np.abs(st1["Q"]), np.trace(st1["F"], axis1=1, axis2=2))
     assert np.all(np.abs(st["Q"] - st1["Q"]) <= 1e-11 * scale)
