@@ -100,7 +100,9 @@ def roofline_record(lib, ctx, crm, config, kr_ms, kr_n, kr_fl, elapsed):
                   "block (a plain K x (variants k0) x r product, K = k1 + donors k2 rows of per-donor sums S = [E1'(g o E0) over all "
                   "cells ; us'(g o E0) donor by donor] against the mixing matrix with the donor-level kinship factor folded in; "
                   "LDS-DMA operand tiles, FP64 MFMA) -- the dominant launch of the kinship-structure route (DESIGN.md 6c); "
-                  "achieved = its executed flops 2 K r* k0 per variant / its duration by HIP events on the library's stream")
+                  "achieved = its executed flops 2 K r k0 per variant / its duration by HIP events on the library's stream, r = the "
+                  "columns of the spectrum this launch computes: all r* of them, or the whole 128-column tiles when r* mod 128 <= 16 "
+                  "(cfg3: 4992 of 5000; the last 8 go through skinny_tn_kernel, one pass over S outside the timed pair)")
     else:
         kernel = ("gemm_tn_glds_sync_kernel<true, KRQ, ECQ, false> (Khatri-Rao contraction A~ = KR(G,E)' Q0, LDS-DMA operand tiles, "
                   "persistent workgroups re-aligned per XCD; <true, 1, 2, false> at k0 = 50; launches of <= 1024 tiles: gemm_tn_glds_kernel) "
