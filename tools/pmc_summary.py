@@ -62,15 +62,17 @@ def main():
     first = variants[names[0]]
     if kin:
         # operands of one launch at config 3: the per-donor sums S (5050 = k1 + donors k2 rows x 204 800 doubles) read once,
-        # MixK(rho*) 5050 x 5000 per selected grid point, A~ 204 800 x 5000 written
-        alg = 8.0 * (5050 * 204800 + 5050 * 5000 + 204800 * 5000)
+        # MixK(rho*) 5050 x 4992 per selected grid point, A~ 204 800 x 4992 written (the spectrum's 5 000 columns less the
+        # last 8, which go through skinny_tn_kernel: scan.hip, spectrum tail)
+        alg = 8.0 * (5050 * 204800 + 5050 * 4992 + 204800 * 4992)
         shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096,
-                 "flops_per_launch": 2.0 * 5050 * 5000 * 50 * 4096}
+                 "flops_per_launch": 2.0 * 5050 * 4992 * 50 * 4096}
         what = ("rocprofv3 --pmc over bench.py's own launches (tools/pmc_bench.sh; bench.py --steps 2 --warmup 1, cfg3): the "
                 "dominant launch of the kinship-structure route, gemm_tn_glds_kernel<false, 1, 0, false, 128, 1> = "
-                "MixK(rho*)' S for the 4096 variants of a block (the donor-level kinship factor folded into the mixing matrix), "
+                "MixK(rho*)' S for the 4096 variants of a block over the 39 whole tile columns of the spectrum (the donor-level kinship "
+                "factor folded into the mixing matrix), "
                 "one pass per counter group; summary by tools/pmc_summary.py")
-        note = "S 8.27 GB + MixK(rho*) 0.2 GB read once, A~ 8.19 GB written"
+        note = "S 8.27 GB + MixK(rho*) 0.2 GB read once, A~ 8.18 GB written"
     else:
         alg = 9.75e9
         shape = {"config": "cfg3", "cells": 20000, "contexts": 50, "variants_per_launch": 4096, "flops_per_launch": 4.096e13}
