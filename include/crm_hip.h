@@ -173,7 +173,10 @@ void crm_panel_destroy(crm_panel* panel);
  * for variants [first, first + count) of the panel.  idx_E / idx_G are the permutation
  * hooks of :398-413 (NULL = identity; n entries each).  Outputs have `count` entries;
  * optional outputs may be NULL.  out_lambda (count x k0) receives the eigenvalues of F in
- * ascending order, out_F (count x k0 x k0) the matrix itself. */
+ * ascending order, out_F (count x k0 x k0) the matrix itself.
+ * A variant whose selected null fit has no kinship term to speak of -- (v0 / v1) max S0(rho*) <= 1e-10: delta at its
+ * upper clamp, a phenotype without a random effect -- is tested with K0 = v1 I: the rotated test direction
+ * Q0(rho*)'(g o E0), which enters Q and F of such a fit through weights <= 1e-10, is not formed. */
 int crm_scan_interaction(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E,
                          const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2,
                          double* out_g2, double* out_eps2, double* out_Q, double* out_lml,
