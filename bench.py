@@ -339,6 +339,12 @@ def main():
                          f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` directly)")
     import torch
 
+    # stdout carries the ONE JSON line of the contract and nothing else: RCCL prints a version banner and gloo its
+    # connection notes to file descriptor 1 -- everything until the line itself is written goes to stderr instead
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
@@ -773,7 +779,10 @@ def main():
     }
     if share_gpu:
         out["data"] = "synthetic; DRY RUN: all ranks share GPU 0 (CRM_BENCH_SHARE_GPU, gloo) -- exercises the N > 1 code path, not a scaling number"
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -180,8 +180,15 @@ def sharded_background(E1, B, rho, device=0, group=None, builder=None, tensor_de
         layout = b.layout()                                   # slot name -> doubles, the same on every rank
         per_point = int(sum(layout.values()))
         most = (nrho + world - 1) // world                    # grid points of the busiest rank: every piece has that size
-        pack = torch.zeros(most * per_point, dtype=torch.float64, device=dev)
-        for k, i in enumerate(owned_grid_points(nrho, rank, world)):
+        own = owned_grid_points(nrho, rank, world)
+        pack = torch.empty(most * per_point, dtype=torch.float64, device=dev)
+        if len(own) < most:
+            pack[len(own) * per_point:].zero_()               # only the padding behind this rank's last piece
+        if pack.is_cuda:
+            # the fill above runs on torch's current stream, the exports below on the library's own (non-blocking) stream:
+            # nothing else orders the two, so torch's stream is drained before the first export touches the buffer
+            torch.cuda.current_stream(pack.device).synchronize()
+        for k, i in enumerate(own):
             off = k * per_point
             for what, size in layout.items():
                 b.export_slot(i, what, pack[off:off + size])
