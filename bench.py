@@ -309,6 +309,9 @@ def main():
     ap.add_argument("--direct-steps", type=int, default=3,
                     help="timed steps of the general-input side leg (the direct contraction against Q0(rho*), what a "
                          "cell-level hK / Ls gets; N = 1 only; 0 = skip)")
+    ap.add_argument("--rotated-steps", type=int, default=3,
+                    help="timed steps of the side leg on the kinship factor as the reference's simulator forms it (U sqrt(S): "
+                         "dense, donor-expanded; N = 1 and --kinship indicator only; 0 = skip)")
     ap.add_argument("--genes", type=int, default=64, help="phenotypes of the config-4 leg (0 = skip)")
     ap.add_argument("--genes-variants", type=int, default=0,
                     help="variants of the config-4 leg, all ranks together (0 = the config's whole fixed panel when "
@@ -605,6 +608,45 @@ def main():
                   "note": "the route a cell-level hK / Ls takes (crm_test_set_kinship_route(ctx, 0) on the same cohort): every "
                           "variant contracted against Q0(rho*) over all cells; side figure, never `value`"}
 
+    # ---- side leg: the kinship factor the reference's simulator forms (_simulate.py:83-102, 477-479: hK = U sqrt(S) of the
+    #      donor-block K -- a DENSE n x m factor whose rows are constant within a donor; SURVEY.md 8d's generator).  The
+    #      headline keeps the donor indicators (the sparse factor of the same K: the data of rounds 1-5, so that the lines stay
+    #      comparable); here the same steps run on a cohort built with the dense factor -- its own constructor, its own
+    #      phenotype (y_k is drawn through hK), the same genotype panel.  The engine finds the donor structure of either factor
+    #      and folds the donor-level m x m block into its mixing matrices, so the two rates should agree.
+    rotated = None
+    if world == 1 and args.rotated_steps > 0 and args.kinship == "indicator":
+        t0 = time.perf_counter()
+        coh2 = make_cohort(donors, cells, k0, 16, seed=20, kinship="rotated")
+        Ls2 = get_L_values(coh2.hK, coh2.E)
+        crm2 = CellRegMap(coh2.y, coh2.E, W=coh2.W, device=local_rank, **({"Ls": Ls2} if args.mode == "C" else {"hK": coh2.hK}))
+        gene2 = crm2._bind_gene()
+        _lib.check(lib.crm_ctx_synchronize(ctx))
+        t_ctor2 = time.perf_counter() - t0
+        rpv, rrho = np.empty(batch), np.empty(batch)
+
+        def scan2(first):
+            _lib.check(lib.crm_scan_interaction(gene2, panel.handle, first, batch, None, None, _lib.ptr(rpv), _lib.ptr(rrho),
+                                                None, None, None, None, None, None, None, None, None))
+
+        scan2(0)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.rotated_steps):
+            scan2((i % weak_blocks) * batch)
+        fence()
+        t_rot = time.perf_counter() - t0
+        rotated = {"value": round(args.rotated_steps * batch / t_rot, 1), "unit": "variant-tests/s", "steps": args.rotated_steps,
+                   "ms_per_step": round(t_rot / args.rotated_steps * 1e3, 3),
+                   "ratio_to_value": round(args.rotated_steps * batch / t_rot / value, 4),
+                   "cohort_and_constructor_s": round(t_ctor2, 2),
+                   "kinship_structure_found": int(lib.crm_background_kinship_groups(crm2._bg.handle)),
+                   "note": "same steps on a cohort whose kinship factor is the dense, donor-expanded U sqrt(S) of the "
+                           "reference's simulator (cellregmap_amd/synth.py: kinship_factor 'rotated') instead of the donor "
+                           "indicators; side figure, never `value`"}
+        del crm2, gene2, Ls2, coh2
+        _engine._bg_cache.clear()
+
     # ---- config 4's shape: `genes` phenotypes against one panel, the variants sharded over the ranks ---------------
     config4 = None
     multi_keep = None
@@ -774,6 +816,7 @@ def main():
                               "run of its own (its build sessions only ever had one GPU) and models no scaling figure"},
         "full_panel": full_panel,
         "direct_route": direct,
+        "rotated_kinship_factor": rotated,
         "config4": config4,
         "donor_collapsed": collapsed,
     }

@@ -933,14 +933,53 @@ class CellRegMap:
             return out["pv"], info, extra
         return out["pv"], info
 
+    def scan_interaction_permutations(self, G, idx_E_list=None, idx_G_list=None, return_Q=False):
+        """``scan_interaction(G, idx_E=perm)`` for a whole list of permutations in one call -- the loop of the reference's
+        calibration test (cellregmap/test/test_struct_lmm2.py:208-209) and of any permutation driver around the hooks at
+        cellregmap/_cellregmap.py:398-413.  The hooks enter only the test direction ``ddot(g[idx_G], E0[idx_E])``: the
+        eleven null fits, rho*, the variance components and the rotations of the variants do not depend on them and are done
+        once per block of variants (``crm_scan_interaction_permuted``); every permutation then runs the score test proper.
+
+        ``idx_E_list`` / ``idx_G_list``: sequences of B index arrays (either may be ``None``: no permutation of that kind;
+        an entry may be ``None`` too = the identity).  Returns ``(pvalues (B, p), info)`` with the reference's four ``info``
+        arrays (they are the same for every permutation); row b of ``pvalues`` is bit for bit what
+        ``scan_interaction(G, idx_E_list[b], idx_G_list[b])`` returns.  ``return_Q``: also the score statistics (B, p)."""
+        lib = _lib.load()
+        panel = self._panel(G)
+        n, p = panel.shape
+        nb = len(idx_E_list) if idx_E_list is not None else (len(idx_G_list) if idx_G_list is not None else 0)
+        if nb < 1 or (idx_E_list is not None and idx_G_list is not None and len(idx_G_list) != nb):
+            raise ValueError("idx_E_list / idx_G_list: one entry per permutation, the same number in both")
+
+        def stack(lst):
+            if lst is None:
+                return None
+            rows = [_permutation(v, n) for v in lst]
+            ident = np.arange(n, dtype=np.int32)
+            return np.ascontiguousarray(np.stack([ident if r is None else r for r in rows]), dtype=np.int32)
+
+        iE, iG = stack(idx_E_list), stack(idx_G_list)
+        gene = self._bind_gene()
+        pv = np.empty((nb, p))
+        Q = np.empty((nb, p)) if return_Q else None
+        info = {k: np.empty(p) for k in ("rho1", "e2", "g2", "eps2")}
+        if p > 0:
+            with _progress(self._device, False, p):
+                _lib.check(lib.crm_scan_interaction_permuted(gene, panel.handle, 0, p, nb, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
+                                                             _lib.ptr(info["rho1"]), _lib.ptr(info["e2"]), _lib.ptr(info["g2"]),
+                                                             _lib.ptr(info["eps2"]), _lib.ptr(Q)))
+        return (pv, info, Q) if return_Q else (pv, info)
+
     def scan_interaction_info(self, G, idx_E=None, idx_G=None):
         """The p-values together with chiscore's ``info`` of ``davies_pvalue(Q, F, True)`` (which the reference
         computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"})``.
         ``model_flags`` (bits ``MODEL_SATURATED`` = 1, ``MODEL_DELTA_AT_ZERO`` = 2, ``MODEL_G_IN_SPAN_W`` = 4,
-        ``MODEL_FLAT_OPTIMUM`` = 8, see include/crm_hip.h) / ``degenerate`` mark the variants where the reference's own
-        result is decided by rounding noise (saturated model, null fit ending at delta = 0); ``flat_optimum`` marks those
-        where the stopping point of the reference's Brent search (1e-6 on logit delta) matters beyond the tolerances
-        (statistics 1e-6, p-values 1e-5): two faithful runs may differ there, everywhere else they cannot."""
+        ``MODEL_FLAT_OPTIMUM`` = 8, ``MODEL_RHO_TIE`` = 16, see include/crm_hip.h) / ``degenerate`` mark the variants where the
+        reference's own result is decided by rounding noise (saturated model, null fit ending at delta = 0);
+        ``flat_optimum`` marks those where a decision of the reference's Brent search (1e-6 on logit delta) had a margin
+        within the rounding noise of the likelihood AND the stopping point matters beyond the tolerances (statistics 1e-6,
+        p-values 1e-5): two faithful runs may differ there; ``rho_tie`` those whose rho* is within that noise of another grid
+        point's likelihood (``info["rho1"]`` may differ between two faithful runs)."""
         lib = _lib.load()
         panel = self._panel(G)
         n, p = panel.shape
@@ -951,7 +990,8 @@ class CellRegMap:
         _lib.check(lib.crm_scan_interaction_info(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
                                                  _lib.ptr(ifault), _lib.ptr(liu), _lib.ptr(flags)))
         return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault,
-                    "model_flags": flags, "degenerate": (flags & 3) != 0, "flat_optimum": (flags & 8) != 0}
+                    "model_flags": flags, "degenerate": (flags & 3) != 0, "flat_optimum": (flags & 8) != 0,
+                    "rho_tie": (flags & 16) != 0}
 
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False, progress=None):

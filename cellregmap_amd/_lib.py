@@ -60,6 +60,7 @@ SIGNATURES = {
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
     "crm_scan_interaction_info": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 6),
+    "crm_scan_interaction_permuted": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int] + [vp] * 8),
     "crm_scan_interaction_multi": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_long, ctypes.c_long] + [vp] * 8),
     "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
     "crm_lmm_fit": (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),

@@ -100,6 +100,26 @@ struct crm_ctx {
     long tail_launches = 0;   // blocks whose last columns took the 160-column-tile launch (crm_test_tail_launches)
     long donor_pair_blocks = 0;   // blocks whose per-donor sums came from the symmetric pair features (crm_test_donor_pair_blocks)
     long tests_without_pair = 0;  // (phenotype, variant) tests whose fit has no kinship term to speak of: no A~ formed for them
+    // crm_scan_interaction_permuted: what the scan of a block computes BEFORE the permutation hooks enter -- the eleven
+    // rotations T(rho) = G'Q0(rho), the null fits and rho* (cellregmap/_cellregmap.py:345-357 sit above the hooks at
+    // :398-413) -- is recorded by the first permutation's pass (per block: the fit records and the rows T(rho*)) and
+    // replayed by the passes of the other permutations, which visit the same blocks in the same order.
+    struct ReplayBlock {
+        long col0 = 0;
+        int nb = 0;
+        bool collapsed = false;
+        std::vector<char> fit;   // NullFitOut[nb]
+        crm::DevBuf T;           // [nb x ldq]: row b = Q0(rho*(b))' g_b
+    };
+    int replay_mode = 0;         // 0 off, 1 record, 2 replay
+    size_t replay_cursor = 0;
+    std::vector<ReplayBlock*> replay_blocks;
+    void replay_clear() {
+        for (ReplayBlock* b : replay_blocks) { b->T.release(); delete b; }
+        replay_blocks.clear();
+        replay_cursor = 0;
+        replay_mode = 0;
+    }
     crm::EighWork* eigh_ws = nullptr;
     bool eigh_ws_busy = false;
     // per-launch event pairs around the dominant kernel (bench.py's roofline leg)

@@ -133,6 +133,15 @@ extern "C" int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, doub
         for (int k = i + 1; k < c; k++) s -= L[k * CMAX + i] * out_beta[k];
         out_beta[i] = s / L[i * CMAX + i];
     }
+    if (!gene->W_basis.empty()) {
+        // crm_gene_create replaced correlated columns by W V (mutually orthogonal): M b' = (M V) b  <=>  b' = V b
+        std::vector<double> b(out_beta, out_beta + c);
+        for (int a = 0; a < c; a++) {
+            double acc = 0.0;
+            for (int k = 0; k < c; k++) acc += gene->W_basis[(size_t)a * c + k] * b[k];
+            out_beta[a] = acc;
+        }
+    }
     return CRM_OK;
     });
 }

@@ -18,12 +18,21 @@ struct NullFitRho {
 struct NullFitTrial {  // one (variant, rho) fit
     double lml, delta, scale;
     int use_g, nfev;
+    double margin;  // brent_search.h: the smallest margin of the decisions that steered the search (units of the objective)
+    double noise;   // first-order bound on the rounding noise of the objective at the optimum, in roundings (x 2^-53)
+    double xunc;    // brent_search.h: movement of the stopping point per unit of perturbation of the objective values
 };
 
 struct NullFitOut {
     int rho_index;
     int use_g;  // 0 when g lies in span(W): X = [W, g] is rank deficient
     double lml, delta, scale, v0, v1;
+    // How far the fit is from another outcome, in units of its own noise bound (select_rho_kernel):
+    // decision = margin / (2^-53 noise) of the search at rho* (include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM);
+    // rho_decision = min over the other grid points i of (lml(rho*) - lml(i)) / (2^-53 (noise(rho*) + noise(i))): how far
+    // the choice of rho* itself is from another one (CRM_MODEL_RHO_TIE).  NaN where a kernel does not measure it.
+    double decision, rho_decision;
+    double margin, noise, gap, xunc;   // (the raw figures of the winner: decision = margin / noise; xunc: brent_search.h)
 };
 
 struct NullFitArgs {
@@ -31,10 +40,10 @@ struct NullFitArgs {
     int nrho, c, restricted;
     int polish;        // secant refinement of the optimum on the analytic derivative
     int exact;         // spectrum pass with IEEE division and one log per entry (the reference's own operations)
-    int probe;         // evaluate the objective at one point instead of searching (register kernels): 1 at probe_x (test
-                       // hook), 2 at probe_xv[variant] (the flat-optimum flag's look at the objective around the optimum)
+    int track;         // 1: the searches leave their trace behind (brent_search.h: margins of their decisions, movement of the
+                       // stopping point; the objective's noise bound) -- calls that ask for model flags
+    int probe;         // 1: evaluate the objective at probe_x instead of searching (register kernels; test hook)
     double probe_x;
-    const double* probe_xv;
     long n;            // cells (unpadded)
     const double* WW;  // [c x c]
     const double* Wy;  // [c]

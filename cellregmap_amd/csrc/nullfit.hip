@@ -15,6 +15,7 @@
 // and follows oracle/brent.py statement by statement.
 #include "crm_internal.h"
 #include "nullfit.h"
+#include "brent_search.h"
 
 namespace crm {
 
@@ -23,14 +24,44 @@ namespace {
 constexpr double LOG2PI = 1.8378770664093453;
 constexpr double EPS_TINY = 2.220446049250313e-16;    // numpy_sugar.epsilon.tiny
 constexpr double EPS_SMALL = 1.4901161193847656e-08;  // numpy_sugar.epsilon.small
-constexpr double LOGMAX = 709.782712893384;           // log(finfo.max)
-constexpr double GOLDEN = 0.381966011250105097;
-constexpr int MAXITER = 500;
+
+// Sum over the 64 lanes, every lane ending with bitwise the same total -- the value of the xor butterfly
+//   for (off = 1, 2, 4, 8, 16, 32) v += shfl_xor(v, off)
+// to the last bit, without its six dependent trips through the LDS crossbar per value (ds_bpermute: at a short spectrum
+// the seven reductions of an evaluation cost more than the pass over the spectrum itself).  Levels 1 and 2 are the
+// butterfly's own pairs as DPP quad permutations.  After them the four lanes of a quad hold one number (a + b is
+// commutative, exactly), so level 4 may pair a lane with ANY lane of the neighbouring quad -- row_half_mirror (lane i <->
+// 7 - i) -- and level 8 with any lane of the other half of its row -- row_mirror (i <-> 15 - i): the same two addends
+// as the butterfly's in every lane.  The rows then hold r0 .. r3, and what the butterfly's last two levels leave in every
+// lane is (r0 + r1) + (r2 + r3) (rows 2, 3: the same sum with its addends swapped): four scalar reads and three additions.
+__device__ inline double dpp_pair(double v, const int ctrl_tag) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_tag) {
+        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double read_lane(double v, const int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 
 __device__ inline double wave_sum(double v) {
+#ifdef CRM_NF_BUTTERFLY_SUM   // (diagnostic builds, tools/diag/compare_builds.py: the round-5 form of this sum)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+#endif
+    v += dpp_pair(v, 0);
+    v += dpp_pair(v, 1);
+    v += dpp_pair(v, 2);
+    v += dpp_pair(v, 3);
+    const double r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 // 1 / D for D > 0 (normal range): hardware reciprocal + two Newton steps -- full double precision to
@@ -99,6 +130,32 @@ __device__ inline bool cholesky(double (&A)[P][P], double& logdet) {
     return true;
 }
 
+// The same factorisation with the logarithms of its pivots left to the caller (piv[j] = L_jj): the objective takes them,
+// together with log(delta) and log(s), in ONE pass of the log routine with one argument per lane -- every lane of the
+// wavefront executes the scalar part of an evaluation redundantly, so five logarithms one after the other cost five times
+// what five logarithms side by side do; the routine and its arguments are the same, and so is every bit of the results.
+template <int P>
+__device__ inline bool cholesky_pivots(double (&A)[P][P], double (&piv)[P]) {
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+        if (!(d > 0.0)) return false;
+        const double l = sqrt(d);
+        A[j][j] = l;
+        piv[j] = l;
+#pragma unroll
+        for (int i = j + 1; i < P; i++) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s / l;
+        }
+    }
+    return true;
+}
+
 template <int P>
 __device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
 #pragma unroll
@@ -117,11 +174,40 @@ __device__ inline void cholesky_solve(const double (&L)[P][P], double (&b)[P]) {
     }
 }
 
+// First-order bound, in units of one rounding (2^-53), on what rounding can do to a value of the objective:
+//   rss = b' K b with b = (-beta, 1): every entry K_uv = sum_j t_u t_v / D_j + (u'v - t_u't_v) / delta carries the
+//   roundings of its terms' magnitudes, sum_j |t_u t_v| / D_j <= sqrt(K~_uu K~_vv) (spectrum part) and
+//   (|u'v| + |t_u't_v|) / delta (the complement is a difference: this is where a small delta amplifies);
+//   the value takes rss through (df / 2) log rss;
+//   the other terms -- log-determinants, n log s, the constant -- through their own magnitudes.
+// Kept out of line: the objective's own expression tree (and with it every fused multiply-add the compiler forms there)
+// must not depend on whether a kernel also asks for this bound.
+template <int U>
+__device__ __noinline__ double objective_noise_bound(const double (&bb)[U], const double (&sd)[U], const double (&pl)[U * (U + 1) / 2],
+                                                     double inv_d, double rss, double df, double lsum, double n_minus_r, double log_delta,
+                                                     double n, double log_s, double logdetXX, double logdetH, double p_eff) {
+    constexpr double LOG2PI_ = 1.8378770664093453;
+    double mag = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int v = u; v < U; v++) {
+            const double spec = sqrt(fabs(sd[u] * sd[v]));
+            const double m_uv = spec + pl[pair_index(u, v, U)] * inv_d;
+            mag += (u == v ? 1.0 : 2.0) * bb[u] * bb[v] * m_uv;
+        }
+    const double logs = fabs(lsum) + fabs(n_minus_r) * fabs(log_delta) + n * fabs(log_s) + df * (LOG2PI_ + 1.0) + fabs(logdetXX) +
+                        fabs(logdetH) + p_eff * fabs(log_s);
+    return 0.5 * (df * mag / fabs(rss) + logs);
+}
+
 // One fit: variant b at grid point w, by one wavefront.  SH: the vectors every variant of a grid point shares --
 // Q0'W, Q0'y, S0 -- are read from LDS (sW [C][sld], sy, sS) instead of global memory.
 // EX: the spectrum pass in the reference's own operations -- an IEEE division and one log per entry -- instead of the
 // hardware reciprocal + Newton steps and the mantissa-product log-determinant (NullFitArgs::exact).
-template <int C, bool SH, bool EX>
+// TR: the search also leaves its trace behind (brent_search.h; NullFitTrial::margin / noise / xunc) -- the kernels of the calls
+// that ask for model flags.  The kernels without it are the scan's.
+template <int C, bool SH, bool EX, bool TR>
 __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, const int w, const int lane,
                                             const double* sW, const double* sy, const double* sS, const int sld) {
     constexpr int P = C + 1;  // columns of X = [W, g]
@@ -272,17 +358,22 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
     // number to the last bit -- a phenotype without a random effect (delta -> 1: half of the genes of an eQTL run) sends the
     // reference's bracketing phase through 63, 127, 255, 511, 709 and Brent's iteration after it, dozens of evaluations of
     // one value.  The two clamped points are evaluated once and remembered (bit-identical results, fewer spectrum passes).
-    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0};
+    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0}, memo_noise[2] = {NAN, NAN};
     bool memo_set[2] = {false, false};
+    bool last_clamped = false;   // the last evaluation was one of the two clamped points
+    bool want_noise = false;     // the next evaluation also bounds the rounding noise of its value (cur_noise)
+    double cur_noise = NAN;
     // f(x) = -lml at d = logistic(x), with beta and scale profiled out
     auto f = [&](double x) -> double {
         nfev++;
         const double delta = logistic_clamped(x);
         const int clamp = delta == 1.0 - EPS_TINY ? 1 : (delta == EPS_TINY ? 0 : -1);
+        last_clamped = clamp >= 0;
         if (clamp >= 0 && memo_set[clamp]) {
             cur_delta = delta;
             cur_scale = memo_scale[clamp];
             cur_lml = memo_lml[clamp];
+            cur_noise = memo_noise[clamp];
             return memo_f[clamp];
         }
         auto remember = [&](double value) -> double {
@@ -291,6 +382,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
                 memo_f[clamp] = value;
                 memo_scale[clamp] = cur_scale;
                 memo_lml[clamp] = cur_lml;
+                memo_noise[clamp] = cur_noise;
             }
             return value;
         };
@@ -300,7 +392,6 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         double K[NP];  // u' Kt^-1 v
 #pragma unroll
         for (int i = 0; i < NP; i++) K[i] = S[i] + (uv[i] - tt[i]) * inv_d;
-        const double logdetK = lsum + (n - (double)r) * log(delta);
         double A[P][P], rhs[P], xky[P];
 #pragma unroll
         for (int i = 0; i < P; i++) {
@@ -316,9 +407,9 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         }
 #pragma unroll
         for (int i = 0; i < P; i++) xky[i] = rhs[i];
-        double logdetH;
+        double piv[P];
         double val;
-        if (!cholesky<P>(A, logdetH)) {
+        if (!cholesky_pivots<P>(A, piv)) {
             cur_delta = delta;
             cur_scale = NAN;
             cur_lml = NAN;
@@ -329,11 +420,45 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
 #pragma unroll
         for (int i = 0; i < P; i++) rss -= xky[i] * rhs[i];
         const double s = fmax(rss / df, EPS_SMALL);
-        val = -0.5 * (df * LOG2PI + df + n * log(s) + logdetK);
-        if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log(s)));
+        // log(delta), log(L_jj), log(s): lane q takes argument q (the others 1), one pass of log, the results read back
+        double larg = 1.0;
+        larg = lane == 0 ? delta : larg;
+#pragma unroll
+        for (int j = 0; j < P; j++) larg = lane == 1 + j ? piv[j] : larg;
+        larg = lane == P + 1 ? s : larg;
+#ifdef CRM_NF_SERIAL_LOGS      // (diagnostic builds: the round-5 form, one logarithm after the other)
+        const double log_delta = log(delta), log_s = log(s);
+        double logdetH = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) logdetH += 2.0 * log(piv[j]);
+        (void)larg;
+#else
+        const double lres = log(larg);
+        const double log_delta = read_lane(lres, 0), log_s = read_lane(lres, P + 1);
+        double logdetH = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) logdetH += 2.0 * read_lane(lres, 1 + j);
+#endif
+        const double logdetK = lsum + (n - (double)r) * log_delta;
+        val = -0.5 * (df * LOG2PI + df + n * log_s + logdetK);
+        if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log_s));
         cur_delta = delta;
         cur_scale = s;
         cur_lml = val;
+        if constexpr (TR) {
+            if (want_noise || clamp >= 0) {
+                double bb[U], sd[U], pl[NP];
+#pragma unroll
+                for (int i = 0; i < P; i++) bb[i] = fabs(rhs[i]);
+                bb[P] = 1.0;
+#pragma unroll
+                for (int u = 0; u < U; u++) sd[u] = S[pair_index(u, u, U)];
+#pragma unroll
+                for (int i = 0; i < NP; i++) pl[i] = fabs(uv[i]) + fabs(tt[i]);
+                cur_noise = objective_noise_bound<U>(bb, sd, pl, inv_d, rss, df, lsum, (n - (double)r), log_delta, n, log_s, logdetXX,
+                                                     logdetH, p_eff);
+            }
+        }
         return remember(-val);
     };
 
@@ -407,97 +532,26 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
     if (a.probe) {
         // test hook (crm_test_null_fit_probe): the objective at one given x instead of the search, so that the
         // likelihood itself can be compared with the oracle's at the same point
-        (void)f(a.probe == 2 ? a.probe_xv[b] : a.probe_x);
+        (void)f(a.probe_x);
         if (lane == 0) {
             NullFitTrial t;
             t.lml = cur_lml; t.delta = cur_delta; t.scale = cur_scale; t.use_g = use_g ? 1 : 0; t.nfev = nfev;
+            t.margin = NAN; t.noise = NAN; t.xunc = NAN;
             a.trial[(long)b * a.nrho + w] = t;
         }
         return;
     }
     {
-        // ---- bracket (oracle/brent.py: bracket) ------------------------------------------
-        double lo = -LOGMAX, hi = LOGMAX;
-        double x0 = 0.0, x1 = 1.0;
-        double f0 = f(x0), f1 = f(x1);
-        if (f1 > f0) {
-            double t = x0; x0 = x1; x1 = t;
-            t = f0; f0 = f1; f1 = t;
-        }
-        double bl, bm, bh, fm;
-        bool bracketed = false;
-        for (int it = 0; it < MAXITER; it++) {
-            double x2 = x1 + 2.0 * (x1 - x0);
-            x2 = fmin(fmax(x2, lo), hi);
-            if (x2 == x1) break;
-            const double f2 = f(x2);
-            if (f2 > f1) {
-                bl = x0 < x2 ? x0 : x2;
-                bh = x0 < x2 ? x2 : x0;
-                bm = x1;
-                fm = f1;
-                bracketed = true;
-                break;
-            }
-            x0 = x1; f0 = f1;
-            x1 = x2; f1 = f2;
-        }
-        if (!bracketed) {
-            bl = x0 < x1 ? x0 : x1;
-            bh = x0 < x1 ? x1 : x0;
-            bm = x1;
-            fm = f1;
-        }
-        // ---- Brent localmin (oracle/brent.py: localmin), rtol = atol = 1e-6 ---------------
-        const double rtol = 1e-6, atol = 1e-6;
-        double A_ = bl, B_ = bh;
-        double bx0 = bm, bf0 = fm;
-        double bx1 = bx0, bx2 = bx0, bf1 = bf0, bf2 = bf0;
-        double d = 0.0, e = 0.0;
-        for (int it = 0; it < MAXITER; it++) {
-            const double m = 0.5 * (A_ + B_);
-            const double tol = rtol * fabs(bx0) + atol;
-            const double tol2 = 2.0 * tol;
-            if (fabs(bx0 - m) <= tol2 - 0.5 * (B_ - A_)) break;
-            double p = 0.0, q = 0.0, rr = 0.0;
-            if (tol < fabs(e)) {
-                rr = (bx0 - bx1) * (bf0 - bf2);
-                q = (bx0 - bx2) * (bf0 - bf1);
-                p = (bx0 - bx2) * q - (bx0 - bx1) * rr;
-                q = 2.0 * (q - rr);
-                if (0.0 < q) p = -p;
-                q = fabs(q);
-                rr = e;
-                e = d;
-            }
-            double u;
-            if (fabs(p) < fabs(0.5 * q * rr) && q * (A_ - bx0) < p && p < q * (B_ - bx0)) {
-                d = p / q;
-                u = bx0 + d;
-                if ((u - A_) < tol2 || (B_ - u) < tol2) d = bx0 < m ? tol : -tol;
-            } else {
-                e = bx0 < m ? B_ - bx0 : A_ - bx0;
-                d = GOLDEN * e;
-            }
-            if (tol <= fabs(d)) u = bx0 + d;
-            else if (0.0 < d) u = bx0 + tol;
-            else u = bx0 - tol;
-            const double fu = f(u);
-            if (fu <= bf0) {
-                if (u < bx0) B_ = bx0; else A_ = bx0;
-                bx2 = bx1; bf2 = bf1;
-                bx1 = bx0; bf1 = bf0;
-                bx0 = u; bf0 = fu;
-            } else {
-                if (u < bx0) A_ = u; else B_ = u;
-                if (fu <= bf1 || bx1 == bx0) {
-                    bx2 = bx1; bf2 = bf1;
-                    bx1 = u; bf1 = fu;
-                } else if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
-                    bx2 = u; bf2 = fu;
-                }
-            }
-        }
+        // ---- bracket + Brent localmin (brent_search.h = oracle/brent.py, statement for statement) ----------------
+        struct Objective {
+            decltype(f)& fn;
+            const bool& at_clamp;
+            __device__ inline double operator()(double x) { return fn(x); }
+            __device__ inline bool clamped() const { return at_clamp; }
+        } objective{f, last_clamped};
+        BrentTrace trace;
+        double bf0;
+        double bx0 = brent_search<TR>(objective, trace, bf0);
         if (a.polish) {
             // secant steps on the analytic derivative (oracle/lmm.py: _polish)
             const double xs = bx0, fs = bf0;
@@ -522,6 +576,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
                 }
             }
         }
+        want_noise = true;
         (void)f(bx0);  // LMM.fit(): beta and scale refreshed at the optimum
         if (lane == 0) {
             NullFitTrial t;
@@ -530,17 +585,24 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
             t.scale = cur_scale;
             t.use_g = use_g ? 1 : 0;
             t.nfev = nfev;
+            if constexpr (TR) {
+                t.margin = fmin(trace.cmp, fmin(trace.sign, trace.edge));
+                t.xunc = trace.xunc;
+                t.noise = cur_noise;
+            } else {
+                t.margin = NAN; t.xunc = NAN; t.noise = NAN;
+            }
             a.trial[(long)b * a.nrho + w] = t;
         }
     }
 }
 
-template <int C, bool EX>
+template <int C, bool EX, bool TR>
 #ifdef CRM_NULLFIT_WAVES
 __attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
 #endif
 __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
-    nullfit_fit<C, false, EX>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
+    nullfit_fit<C, false, EX, TR>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
 }
 
 // The same fits with the shared vectors of a grid point resident in LDS.  The one-wavefront-per-fit kernel above
@@ -551,7 +613,7 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
 // grid point: likelihood-evaluation counts differ from variant to variant); when the queue is empty the workgroup moves
 // on to the next grid point with work left.  Only Q0'g still comes from L2.
 constexpr int NF_SHARED_WAVES = 12;
-template <int C, bool EX>
+template <int C, bool EX, bool TR>
 __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(NullFitArgs a, int variants, int sld,
                                                                              unsigned* __restrict__ queue) {
     extern __shared__ double nf_sm[];   // Q0'W [C][sld], Q0'y [sld], S0 [sld]
@@ -586,7 +648,7 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
                                                            __HIP_MEMORY_SCOPE_AGENT);
             const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
             if (b >= (unsigned)variants) break;
-            nullfit_fit<C, true, EX>(a, (int)b, w, lane, sW, sy, sS, sld);
+            nullfit_fit<C, true, EX, TR>(a, (int)b, w, lane, sW, sy, sS, sld);
         }
         __syncthreads();
     }
@@ -612,6 +674,7 @@ __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nr
     }
     NullFitOut o;
     o.use_g = trial[(long)b * nrho].use_g;
+    o.decision = NAN; o.rho_decision = NAN; o.margin = NAN; o.noise = NAN; o.gap = NAN; o.xunc = NAN;
     if (!fitted) {
         o.rho_index = -1;
         o.lml = NAN; o.delta = NAN; o.scale = NAN; o.v0 = NAN; o.v1 = NAN;
@@ -626,16 +689,34 @@ __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nr
         o.scale = t.scale;
         o.v0 = t.scale * (1.0 - t.delta);
         o.v1 = t.scale * t.delta;
+        // distance from another outcome in units of the noise bound: the search at rho*, and the choice of rho* itself
+        constexpr double ROUNDING = 1.1102230246251565e-16;   // 2^-53
+        o.margin = t.margin;
+        o.noise = t.noise;
+        o.xunc = t.xunc;
+        o.decision = t.margin / (ROUNDING * t.noise);
+        double gap = INFINITY, rdec = INFINITY;
+        for (int i = 0; i < nrho; i++) {
+            if (i == bi) continue;
+            const NullFitTrial q = trial[(long)b * nrho + i];
+            const double g = best - q.lml;                      // >= 0 (> 0 before bi: first strictly larger wins)
+            gap = fmin(gap, g);
+            rdec = fmin(rdec, g / (ROUNDING * (t.noise + q.noise)));
+        }
+        o.gap = gap;
+        o.rho_decision = rdec;
     }
     out[b] = o;
 }
 
 }  // namespace
 
+// (the trace is built for the default arithmetic; the "exact" test form runs without it and reports no decision distance)
 template <int C>
 static void launch_c(hipStream_t st, const NullFitArgs& a, int variants) {
-    if (a.exact) hipLaunchKernelGGL((nullfit_kernel<C, true>), dim3(variants, a.nrho), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((nullfit_kernel<C, false>), dim3(variants, a.nrho), dim3(64), 0, st, a);
+    if (a.exact) hipLaunchKernelGGL((nullfit_kernel<C, true, false>), dim3(variants, a.nrho), dim3(64), 0, st, a);
+    else if (a.track) hipLaunchKernelGGL((nullfit_kernel<C, false, true>), dim3(variants, a.nrho), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((nullfit_kernel<C, false, false>), dim3(variants, a.nrho), dim3(64), 0, st, a);
 }
 
 int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool force_wide, unsigned* queue) {
@@ -657,15 +738,19 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         CRM_HIP(hipGetDevice(&dev));
         CRM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         CRM_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned) * CRM_MAX_RHO, st));
-        const void* fn = a.exact ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, true>)
-                                 : reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false>);
+        const void* fn = a.exact ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, true, false>)
+                                 : (a.track ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false, true>)
+                                            : reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false, false>));
         if (shared_lds > 60 * 1024)
             CRM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));
         if (a.exact)
-            hipLaunchKernelGGL((nullfit_shared_kernel<1, true>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
+            hipLaunchKernelGGL((nullfit_shared_kernel<1, true, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
+                               variants, sld, queue);
+        else if (a.track)
+            hipLaunchKernelGGL((nullfit_shared_kernel<1, false, true>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
                                variants, sld, queue);
         else
-            hipLaunchKernelGGL((nullfit_shared_kernel<1, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
+            hipLaunchKernelGGL((nullfit_shared_kernel<1, false, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
                                variants, sld, queue);
     } else if (a.c > CRM_MAX_COV_WIDE) {
         CRM_TRY(launch_nullfit_xwide(st, a, variants));

@@ -11,6 +11,7 @@
 // (bracket + Brent, rtol = atol = 1e-6) is the same statement sequence as nullfit.hip and
 // oracle/brent.py, executed uniformly by all threads.
 #include "nullfit.h"
+#include "brent_search.h"
 
 namespace crm {
 
@@ -19,9 +20,6 @@ namespace {
 constexpr double LOG2PI = 1.8378770664093453;
 constexpr double EPS_TINY = 2.220446049250313e-16;
 constexpr double EPS_SMALL = 1.4901161193847656e-08;
-constexpr double LOGMAX = 709.782712893384;
-constexpr double GOLDEN = 0.381966011250105097;
-constexpr int MAXITER = 500;
 constexpr int CHW = 64;        // spectrum entries per staging step
 constexpr int KT_MAX = 64;     // c + 2 <= 64
 
@@ -232,19 +230,23 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
     double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
     int nfev = 0;
     // (the two clamped points delta = eps, 1 - eps are evaluated once and remembered: see nullfit.hip)
-    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0};
+    double memo_f[2] = {0.0, 0.0}, memo_scale[2] = {0.0, 0.0}, memo_lml[2] = {0.0, 0.0}, memo_noise[2] = {NAN, NAN};
     bool memo_set[2] = {false, false};
+    bool last_clamped = false, want_noise = false;   // (as in nullfit.hip)
+    double cur_noise = NAN;
     auto f = [&](double x) -> double {
         nfev++;
         const double delta = logistic_clamped(x);
         const int clamp = delta == 1.0 - EPS_TINY ? 1 : (delta == EPS_TINY ? 0 : -1);
+        last_clamped = clamp >= 0;
         if (clamp >= 0 && memo_set[clamp]) {
-            cur_delta = delta; cur_scale = memo_scale[clamp]; cur_lml = memo_lml[clamp];
+            cur_delta = delta; cur_scale = memo_scale[clamp]; cur_lml = memo_lml[clamp]; cur_noise = memo_noise[clamp];
             return memo_f[clamp];
         }
         auto remember = [&](double value) -> double {
             if (clamp >= 0) {
                 memo_set[clamp] = true; memo_f[clamp] = value; memo_scale[clamp] = cur_scale; memo_lml[clamp] = cur_lml;
+                memo_noise[clamp] = cur_noise;
             }
             return value;
         };
@@ -280,6 +282,26 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
             double rss = sh.Gm[(c + 1) * KT_MAX + (c + 1)] + sh.Cp[(c + 1) * KT_MAX + (c + 1)] * inv_d;
             for (int i = 0; i < P; i++) rss -= sh.rhs[i] * xk[i];
             sh.scal[2] = rss;
+            if (a.track && (want_noise || clamp >= 0)) {
+                // the noise bound of nullfit.hip: magnitudes of the terms of rss = b' K b, b = (-beta, 1)
+                // (Gm: spectrum sums, Cp: complements u'v - t_u't_v, whose two parts are each at most sqrt(u'u v'v))
+                xk[P] = 1.0;
+                const int yi = c + 1;
+                auto plain = [&](int i) -> double { return i < c ? a.WW[i * c + i] : (i == c ? a.gg[b] : a.yy); };
+                double mag = 0.0;
+                for (int u = 0; u <= P; u++) {
+                    const int ui = u < P ? u : yi;
+                    if (u < P && !use_g && u == c) continue;
+                    for (int v = u; v <= P; v++) {
+                        const int vi = v < P ? v : yi;
+                        if (v < P && !use_g && v == c) continue;
+                        const double spec = sqrt(fabs(sh.Gm[ui * KT_MAX + ui] * sh.Gm[vi * KT_MAX + vi]));
+                        const double cpl = 2.0 * sqrt(fabs(plain(ui) * plain(vi)));
+                        mag += (u == v ? 1.0 : 2.0) * fabs(xk[u]) * fabs(xk[v]) * (spec + cpl * inv_d);
+                    }
+                }
+                sh.scal[3] = mag;
+            }
         }
         __syncthreads();
         const double rss = sh.scal[2];
@@ -287,89 +309,24 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
         double val = -0.5 * (df * LOG2PI + df + n * log(s) + logdetK);
         if (a.restricted) val += 0.5 * (logdetXX - (logdetH - p_eff * log(s)));
         cur_delta = delta; cur_scale = s; cur_lml = val;
+        if (a.track && (want_noise || clamp >= 0))
+            cur_noise = 0.5 * (df * sh.scal[3] / fabs(rss) + fabs(lsum) + fabs((n - (double)r) * log(delta)) + n * fabs(log(s))
+                               + df * (LOG2PI + 1.0) + fabs(logdetXX) + fabs(logdetH) + p_eff * fabs(log(s)));
         __syncthreads();
         return remember(-val);
     };
 
-    // ---- bracket + Brent, identical to nullfit.hip -------------------------------------------------
-    double lo = -LOGMAX, hi = LOGMAX;
-    double x0 = 0.0, x1 = 1.0;
-    double f0 = f(x0), f1 = f(x1);
-    if (f1 > f0) {
-        double t = x0; x0 = x1; x1 = t;
-        t = f0; f0 = f1; f1 = t;
-    }
-    double bl, bm, bh, fm;
-    bool bracketed = false;
-    for (int it = 0; it < MAXITER; it++) {
-        double x2 = x1 + 2.0 * (x1 - x0);
-        x2 = fmin(fmax(x2, lo), hi);
-        if (x2 == x1) break;
-        const double f2 = f(x2);
-        if (f2 > f1) {
-            bl = x0 < x2 ? x0 : x2;
-            bh = x0 < x2 ? x2 : x0;
-            bm = x1; fm = f1;
-            bracketed = true;
-            break;
-        }
-        x0 = x1; f0 = f1;
-        x1 = x2; f1 = f2;
-    }
-    if (!bracketed) {
-        bl = x0 < x1 ? x0 : x1;
-        bh = x0 < x1 ? x1 : x0;
-        bm = x1; fm = f1;
-    }
-    const double rtol = 1e-6, atol = 1e-6;
-    double A_ = bl, B_ = bh;
-    double bx0 = bm, bf0 = fm;
-    double bx1 = bx0, bx2 = bx0, bf1 = bf0, bf2 = bf0;
-    double d = 0.0, e = 0.0;
-    for (int it = 0; it < MAXITER; it++) {
-        const double m = 0.5 * (A_ + B_);
-        const double tol = rtol * fabs(bx0) + atol;
-        const double tol2 = 2.0 * tol;
-        if (fabs(bx0 - m) <= tol2 - 0.5 * (B_ - A_)) break;
-        double p = 0.0, q = 0.0, rr = 0.0;
-        if (tol < fabs(e)) {
-            rr = (bx0 - bx1) * (bf0 - bf2);
-            q = (bx0 - bx2) * (bf0 - bf1);
-            p = (bx0 - bx2) * q - (bx0 - bx1) * rr;
-            q = 2.0 * (q - rr);
-            if (0.0 < q) p = -p;
-            q = fabs(q);
-            rr = e;
-            e = d;
-        }
-        double u;
-        if (fabs(p) < fabs(0.5 * q * rr) && q * (A_ - bx0) < p && p < q * (B_ - bx0)) {
-            d = p / q;
-            u = bx0 + d;
-            if ((u - A_) < tol2 || (B_ - u) < tol2) d = bx0 < m ? tol : -tol;
-        } else {
-            e = bx0 < m ? B_ - bx0 : A_ - bx0;
-            d = GOLDEN * e;
-        }
-        if (tol <= fabs(d)) u = bx0 + d;
-        else if (0.0 < d) u = bx0 + tol;
-        else u = bx0 - tol;
-        const double fu = f(u);
-        if (fu <= bf0) {
-            if (u < bx0) B_ = bx0; else A_ = bx0;
-            bx2 = bx1; bf2 = bf1;
-            bx1 = bx0; bf1 = bf0;
-            bx0 = u; bf0 = fu;
-        } else {
-            if (u < bx0) A_ = u; else B_ = u;
-            if (fu <= bf1 || bx1 == bx0) {
-                bx2 = bx1; bf2 = bf1;
-                bx1 = u; bf1 = fu;
-            } else if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
-                bx2 = u; bf2 = fu;
-            }
-        }
-    }
+    // ---- bracket + Brent localmin: the search shared with nullfit.hip (brent_search.h) ---------------------------
+    struct Objective {
+        decltype(f)& fn;
+        const bool& at_clamp;
+        __device__ inline double operator()(double x) { return fn(x); }
+        __device__ inline bool clamped() const { return at_clamp; }
+    } objective{f, last_clamped};
+    BrentTrace trace;
+    double bf0;
+    const double bx0 = a.track ? brent_search<true>(objective, trace, bf0) : brent_search<false>(objective, trace, bf0);
+    want_noise = true;
     (void)f(bx0);
     if (tid == 0) {
         NullFitTrial t;
@@ -378,6 +335,9 @@ __global__ __launch_bounds__(256) void nullfit_wide_kernel(NullFitArgs a, int rh
         t.scale = cur_scale;
         t.use_g = use_g ? 1 : 0;
         t.nfev = nfev;
+        t.margin = a.track ? fmin(trace.cmp, fmin(trace.sign, trace.edge)) : NAN;
+        t.xunc = a.track ? trace.xunc : NAN;
+        t.noise = a.track ? cur_noise : NAN;
         a.trial[(long)b * a.nrho + w] = t;
     }
 }

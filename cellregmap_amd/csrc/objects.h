@@ -89,6 +89,8 @@ struct crm_gene {
     int c = 0, k0 = 0;
     long ld_yw = 0, ldw = 0, lde = 0;
     std::vector<double> W_host;   // the covariates as used (orthogonal columns), n x c: crm_gene_create_like sums W'y from it
+    std::vector<double> W_basis;  // c x c, empty = identity: W_host = W V for the caller's W (crm_gene_create brought correlated
+                                  // columns to orthogonal ones); crm_lmm_fit returns V beta, the coefficients of the caller's W
     crm::DevBuf yW;   // [n_pad x ld_yw]: column 0 = y, columns 1..c = W
     crm::DevBuf E0;   // [n_pad x lde]
     crm::DevBuf WW, Wy;

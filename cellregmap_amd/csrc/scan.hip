@@ -443,6 +443,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     // 1e-13 the diagonal test asks for up to cond(W) ~ 1e7 -- beyond which the reference's own rank rule
     // (numpy_sugar.economic_svd: singular values below sqrt(eps)) is what decides.
     std::vector<double> Wo;
+    std::vector<double> Vtot;   // product of the passes' V (empty: W was orthogonal as passed)
     const double* Wuse = W;
     for (int pass = 0; pass < 4 && !is_diagonal(); pass++) {
         std::vector<double> A(WW), V((size_t)c * c, 0.0);
@@ -489,6 +490,14 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
         Wo.swap(Wn);
         Wuse = Wo.data();
         inner_products(Wuse);
+        if (Vtot.empty()) Vtot = V;
+        else {
+            std::vector<double> T((size_t)c * c, 0.0);
+            for (int a = 0; a < c; a++)
+                for (int k = 0; k < c; k++)
+                    for (int b = 0; b < c; b++) T[a * c + b] += Vtot[a * c + k] * V[k * c + b];
+            Vtot.swap(T);
+        }
     }
     if (!is_diagonal()) {
         set_error("gene: the covariates could not be brought to mutually orthogonal columns (W'W stays coupled beyond 1e-13 "
@@ -538,6 +547,7 @@ int crm_gene_create(crm_background* bg, const double* y, const double* W, int c,
     CRM_HIP(hipMemcpyAsync(g->Wy.ptr, Wy.data(), sizeof(double) * c, hipMemcpyHostToDevice, ctx->stream));
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     g->W_host.assign(Wuse, Wuse + (size_t)n * c);
+    g->W_basis = Vtot;
     if ((rc = gene_rotations(g)) != CRM_OK) return fail(rc);
     *out = g;
     return CRM_OK;
@@ -572,6 +582,7 @@ int crm_gene_create_like(const crm_gene* like, const double* y, crm_gene** out) 
     g->e0_key = like->e0_key; g->w_key = like->w_key;
     g->ldw = like->ldw; g->lde = like->lde; g->ld_yw = like->ld_yw;
     g->W_host = like->W_host;
+    g->W_basis = like->W_basis;
     int rc = CRM_OK;
     auto fail = [&](int code) { crm_gene_destroy(g); return code; };
     hipStream_t st = ctx->stream;
@@ -648,6 +659,7 @@ int crm_gene_create_batch(const crm_gene* like, const double* Y, long ldy, int n
         g->e0_key = like->e0_key; g->w_key = like->w_key;
         g->ldw = like->ldw; g->lde = like->lde; g->ld_yw = like->ld_yw;
         g->W_host = like->W_host;
+        g->W_basis = like->W_basis;
         const DevBuf* src[] = {&like->yW, &like->E0, &like->WW, &like->Wproj, &like->rot};
         DevBuf* dst[] = {&g->yW, &g->E0, &g->WW, &g->Wproj, &g->rot};
         for (int q = 0; q < 5; q++) {
@@ -1160,12 +1172,50 @@ __global__ void flat_probe_fit_kernel(const crm::NullFitOut* __restrict__ fit, i
     out[b] = f;
 }
 
+// crm_scan_interaction_permuted (crm_ctx::ReplayBlock): the rows T(rho*(b)) of a block out of / back into the per-grid-point
+// slabs of the rotations, T[(rho * blk + b) * ldT + j]
+__global__ void replay_rows_kernel(double* __restrict__ T, long blk, long ldT, const crm::NullFitOut* __restrict__ fit, int nb,
+                                   int cols, double* __restrict__ rows, int restore) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || j >= cols) return;
+    const int ri = fit[b].rho_index;
+    if (ri < 0) return;
+    double* slab = T + ((size_t)ri * blk + b) * ldT;
+    if (restore) slab[j] = rows[(size_t)b * ldT + j];
+    else rows[(size_t)b * ldT + j] = slab[j];
+}
+
+// CRM_MODEL_FLAT_OPTIMUM / CRM_MODEL_RHO_TIE: a decision of the null fit counts as open to rounding when its margin is
+// within this many times the first-order noise bound of the objective (in roundings of 2^-53; nullfit.hip).  Calibrated on
+// device-vs-oracle fuzz streams (tools/diag/flat_flag_study.py, profiles/r06_flat_flag_*): the bound is a sum of
+// magnitudes, rounding errors add like a random walk, so the factor is well below one.
+constexpr double FLAT_KAPPA = 1.0;
+constexpr double RHO_KAPPA = 1.0;
+constexpr int FLAT_REC = 10;   // doubles per variant of the diagnostics record (crm_test_null_fit_probe_read)
+
 struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: count*k0, F: count*k0*k0)
     double *pv, *rho1, *e2, *g2, *eps2, *Q, *lml, *delta, *scale, *lambda, *F;
     int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
     double* liu = nullptr;   // the modified-Liu p-value (chiscore's info["liu_pval"])
     int* flags = nullptr;    // CRM_MODEL_* bits per variant (include/crm_hip.h)
 };
+
+// Variants per block of a scan of `count` variants.  Automatic: as many as keep the A~ buffer (block x k0 x ldq doubles)
+// within 16 GB, at most 4096 -- fixed per-block costs (host round trip for the rho* groups, small launches, the last, partly
+// filled round of workgroups) then weigh 2-3 % less than at 1024.
+static bool scan_slow_forms(const crm_gene* g0) {
+    // the slower per-variant kernels (more than 144 Gram rows or 128 contexts): their global-memory work space
+    return g0->k0 + g0->c + 2 > 144 || g0->k0 > 128 || assemble_rows_scratch_doubles(1, g0->k0, g0->c) > 0;
+}
+static int scan_block_variants(const crm_ctx* ctx, const crm_gene* g0, long count) {
+    long auto_blk = (long)(16.0 * (1ull << 30) / (sizeof(double) * (double)g0->k0 * (double)g0->bg->ldq)) / 128 * 128;
+    auto_blk = std::max<long>(256, std::min<long>(auto_blk, CRM_MAX_AUTO_BLOCK));
+    int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
+    if (g0->c > CRM_MAX_COV_WIDE) BLK = std::min(BLK, 512);   // (63 .. 128 covariate columns: the slow null-fit kernel's scratch)
+    if (scan_slow_forms(g0)) BLK = std::min(BLK, 512);
+    return BLK;
+}
 
 // One pass over variants [first, first + count) for one or several genes that share the background,
 // the covariates W and the contexts E0 (several phenotypes against one panel).  What does not depend
@@ -1238,21 +1288,13 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         }
     }
     // several genes may ask for several rho* per variant: keep the (variant, rho) pair list bounded
-    // automatic block: as many variants as keep the A~ buffer (block x k0 x ldq doubles) within 16 GB, at
-    // most 4096 -- fixed per-block costs (host round trip for the rho* groups, small launches, the last,
-    // partly filled round of workgroups) then weigh 2-3 % less than at 1024
-    long auto_blk = (long)(16.0 * (1ull << 30) / (sizeof(double) * (double)g0->k0 * (double)bg->ldq)) / 128 * 128;
-    auto_blk = std::max<long>(256, std::min<long>(auto_blk, CRM_MAX_AUTO_BLOCK));
-    int BLK = (int)std::min<long>(ctx->block_variants > 0 ? ctx->block_variants : auto_blk, round_up(count, 128));
+    const bool slow_forms = scan_slow_forms(g0);
+    int BLK = scan_block_variants(ctx, g0, count);
     // Several phenotypes: the pair-ordered buffers (A~ and, on the routes through H, its gathered operand) grow with the
     // number of distinct (variant, rho*) pairs, up to min(nrho, ng) per variant.  They are kept within 128 GB (under half of the
     // device) by running the pair stage of a block -- steps 5 to 11 -- over sub-ranges of its variants, while the stages
     // before it (block copies, rotations and, above all, the per-phenotype null fits, which run twice as fast per variant in
     // launches of 4096 variants as in launches of 2048) keep the full block.
-    if (g0->c > CRM_MAX_COV_WIDE) BLK = std::min(BLK, 512);   // (63 .. 128 covariate columns: the slow null-fit kernel's scratch)
-    // the slower per-variant kernels (more than 144 Gram rows or 128 contexts): their global-memory work space
-    const bool slow_forms = g0->k0 + g0->c + 2 > 144 || g0->k0 > 128 || assemble_rows_scratch_doubles(1, g0->k0, g0->c) > 0;
-    if (slow_forms) BLK = std::min(BLK, 512);
     int pair_cap = BLK;
     if (ng > 1) {
         const char* cap_env = getenv("CRM_PAIR_BUFFER_GB");
@@ -1674,6 +1716,25 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         //    flops per variant instead of 2 n sum r.
         const bool fastT = !collapsed && bg->fast_T && ctx->fast_T;
         if (!fastT && !collapsed) CRM_TRY(crm_background_require_q0(bg, -1));
+        // (crm_scan_interaction_permuted: the passes after the first take the rotations at rho* and the fits of this block
+        // from the first one's record -- neither depends on the permutation hooks)
+        const bool replaying = ctx->replay_mode == 2;
+        std::vector<double> flat_obj;
+        if (replaying) {
+            if (ng != 1 || ctx->replay_cursor >= ctx->replay_blocks.size()) {
+                set_error("scan: the replayed pass visits a block the recorded one did not");
+                return CRM_ERR_INTERNAL;
+            }
+            crm_ctx::ReplayBlock* rb = ctx->replay_blocks[ctx->replay_cursor++];
+            if (rb->col0 != col0 || rb->nb != nb || rb->collapsed != collapsed || rb->fit.size() != sizeof(NullFitOut) * (size_t)nb) {
+                set_error("scan: the replayed pass visits its blocks in another order than the recorded one");
+                return CRM_ERR_INTERNAL;
+            }
+            CRM_HIP(hipMemcpyAsync(d_fit, rb->fit.data(), rb->fit.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(replay_rows_kernel, dim3((unsigned)((ldT + 255) / 256), nb), dim3(256), 0, st, ctx->ws_T.as<double>(),
+                               (long)BLK, ldT, d_fit, nb, (int)ldT, rb->T.as<double>(), 1);
+            CRM_HIP(hipGetLastError());
+        } else {
         if (fastT && kfold) {
             // folded form: rows [0, k1) = E1'G over all cells (sliced along the cell axis), rows k1 + d' k2 + j = per-donor
             // us_j'G over the donor's own cells; the contraction over the donors sits in MixK (objects.h)
@@ -1812,8 +1873,6 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         CRM_HIP(hipMemcpyAsync(d_probs + 1, probs.data(), sizeof(GemmProblem) * n_main, hipMemcpyHostToDevice, st));
         CRM_TRY(launch_gemm_tn(ctx, d_probs + 1, n_main, nb, (int)ldq, fastT ? kdim : xrows, false, 0, 1, 0));
         // 4. null fits + rho* per gene
-        std::vector<NullFitArgs> fit_args;     // (kept for the flat-optimum probes of info calls)
-        std::vector<double> flat_obj;
         trace_push("crm null fits");
         for (int gi = 0; gi < ng; gi++) {
             crm_gene* g = genes[gi];
@@ -1836,11 +1895,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             fa.trial = d_trial; fa.out = d_fit + (size_t)gi * BLK;
             fa.probe = ctx->probe_on ? 1 : 0; fa.probe_x = ctx->probe_x;
+            fa.track = outs[gi].flags ? 1 : 0;
             CRM_TRY(launch_nullfit(st, fa, nb, false, d_queue));
-            if (outs[gi].flags) {
-                if (fit_args.size() < (size_t)ng) fit_args.resize(ng);
-                fit_args[gi] = fa;
-            }
         }
         trace_pop();
         if (ctx->probe_on) {   // test hook: keep the (variant, grid point) records of this block and stop here
@@ -1854,6 +1910,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             }
             return CRM_OK;
         }
+        }   // (not replaying)
         // 5. the (rho, variant) pairs some gene selected, ordered by rho (host; nb*ng*48 bytes cross PCIe)
         CRM_HIP(hipMemcpyAsync(h_fit.data(), d_fit, sizeof(NullFitOut) * (size_t)BLK * ng, hipMemcpyDeviceToHost, st));
         if (collapsed && near_out) CRM_HIP(hipMemcpyAsync(h_near.data(), d_near, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
@@ -1869,43 +1926,32 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     return CRM_ERR_NUMERIC;
                 }
             }
-        // Flat-optimum flag, first half (info calls only; include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM): how much the objective
-        // itself changes one stopping tolerance of the reference's search away from where the fit stopped, relative to its
-        // value.  Brent's last comparisons f(x +- tol) <= f(x) are decided by rounding noise -- and the stopping point by a
-        // whole tolerance -- only where that change is within the noise of the likelihood (up to 5e-14 of its value between
-        // two faithful implementations; of 143 000 random scans the ones that land beyond the tolerances
-        // have a change of at most 1.9e-13: the bound is 3e-13).  -1: not measured (the wider null-fit kernels).
+        if (ctx->replay_mode == 1) {
+            if (ng != 1) {
+                set_error("scan: the permutation replay serves one phenotype per call");
+                return CRM_ERR_INTERNAL;
+            }
+            crm_ctx::ReplayBlock* rb = new crm_ctx::ReplayBlock();
+            ctx->replay_blocks.push_back(rb);
+            rb->col0 = col0; rb->nb = nb; rb->collapsed = collapsed;
+            rb->fit.resize(sizeof(NullFitOut) * (size_t)nb);
+            memcpy(rb->fit.data(), h_fit.data(), rb->fit.size());
+            CRM_TRY(rb->T.ensure(sizeof(double) * (size_t)nb * ldT));
+            hipLaunchKernelGGL(replay_rows_kernel, dim3((unsigned)((ldT + 255) / 256), nb), dim3(256), 0, st, ctx->ws_T.as<double>(),
+                               (long)BLK, ldT, d_fit, nb, (int)ldT, rb->T.as<double>(), 0);
+            CRM_HIP(hipGetLastError());
+        }
+        // Flat-optimum flag, first half (info calls only; include/crm_hip.h: CRM_MODEL_FLAT_OPTIMUM): how far the search of the
+        // selected fit was from taking another path -- the smallest margin of the decisions on objective values that steered
+        // it (brent_search.h), in units of the first-order bound on the objective's rounding noise at the optimum
+        // (nullfit.hip: cur_noise; select_rho_kernel: decision).  NaN: a fit whose kernel did not measure it.
         for (int gi = 0; gi < ng; gi++) {
             if (!outs[gi].flags) continue;
             if (flat_obj.empty()) flat_obj.assign((size_t)BLK * ng, -1.0);
-            for (int b = 0; b < nb; b++) flat_obj[(size_t)gi * BLK + b] = -1.0;
-            if (c > CRM_MAX_COV) continue;
-            std::vector<double> hx(nb), drop(nb, INFINITY);
-            std::vector<NullFitTrial> h_trial((size_t)nb * nrho);
-            ScopedBuf dxv, dscratch;
-            CRM_TRY(dxv.ensure(sizeof(double) * nb));
-            CRM_TRY(dscratch.ensure(sizeof(NullFitOut) * (size_t)nb));
-            NullFitArgs fa = fit_args[gi];
-            fa.probe = 2; fa.probe_xv = dxv.as<double>(); fa.out = dscratch.as<NullFitOut>(); fa.polish = 0;
-            for (int side = 0; side < 2; side++) {
-                for (int b = 0; b < nb; b++) {
-                    const double tiny = 2.220446049250313e-16;
-                    const double d = std::min(std::max(h_fit[(size_t)gi * BLK + b].delta, tiny), 1.0 - tiny);
-                    const double x = std::log(d) - std::log1p(-d);
-                    hx[b] = x + (side == 0 ? 1.0 : -1.0) * (1e-6 * std::fabs(x) + 1e-6);
-                }
-                CRM_HIP(hipMemcpyAsync(dxv.ptr, hx.data(), sizeof(double) * nb, hipMemcpyHostToDevice, st));
-                CRM_TRY(launch_nullfit(st, fa, nb, false, nullptr));
-                CRM_HIP(hipMemcpyAsync(h_trial.data(), d_trial, sizeof(NullFitTrial) * h_trial.size(), hipMemcpyDeviceToHost, st));
-                CRM_HIP(hipStreamSynchronize(st));
-                for (int b = 0; b < nb; b++) {
-                    const NullFitOut& f = h_fit[(size_t)gi * BLK + b];
-                    const double there = h_trial[(size_t)b * nrho + f.rho_index].lml;
-                    const double rel = (f.lml - there) / std::fabs(f.lml);      // > 0: the optimum is higher
-                    drop[b] = std::min(drop[b], rel == rel ? rel : -INFINITY);
-                }
+            for (int b = 0; b < nb; b++) {
+                const double dec = h_fit[(size_t)gi * BLK + b].decision;
+                flat_obj[(size_t)gi * BLK + b] = dec == dec ? dec : -1.0;
             }
-            for (int b = 0; b < nb; b++) flat_obj[(size_t)gi * BLK + b] = drop[b];
         }
         // ---- the pair stage, over sub-ranges [sb0, sb0 + nsb) of the block (one sub-range unless several phenotypes ask for
         //      more (variant, rho*) pairs than the pair-ordered buffers hold).  Inside, the block-order names below stand for
@@ -2388,8 +2434,10 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             // reference's search to either side; how far Q and p move says whether the search's last comparison matters
             std::vector<char> flat;
             std::vector<double> probe_rec;
+            const double flat_kappa = FLAT_KAPPA * 1e-3 * form("flat_kappa_milli", 1000);
+            const double rho_kappa = RHO_KAPPA * 1e-3 * form("flat_kappa_milli", 1000);
             if (o.flags) {
-                probe_rec.assign((size_t)nb * 3, 0.0);
+                probe_rec.assign((size_t)nb * FLAT_REC, 0.0);
                 std::vector<double> q0(nb), p0(nb), q1(nb), p1(nb), lam0((size_t)nb * k0);
                 CRM_HIP(hipMemcpyAsync(lam0.data(), d_lam, sizeof(double) * (size_t)nb * k0, hipMemcpyDeviceToHost, st));
                 CRM_HIP(hipMemcpyAsync(q0.data(), d_Q, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
@@ -2415,13 +2463,16 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                         for (int j = 0; j < k0; j++) trace += lam0[(size_t)b * k0 + j];
                         const bool q_moves = std::fabs(q1[b] - q0[b]) > 5e-7 * std::max(std::fabs(q0[b]), trace);
                         const bool p_moves = std::fabs(p1[b] - p0[b]) > 5e-6 * std::fabs(p0[b]);
-                        // ... and it only matters where the search cannot tell the two points apart (first half, above)
-                        const double drop = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
-                        const bool undecided = !(drop > 3e-13);
-                        probe_rec[(size_t)b * 3] = drop;
-                        probe_rec[(size_t)b * 3 + 1] = std::max(probe_rec[(size_t)b * 3 + 1],
-                                                                std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace));
-                        probe_rec[(size_t)b * 3 + 2] = std::max(probe_rec[(size_t)b * 3 + 2], std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]));
+                        // ... and it only matters where rounding could have sent the search another way (first half, above)
+                        const double dec = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
+                        const bool undecided = !(dec > flat_kappa);
+                        const NullFitOut& fo = h_fit[(size_t)gi * BLK + b];
+                        double* rec = &probe_rec[(size_t)b * FLAT_REC];
+                        rec[0] = dec;
+                        rec[1] = std::max(rec[1], std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace));
+                        rec[2] = std::max(rec[2], std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]));
+                        rec[3] = fo.margin; rec[4] = fo.noise; rec[5] = fo.rho_decision; rec[6] = fo.gap; rec[7] = fo.lml;
+                        rec[8] = fo.xunc; rec[9] = fo.delta;
                         if ((q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) && undecided) flat[b] = 1;
                     }
                 }
@@ -2441,6 +2492,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     if (!(f.delta > 1e-8)) fl |= CRM_MODEL_DELTA_AT_ZERO;
                     if (!f.use_g) fl |= CRM_MODEL_G_IN_SPAN_W;
                     if (!flat.empty() && flat[b]) fl |= CRM_MODEL_FLAT_OPTIMUM;
+                    if (f.rho_decision == f.rho_decision && !(f.rho_decision > rho_kappa)) fl |= CRM_MODEL_RHO_TIE;
                     o.flags[done + b] = fl;
                 }
                 if (o.rho1) o.rho1[done + b] = rho;
@@ -2531,6 +2583,52 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
     o.flags = out_model_flags;
     std::vector<ScanOut> outs{o};
     return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+    });
+}
+
+// B permutations of one scan (include/crm_hip.h): the first permutation's pass records, per block, the fits and the rows
+// T(rho*); the others replay them.  The panel is walked in chunks that keep the record within REPLAY_CAP_BYTES.
+int crm_scan_interaction_permuted(crm_gene* gene, crm_panel* panel, long first, long count, int nperm, const int* idx_E,
+                                  const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2, double* out_g2,
+                                  double* out_eps2, double* out_Q) {
+    return crm::guarded_on("crm_scan_interaction_permuted", gene ? gene->ctx : nullptr, [&]() -> int {
+    if (!gene || !panel || nperm < 1 || !out_pvalue) return CRM_ERR_ARG;
+    if (first < 0 || count < 0 || first + count > panel->p) {
+        set_error("scan: variants [%ld, %ld) outside the panel (p = %ld)", first, first + count, panel->p);
+        return CRM_ERR_ARG;
+    }
+    crm_ctx* ctx = gene->ctx;
+    if (ctx->replay_mode != 0 || ctx->in_scan) {
+        set_error("scan: another scan is running on this context");
+        return CRM_ERR_UNSUPPORTED;
+    }
+    const long n = gene->bg->n;
+    constexpr double REPLAY_CAP_BYTES = 8.0 * (1ull << 30);
+    // (whole blocks of the scan as one call over all `count` variants would cut them: the same launches, the same bits)
+    const long blk = scan_block_variants(ctx, gene, count);
+    const long chunk_cap = std::max<long>(blk, (long)(REPLAY_CAP_BYTES / (sizeof(double) * (double)gene->bg->ldq)) / blk * blk);
+    struct Clear { crm_ctx* c; ~Clear() { c->replay_clear(); } } clear{ctx};
+    std::vector<crm_gene*> genes{gene};
+    for (long at = 0; at < count; at += chunk_cap) {
+        const long len = std::min(chunk_cap, count - at);
+        ctx->replay_clear();
+        for (int q = 0; q < nperm; q++) {
+            ctx->replay_mode = q == 0 ? 1 : 2;
+            ctx->replay_cursor = 0;
+            // (rho*, the variance components and the fit do not depend on the permutation: written by the first pass)
+            ScanOut o{out_pvalue + (size_t)q * count + at, nullptr, nullptr, nullptr, nullptr,
+                      out_Q ? out_Q + (size_t)q * count + at : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (q == 0) {
+                o.rho1 = out_rho1 ? out_rho1 + at : nullptr; o.e2 = out_e2 ? out_e2 + at : nullptr;
+                o.g2 = out_g2 ? out_g2 + at : nullptr; o.eps2 = out_eps2 ? out_eps2 + at : nullptr;
+            }
+            std::vector<ScanOut> outs{o};
+            const int rc = scan_core(genes, panel, first + at, len, idx_E ? idx_E + (size_t)q * n : nullptr,
+                                     idx_G ? idx_G + (size_t)q * n : nullptr, outs);
+            if (rc != CRM_OK) return rc;
+        }
+    }
+    return CRM_OK;
     });
 }
 

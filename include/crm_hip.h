@@ -198,19 +198,42 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
  *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X);
  *   FLAT_OPTIMUM   the reference stops its null fit with Brent's search at rtol = atol = 1e-6 on logit(delta)
- *                  (_cellregmap.py:351-352).  Where the likelihood changes by less than 3e-13 of its value over one such
- *                  tolerance, the search's last comparisons are decided by rounding noise and two faithful runs can stop
- *                  a whole tolerance apart.  The flag is raised where that happens AND matters: the library evaluates the
- *                  likelihood one tolerance to either side of where its fit stopped, and the score test there as well
- *                  (scale re-estimated, Q, F and the p-value recomputed); flagged are the variants whose likelihood is
- *                  flat in that sense and whose Q moves by more than 5e-7 (relative to max(Q, tr F)) or whose p moves by
- *                  more than 5e-6 (relative) -- half the tolerances statistics (1e-6) and p-values (1e-5) are held to.
- *                  Variants without the flag reproduce to those tolerances; with more than 8 covariate columns the
- *                  likelihood is not probed and the second condition alone decides. */
+ *                  (_cellregmap.py:351-352).  That search is a sequence of decisions on likelihood VALUES (the bracketing
+ *                  phase's and localmin's comparisons, the sign of a parabolic step shorter than the tolerance); two
+ *                  faithful implementations take the same path unless one of those decisions has a margin within the
+ *                  rounding noise of the likelihood, and where they part they stop up to a whole tolerance apart.  The
+ *                  library's own search (the same statements) records the smallest margin of the fit at rho* and bounds
+ *                  the noise of its objective to first order (magnitudes of the terms of the residual sum of squares,
+ *                  of the log-determinants and of n log s, times 2^-53); the flag is raised where the margin is within
+ *                  that bound AND it matters: the score test is re-evaluated with delta one tolerance to either side
+ *                  (scale re-estimated, Q, F and the p-value recomputed) and flagged are the variants whose Q moves by
+ *                  more than 5e-7 (relative to max(Q, tr F)) or whose p moves by more than 5e-6 (relative) -- half the
+ *                  tolerances statistics (1e-6) and p-values (1e-5) are held to.  Variants without the flag reproduce to
+ *                  those tolerances on every stream this has been measured on (what share of scans
+ *                  carries the flag, and how many of those actually differ);
+ *   RHO_TIE        the likelihoods of rho* and of another grid point differ by less than the same noise bound: which of
+ *                  the two the reference's strict `>` (_cellregmap.py:354-357) keeps is decided by rounding, and
+ *                  info["rho1"] with it (phenotypes without a kinship term tie on the whole grid: their p-values do not
+ *                  depend on rho). */
 #define CRM_MODEL_SATURATED 1
 #define CRM_MODEL_DELTA_AT_ZERO 2
 #define CRM_MODEL_G_IN_SPAN_W 4
 #define CRM_MODEL_FLAT_OPTIMUM 8
+#define CRM_MODEL_RHO_TIE 16
+
+/* nperm permutations of one scan in one call -- the reference's use of its permutation hooks (_cellregmap.py:398-413; its
+ * calibration test cellregmap/test/test_struct_lmm2.py:208-209 calls scan_interaction(G, idx_E=perm) in a loop).  The hooks
+ * enter only the test direction sqrt(dK) = diag(g[idx_G]) E0[idx_E]: the eleven null fits, rho*, the variance components and
+ * the rotations of the variants are the same for every permutation and are computed once per block of variants; each
+ * permutation then runs the score test proper (its contraction, Gram, eigenvalues, Davies).
+ *   idx_E, idx_G   nperm x n int (row q = the permutation of call q; either may be NULL = identity for every call)
+ *   out_pvalue     nperm x count; out_Q the same (may be NULL)
+ *   out_rho1 / out_e2 / out_g2 / out_eps2   count each (may be NULL): permutation-independent
+ * Row q of the outputs is bit for bit what crm_scan_interaction(gene, panel, first, count, idx_E + q n, idx_G + q n, ...)
+ * returns. */
+int crm_scan_interaction_permuted(crm_gene* gene, crm_panel* panel, long first, long count, int nperm, const int* idx_E,
+                                  const int* idx_G, double* out_pvalue, double* out_rho1, double* out_e2, double* out_g2,
+                                  double* out_eps2, double* out_Q);
 
 /* Several phenotypes against one panel in one pass ("genes" that share the background, W and E0):
  * everything that does not depend on y -- G'Q0(rho), the Khatri-Rao contraction per (variant, rho)
@@ -235,7 +258,8 @@ int crm_scan_association(crm_gene* gene, crm_panel* panel, long first, long coun
  * crm_lmm_fit: LMM(y, M, QS(rho), restricted).fit() for every grid point of the gene's background
  * (M = the gene's covariate matrix), keeping the first strictly larger lml.
  *   out_fit  6 doubles {rho, v0, v1, lml, delta, grid index}
- *   out_beta c doubles (may be NULL): the fixed effects of the kept fit (LMM.beta)
+ *   out_beta c doubles (may be NULL): the fixed effects of the kept fit (LMM.beta), as coefficients of the columns of M
+ *            the caller passed to crm_gene_create (columns the library orthogonalised are mapped back)
  * crm_cov_solve: out = (v0 Q0 S0 Q0' + v1 I)^-1 rhs for grid point rho_index of `bg` -- QSCov.solve
  * (_math.py:40-67); rhs and out are n x m row-major host arrays. */
 int crm_lmm_fit(crm_gene* gene, int restricted, double* out_fit, double* out_beta);

@@ -160,3 +160,45 @@ def test_lmm_fit_reproduces_the_documented_glimix_core_example():
     ref = LMM(y, X, economic_qs_linear(G))
     ref.fit(verbose=False)
     np.testing.assert_allclose(beta, ref.beta, rtol=1e-6)
+
+
+def test_lmm_fit_returns_beta_in_the_callers_basis_for_correlated_covariates():
+    """The C-ABI on its own (no Python host in between): crm_gene_create brings correlated covariate columns to mutually
+    orthogonal ones (W V, cyclic Jacobi); crm_lmm_fit must hand back the coefficients of the columns the CALLER passed --
+    glimix-core's LMM.beta (_cellregmap.py:186,232) -- not those of the rotated basis.  Both sides with the polished
+    optimum: the comparison is on the algebra, not on where a 1e-6 search stops."""
+    import ctypes
+
+    from cellregmap_amd import _engine, _lib
+    from oracle.lmm import LMM
+
+    c = make_cohort(9, 14, 3, 2, seed=41)
+    rng = np.random.default_rng(2)
+    n = c.y.size
+    base = rng.normal(size=(n, 1))
+    W = np.concatenate([np.ones((n, 1)), base + 0.05 * rng.normal(size=(n, 1)), 2.0 * base + 0.3 * rng.normal(size=(n, 1)),
+                        rng.normal(size=(n, 1)) + 3.0], axis=1)           # columns 1 and 2 correlate at 0.99
+    obj = _engine.CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib = _lib.load()
+    ctx = _engine._context(0)
+    _lib.check(lib.crm_set_null_fit_polish(ctx, 1))
+    try:
+        h = ctypes.c_void_p()
+        y, Wc, E0 = _lib.f64(c.y), _lib.f64(W), _lib.f64(c.E)
+        _lib.check(lib.crm_gene_create(obj._bg.handle, _lib.ptr(y), _lib.ptr(Wc), Wc.shape[1], _lib.ptr(E0), E0.shape[1],
+                                       ctypes.byref(h)))
+        try:
+            fit, beta = np.empty(6), np.empty(W.shape[1])
+            _lib.check(lib.crm_lmm_fit(h, 1, _lib.ptr(fit), _lib.ptr(beta)))
+        finally:
+            lib.crm_gene_destroy(h)
+    finally:
+        _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
+    ri = int(fit[5])
+    Q0, S0 = obj._bg.read(ri, n)
+    o = LMM(c.y, W, ((Q0,), S0), restricted=True)
+    o.fit(verbose=False, polish=True)
+    assert abs(fit[3] - o.lml()) <= 1e-10 * abs(o.lml())
+    np.testing.assert_allclose(beta, o.beta, rtol=1e-7, atol=1e-9 * np.abs(o.beta).max())
+    # (and it is not the rotated basis' vector: with these columns the two differ by far more than the tolerance)
+    assert np.abs(W @ beta - o.mean()).max() <= 1e-7 * np.abs(o.mean()).max()

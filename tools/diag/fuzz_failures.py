@@ -29,9 +29,9 @@ for idx, case in enumerate(fuzz_cases(count, seed=seed, wide_covariates=True, **
     except ValueError:
         continue
     flat = crm.scan_interaction_info(GenotypePanel(G, groups=None), **hooks)[1]["flat_optimum"]
-    rec = np.zeros(3 * G.shape[1])
+    rec = np.zeros(10 * G.shape[1])
     got = _lib.load().crm_test_null_fit_probe_read(_engine._context(0), _lib.ptr(rec), rec.size)
-    rec = rec.reshape(-1, 3) if got == rec.size else np.full((G.shape[1], 3), np.nan)
+    rec = rec.reshape(-1, 10) if got == rec.size else np.full((G.shape[1], 10), np.nan)
     for groups in (None, "auto"):
         pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
         same = info["rho1"] == oinfo["rho1"]
@@ -43,7 +43,7 @@ for idx, case in enumerate(fuzz_cases(count, seed=seed, wide_covariates=True, **
         if bad.any():
             j = int(np.argmax(np.where(bad, np.maximum(dq, dp), 0)))
             print("problem %d %s: cells %d contexts %d covariates %d variants %d mode %s hooks %s path %s: %d bad; worst variant %d: "
-                  "rho %g vs %g, dlml %.2e, dQ %.2e, dp %.2e, flat %d, delta %.3e vs %.3e; probes: margin %.2e Q move %.2e p move %.2e" %
+                  "rho %g vs %g, dlml %.2e, dQ %.2e, dp %.2e, flat %d, delta %.3e vs %.3e; probes: decision %.2e Q move %.2e p move %.2e" %
                   (idx, case[:8] if isinstance(case, tuple) else "", y.size, E.shape[1], W.shape[1], G.shape[1], case[6], sorted(hooks),
                    "dense" if groups is None else "auto", int(bad.sum()), j, info["rho1"][j], oinfo["rho1"][j], dl[j], dq[j], dp[j],
                    int(flat[j]), st["delta"][j], ost["delta"][j], rec[j, 0], rec[j, 1], rec[j, 2]), flush=True)
