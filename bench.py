@@ -450,7 +450,7 @@ def main():
         upload_full_panel()                    # (inside the end-to-end figure, after the constructor's own)
     ranks = [crm._bg.rank(i) for i in range(len(crm._rho1))]
     gene = crm._gene
-    cols = cohort.E.shape[1] + (Ls.us.shape[1] * Ls.hK.shape[1] if args.mode == "C" else cohort.hK.shape[1])
+    cols = cohort.E.shape[1] + (Ls.shape_us[1] * Ls.hK.shape[1] if args.mode == "C" else cohort.hK.shape[1])
     c_cov = cohort.W.shape[1]
 
     def scan(panel, first, count, pv, rho1, Q=None):
@@ -739,7 +739,7 @@ def main():
     f_alg = algorithmic_flops(n, ranks, rstar, k0, c_cov)
     kin = None
     if kin_groups:
-        k2_, m_ = (Ls.us.shape[1], Ls.hK.shape[1]) if args.mode == "C" else (0, 0)
+        k2_, m_ = (Ls.shape_us[1], Ls.hK.shape[1]) if args.mode == "C" else (0, 0)
         folded = lib.crm_background_kinship_folded(crm._bg.handle)
         pairs = k0 * (k0 + 1) // 2 if lib.crm_test_donor_pair_blocks(ctx) > 0 else 0
         kin = (cohort.E.shape[1], k2_, (kin_groups + 15) // 16 * 16, m_, (cohort.E.shape[1] + kin_groups * k2_) if folded else 0, pairs)

@@ -50,24 +50,46 @@ def _economic_svd(X):
 class HadamardHalves(Sequence):
     """The list ``[diag(us[:, i]) @ hK for i]`` that ``get_L_values`` returns, kept in factored form:
     indexing / iterating yields the same arrays as the reference's list, but ``CellRegMap`` hands the
-    two factors to the device and never materialises the n x (k*m) concatenation on the host."""
+    two factors to the device and never materialises the n x (k*m) concatenation on the host.
 
-    def __init__(self, us, hK, contexts=None):
-        self.us = np.ascontiguousarray(us, dtype=float)
+    ``us`` may be given as a callable: it is then computed on first use (``get_L_values`` with contexts of full column
+    rank: the device takes the contexts themselves, below, and the thin SVD -- a tenth of a second at 20 000 cells -- is
+    only ever needed by a caller that indexes the list)."""
+
+    def __init__(self, us, hK, contexts=None, columns=None):
+        self._us = None if callable(us) else np.ascontiguousarray(us, dtype=float)
+        self._make_us = us if callable(us) else None
         self.hK = np.ascontiguousarray(hK, dtype=float)
+        self._k2 = int(columns) if self._us is None else self._us.shape[1]
         # What the device is handed in the place of ``us``.  us = U S = E V with V orthogonal when E has full column rank,
         # so [diag(E[:, i]) hK for i] is the same covariance sum_i L_i L_i' = K o EE' in another basis of the same column
         # space (H -> H blockdiag(I, V (x) I): same Gram spectrum, same Q0 S0 Q0').  In that basis the per-donor sums of the
         # kinship-structure route against the kinship term's contexts are sums against the scan's own contexts -- symmetric
         # when E2 = E, the reference's default -- which halves their product (csrc/scan.hip: donor pairs).
-        self.device_us = self.us
+        self._device_us = None
         if contexts is not None:
             E = np.ascontiguousarray(contexts, dtype=float)
-            if E.shape == self.us.shape:
-                self.device_us = E
+            if E.shape == (self.hK.shape[0], self._k2):
+                self._device_us = E
+
+    @property
+    def us(self):
+        if self._us is None:
+            self._us = np.ascontiguousarray(self._make_us(), dtype=float)
+            self._make_us = None
+        return self._us
+
+    @property
+    def device_us(self):
+        return self._device_us if self._device_us is not None else self.us
+
+    @property
+    def shape_us(self):
+        """(n, columns of us) without forming it."""
+        return self.hK.shape[0], self._k2
 
     def __len__(self):
-        return self.us.shape[1]
+        return self._k2
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -78,11 +100,7 @@ class HadamardHalves(Sequence):
 _us_cache = OrderedDict()  # digest of E -> U * S (an eQTL run calls get_L_values with one E per gene)
 
 
-def get_L_values(hK, E):
-    """L_i = diag((U S)[:, i]) hK with U, S from the economic SVD of E
-    (_cellregmap.py:533-545); sum_i L_i L_i' = K o EE' (proof.md)."""
-    E = np.asarray(E, float)
-    key = _digest(E)
+def _cached_us(E, key):
     us = _us_cache.get(key)
     if us is None:
         U, S, _ = _economic_svd(E)
@@ -92,7 +110,24 @@ def get_L_values(hK, E):
             _us_cache.popitem(last=False)
     else:
         _us_cache.move_to_end(key)
-    return HadamardHalves(us, np.asarray(hK, float), contexts=E)
+    return us
+
+
+def get_L_values(hK, E):
+    """L_i = diag((U S)[:, i]) hK with U, S from the economic SVD of E
+    (_cellregmap.py:533-545); sum_i L_i L_i' = K o EE' (proof.md).
+
+    The SVD is taken when somebody looks at the list (``HadamardHalves``) -- or right away unless the contexts are
+    certainly of full column rank by the reference's rule (numpy_sugar.economic_svd keeps singular values >= sqrt(eps)):
+    certified here from the Gram matrix E'E, whose eigenvalues are the squared singular values to ~1e-12 of the largest,
+    by asking for a smallest one above 1e-8 of the largest AND above 1e-6 -- both far on the safe side of the rule."""
+    E = np.asarray(E, float)
+    key = _digest(E)
+    if E.ndim == 2 and E.shape[0] >= E.shape[1] >= 1 and key not in _us_cache:
+        lam = np.linalg.eigvalsh(E.T @ E)
+        if np.all(np.isfinite(lam)) and lam[0] > 1e-8 * lam[-1] and lam[0] > 1e-6:
+            return HadamardHalves(lambda: _cached_us(E, key), np.asarray(hK, float), contexts=E, columns=E.shape[1])
+    return HadamardHalves(_cached_us(E, key), np.asarray(hK, float), contexts=E)
 
 
 class _Background:
@@ -293,7 +328,7 @@ class BackgroundBuilder:
     def _begin(self, lib, E1c, B, nrho, flags, rel_tol, h, device):
         if isinstance(B, HadamardHalves):
             _lib.check(lib.crm_background_begin(_context(device), E1c.shape[0], _lib.ptr(E1c), E1c.shape[1], None,
-                                                B.us.shape[1] * B.hK.shape[1], _lib.ptr(B.device_us), B.us.shape[1],
+                                                B.shape_us[1] * B.hK.shape[1], _lib.ptr(B.device_us), B.shape_us[1],
                                                 _lib.ptr(B.hK), B.hK.shape[1], nrho, _lib.ptr(self.rho), _lib.ptr(flags),
                                                 float(rel_tol), ctypes.byref(h)))
         else:
@@ -686,7 +721,7 @@ class CellRegMap:
         assert self._y.shape[0] == self._E0.shape[0]
         assert self._y.shape[0] == self._E1.shape[0]
         if isinstance(Ls, HadamardHalves):
-            assert self._y.shape[0] == Ls.us.shape[0] == Ls.hK.shape[0]
+            assert self._y.shape[0] == Ls.shape_us[0] == Ls.hK.shape[0]
         else:
             for L in Ls:
                 assert self._y.shape[0] == L.shape[0]
@@ -972,14 +1007,20 @@ class CellRegMap:
 
     def scan_interaction_info(self, G, idx_E=None, idx_G=None):
         """The p-values together with chiscore's ``info`` of ``davies_pvalue(Q, F, True)`` (which the reference
-        computes at :435 and drops): ``(pvalues, {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate"})``.
+        computes at :435 and drops) and with how reproducible every variant's result is:
+        ``(pvalues, {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate", "flat_optimum",
+        "statistic_at_tolerance", "rho_tie", "bound_Q", "bound_p"})``.
+
+        ``bound_Q`` / ``bound_p``: how far the score statistic (relative to max(Q, tr F)) and the p-value (relative) of two
+        faithful runs of the reference's procedure may differ -- the reference stops its null fit at a tolerance of 1e-6 on
+        logit(delta), and where exactly a search stops within that tolerance is decided by rounding noise
+        (include/crm_hip.h: crm_scan_interaction_bounds).  ``flat_optimum`` = ``bound_p > 1e-5`` (about 2 % of scans),
+        ``statistic_at_tolerance`` = ``bound_Q > 1e-6`` (more than a third: Q moves by ~1e-6 per tolerance).
         ``model_flags`` (bits ``MODEL_SATURATED`` = 1, ``MODEL_DELTA_AT_ZERO`` = 2, ``MODEL_G_IN_SPAN_W`` = 4,
-        ``MODEL_FLAT_OPTIMUM`` = 8, ``MODEL_RHO_TIE`` = 16, see include/crm_hip.h) / ``degenerate`` mark the variants where the
-        reference's own result is decided by rounding noise (saturated model, null fit ending at delta = 0);
-        ``flat_optimum`` marks those where a decision of the reference's Brent search (1e-6 on logit delta) had a margin
-        within the rounding noise of the likelihood AND the stopping point matters beyond the tolerances (statistics 1e-6,
-        p-values 1e-5): two faithful runs may differ there; ``rho_tie`` those whose rho* is within that noise of another grid
-        point's likelihood (``info["rho1"]`` may differ between two faithful runs)."""
+        ``MODEL_FLAT_OPTIMUM`` = 8, ``MODEL_RHO_TIE`` = 16, ``MODEL_STATISTIC_AT_TOLERANCE`` = 32) / ``degenerate`` mark the
+        variants where the reference's own result is decided by rounding noise outright (saturated model, null fit ending at
+        delta = 0); ``rho_tie`` those whose rho* is within the likelihood's noise of another grid point's
+        (``info["rho1"]`` may differ between two faithful runs)."""
         lib = _lib.load()
         panel = self._panel(G)
         n, p = panel.shape
@@ -987,11 +1028,12 @@ class CellRegMap:
         iE, iG = _permutation(idx_E, n), _permutation(idx_G, n)
         pv, liu = np.empty(p), np.empty(p)
         ifault, flags = np.empty(p, np.int32), np.empty(p, np.int32)
-        _lib.check(lib.crm_scan_interaction_info(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
-                                                 _lib.ptr(ifault), _lib.ptr(liu), _lib.ptr(flags)))
+        bq, bp = np.empty(p), np.empty(p)
+        _lib.check(lib.crm_scan_interaction_bounds(gene, panel.handle, 0, p, _lib.ptr(iE), _lib.ptr(iG), _lib.ptr(pv),
+                                                   _lib.ptr(ifault), _lib.ptr(liu), _lib.ptr(flags), _lib.ptr(bq), _lib.ptr(bp)))
         return pv, {"liu_pval": liu, "Is_Converged": (ifault == 0).astype(int), "ifault": ifault,
                     "model_flags": flags, "degenerate": (flags & 3) != 0, "flat_optimum": (flags & 8) != 0,
-                    "rho_tie": (flags & 16) != 0}
+                    "rho_tie": (flags & 16) != 0, "statistic_at_tolerance": (flags & 32) != 0, "bound_Q": bq, "bound_p": bp}
 
     # -- association scans (_cellregmap.py:246-314) --------------------------------------------------
     def _scan_association(self, G, fast, return_stats=False, progress=None):

@@ -60,6 +60,7 @@ SIGNATURES = {
     "crm_panel_destroy": (None, [vp]),
     "crm_scan_interaction": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 13),
     "crm_scan_interaction_info": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 6),
+    "crm_scan_interaction_bounds": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long] + [vp] * 8),
     "crm_scan_interaction_permuted": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int] + [vp] * 8),
     "crm_scan_interaction_multi": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_long, ctypes.c_long] + [vp] * 8),
     "crm_scan_association": (ctypes.c_int, [vp, vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "crm_test_set_contraction": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
     "crm_test_set_shared_h": (ctypes.c_int, [vp, ctypes.c_int]),
     "crm_test_tail_launches": (ctypes.c_long, [vp]),
+    "crm_test_spectrum_tail_launches": (ctypes.c_long, [vp]),
     "crm_test_dense_repeats": (ctypes.c_long, [vp]),
     "crm_test_donor_pair_blocks": (ctypes.c_long, [vp]),
     "crm_test_tests_without_pair": (ctypes.c_long, [vp]),

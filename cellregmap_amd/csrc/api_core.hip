@@ -305,7 +305,7 @@ namespace {
 struct FormSlot { const char* name; int value; bool set; };
 FormSlot g_forms[] = {{"gram_staged", 0, false}, {"kr_no_tail", 0, false}, {"nullfit_per_wave", 0, false}, {"kin_fold", 0, false},
                       {"eigh_one_stage", 0, false}, {"nullfit_exact", 0, false}, {"donor_pairs", 0, false},
-                      {"pairs_without_kinship_term", 0, false}, {"flat_kappa_milli", 0, false}};
+                      {"pairs_without_kinship_term", 0, false}, {"flat_kappa_milli", 0, false}, {"chase_abort", 0, false}, {"nullfit_one_per_wave", 0, false}};
 std::mutex g_forms_mu;
 }  // namespace
 int form(const char* name, int otherwise) {

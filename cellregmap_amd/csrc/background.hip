@@ -664,14 +664,18 @@ static int background_seal(crm_background* bg) {
     // the mixing-matrix route amplifies rounding by sqrt(S_max / S_min): use it only for spectra
     // whose kept part is well conditioned
     bg->fast_T = bb->thin;
+    // (also kept: the largest entry of every spectrum -- scan.hip decides from it which fits have no kinship term to speak
+    // of; filled here, once, before the background is shared between genes and threads)
     std::vector<double> s0;
-    for (int i = 0; i < bg->nrho && bg->fast_T; i++) {
+    bg->s0_max.assign(bg->nrho, 0.0);
+    for (int i = 0; i < bg->nrho; i++) {
         const int r = bg->r[i];
         if (r == 0) continue;
         s0.resize(r);
         CRM_HIP(hipMemcpy(s0.data(), bg->S0[i].ptr, sizeof(double) * r, hipMemcpyDeviceToHost));  // (imported ones too)
         double smax = 0.0, smin = 1e300;
         for (double v : s0) { smax = std::max(smax, v); smin = std::min(smin, v); }
+        bg->s0_max[i] = smax;
         if (!(smax <= 1e6 * smin)) bg->fast_T = false;
     }
     const bool thin = bb->thin;

@@ -19,16 +19,7 @@ namespace crm {
 struct BrentTrace {
     double cmp;    // smallest |f(a) - f(b)| over the value comparisons that steered the search
     double sign;   // smallest distance (in units of f) of a sub-tolerance parabolic step from changing its sign
-    double edge;   // smallest perturbation of the objective values (units of f) that turns one of the search's tests on
-                   // POSITIONS round: the acceptance tests of a parabolic step, its distance from the ends of the
-                   // bracket (u - a < 2 tol: replaced by a step of +-tol) and the stopping test
-    double xunc;   // how far the stopping point moves per unit of perturbation of the objective values (x per unit of f),
-                   // to first order: the last parabolic steps are quotients of differences of nearly equal values
-    __device__ inline void reset() { cmp = INFINITY; sign = INFINITY; edge = INFINITY; xunc = 0.0; }
-    __device__ inline void position_test(double distance, double moves_per_unit) {
-        const double m = moves_per_unit > 0.0 ? fabs(distance) / moves_per_unit : INFINITY;
-        if (m < edge) edge = m;
-    }
+    __device__ inline void reset() { cmp = INFINITY; sign = INFINITY; }
     __device__ inline void compare(double fa, double fb, bool tie_by_construction) {
         // (two points beyond the clamp of the logistic are the SAME delta: their values are one memoised number on
         // either side of any comparison, here and in the reference -- an exact tie that no rounding can break)
@@ -92,14 +83,11 @@ __device__ __forceinline__ double brent_search(F& f, BrentTrace& tr, double& fx)
     double bx0 = bm, bf0 = fm;
     double bx1 = bx0, bx2 = bx0, bf1 = bf0, bf2 = bf0;
     bool k0 = c1, k1 = c1, k2 = c1;   // (clamp state of bx0, bx1, bx2)
-    double ux0 = 0.0, ux1 = 0.0, ux2 = 0.0;   // first-order movement of bx0, bx1, bx2 per unit of perturbation of the values
     double d = 0.0, e = 0.0;
     for (int it = 0; it < MAXITER_; it++) {
         const double m = 0.5 * (A_ + B_);
         const double tol = rtol * fabs(bx0) + atol;
         const double tol2 = 2.0 * tol;
-        // (the ends of the bracket are earlier points of the search: they move at most as the three kept ones do)
-        if constexpr (TRACK) tr.position_test(fabs(bx0 - m) - (tol2 - 0.5 * (B_ - A_)), 2.0 * fmax(ux0, fmax(ux1, ux2)));
         if (fabs(bx0 - m) <= tol2 - 0.5 * (B_ - A_)) break;
         double p = 0.0, q = 0.0, rr = 0.0;
         if (tol < fabs(e)) {
@@ -113,35 +101,17 @@ __device__ __forceinline__ double brent_search(F& f, BrentTrace& tr, double& fx)
             e = d;
         }
         double u;
-        double uu = ux0;   // movement of the next point per unit of perturbation (a step of +-tol or a golden one: bx0's)
-        // p = (x0-x2)^2 (f0-f1) - (x0-x1)^2 (f0-f2), q = 2 |(x0-x2)(f0-f1) - (x0-x1)(f0-f2)|: a change of the three values
-        // by eta each moves p by at most cp eta and q by at most cq eta
-        double cp = 0.0, cq = 0.0;
-        if constexpr (TRACK) {
-            const double w2 = fabs(bx0 - bx2), w1 = fabs(bx0 - bx1);
-            cp = 2.0 * (w2 * w2 + w1 * w1);
-            cq = 4.0 * (w2 + w1);
-            if (rr != 0.0) {   // (a parabola was formed this iteration: rr = the step before last, beyond tol)
-                tr.position_test(fabs(p) - fabs(0.5 * q * rr), cp + 0.5 * fabs(rr) * cq);
-                tr.position_test(p - q * (A_ - bx0), cp + fabs(A_ - bx0) * cq);
-                tr.position_test(q * (B_ - bx0) - p, cp + fabs(B_ - bx0) * cq);
-            }
-        }
         if (fabs(p) < fabs(0.5 * q * rr) && q * (A_ - bx0) < p && p < q * (B_ - bx0)) {
             d = p / q;
             u = bx0 + d;
             if constexpr (TRACK) {
-                // d = p / q moves by (cp + |d| cq) / q per unit of eta, on top of the movement of the three points themselves
-                const double du = fmax(ux0, fmax(ux1, ux2)) + (cp + fabs(d) * cq) / q;
-                tr.position_test((u - A_) - tol2, du);
-                tr.position_test((B_ - u) - tol2, du);
-                if (!((u - A_) < tol2 || (B_ - u) < tol2)) {
-                    if (fabs(d) < tol) {   // only the sign of the step survives below
-                        const double s = cp > 0.0 ? fabs(p) / cp : 0.0;
-                        if (s < tr.sign) tr.sign = s;
-                    } else {
-                        uu = du;
-                    }
+                if (!((u - A_) < tol2 || (B_ - u) < tol2) && fabs(d) < tol) {
+                    // only the sign of the step survives below: p = (x0-x2)^2 (f0-f1) - (x0-x1)^2 (f0-f2); a change of the
+                    // three values by eta each moves p by at most 2 eta ((x0-x2)^2 + (x0-x1)^2)
+                    const double w2 = bx0 - bx2, w1 = bx0 - bx1;
+                    const double cp = 2.0 * (w2 * w2 + w1 * w1);
+                    const double s = cp > 0.0 ? fabs(p) / cp : 0.0;
+                    if (s < tr.sign) tr.sign = s;
                 }
             }
             if ((u - A_) < tol2 || (B_ - u) < tol2) d = bx0 < m ? tol : -tol;
@@ -157,24 +127,23 @@ __device__ __forceinline__ double brent_search(F& f, BrentTrace& tr, double& fx)
         if constexpr (TRACK) tr.compare(fu, bf0, ku && k0);
         if (fu <= bf0) {
             if (u < bx0) B_ = bx0; else A_ = bx0;
-            bx2 = bx1; bf2 = bf1; k2 = k1; ux2 = ux1;
-            bx1 = bx0; bf1 = bf0; k1 = k0; ux1 = ux0;
-            bx0 = u; bf0 = fu; k0 = ku; ux0 = uu;
+            bx2 = bx1; bf2 = bf1; k2 = k1;
+            bx1 = bx0; bf1 = bf0; k1 = k0;
+            bx0 = u; bf0 = fu; k0 = ku;
         } else {
             if (u < bx0) A_ = u; else B_ = u;
             if constexpr (TRACK) { if (bx1 != bx0) tr.compare(fu, bf1, ku && k1); }
             if (fu <= bf1 || bx1 == bx0) {
-                bx2 = bx1; bf2 = bf1; k2 = k1; ux2 = ux1;
-                bx1 = u; bf1 = fu; k1 = ku; ux1 = uu;
+                bx2 = bx1; bf2 = bf1; k2 = k1;
+                bx1 = u; bf1 = fu; k1 = ku;
             } else {
                 if constexpr (TRACK) { if (bx2 != bx0 && bx2 != bx1) tr.compare(fu, bf2, ku && k2); }
                 if (fu <= bf2 || bx2 == bx0 || bx2 == bx1) {
-                    bx2 = u; bf2 = fu; k2 = ku; ux2 = uu;
+                    bx2 = u; bf2 = fu; k2 = ku;
                 }
             }
         }
     }
-    if constexpr (TRACK) tr.xunc = ux0;
     fx = bf0;
     return bx0;
 }

@@ -98,6 +98,7 @@ struct crm_ctx {
     // crm_ctx_destroy, or when another allocation would otherwise fail.
     long dense_repeats = 0;   // variants a collapsed scan repeated on the dense path (nearly collinear with W)
     long tail_launches = 0;   // blocks whose last columns took the 160-column-tile launch (crm_test_tail_launches)
+    long spectrum_tail_launches = 0;   // blocks whose last few columns of the spectrum went through the skinny one-pass kernel
     long donor_pair_blocks = 0;   // blocks whose per-donor sums came from the symmetric pair features (crm_test_donor_pair_blocks)
     long tests_without_pair = 0;  // (phenotype, variant) tests whose fit has no kinship term to speak of: no A~ formed for them
     // crm_scan_interaction_permuted: what the scan of a block computes BEFORE the permutation hooks enter -- the eleven

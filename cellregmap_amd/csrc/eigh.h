@@ -62,6 +62,8 @@ int eigh_rows_to_columns(crm_ctx* ctx, EighWork& w, const double* Qt);    // w.A
 // Same outputs as eigh_batched.  CRM_ERR_UNSUPPORTED with nothing computed when the problem is outside what the
 // two-stage form serves, CRM_ERR_BUSY-like CRM_ERR_HIP never: a chase that cannot keep its workgroups co-resident gives
 // up after a bounded wait and returns CRM_ERR_UNSUPPORTED too -- the caller then runs eigh_batched.
+// bound of every inter-workgroup wait of the two-stage solver, in ticks of the constant 100 MHz wall clock (wall_clock64): 2 s
+constexpr unsigned long long E2_WAIT_TICKS = 200000000ull;
 constexpr int E2_W = 64;       // panel width of stage 1 = half-bandwidth = reflector length of the chase = sweeps per group
 int eigh2_family(crm_ctx* ctx, EighWork& w, const double* wa, const double* wb, double* lam_host, double** Zt);
 bool eigh2_serves(long dim, int batch);

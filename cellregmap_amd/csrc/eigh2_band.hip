@@ -49,10 +49,11 @@ __device__ inline bool grid_barrier(unsigned* ctr, unsigned target, int* abort_f
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
         long spins = 0;
+        const unsigned long long t_start = wall_clock64();   // (100 MHz: the wait is bounded by wall clock, E2_WAIT_TICKS)
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 1023) == 0) {
-                if (spins > (1L << 25) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (wall_clock64() - t_start > E2_WAIT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;

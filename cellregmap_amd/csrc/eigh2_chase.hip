@@ -53,6 +53,7 @@ struct ChaseArgs {
     int* prog;   long prog_slab;    // [batch][dimp]
     int* abort_flag;
     long n, dimp;
+    unsigned long long wait_ticks;  // bound of a workgroup's wait for its predecessor, in ticks of the 100 MHz wall clock
 };
 
 // dlarfg on a wavefront: lane i holds x_i (zero beyond len); returns v_i (v_0 = 1), tau and beta on every lane
@@ -108,10 +109,14 @@ __global__ __launch_bounds__(256) void e2_chase_kernel(ChaseArgs a) {
             if (tid == 0) {
                 int ok = 1, val;
                 long spins = 0;
+                // (bounded by wall clock -- the constant 100 MHz counter: a whole chase takes 0.1 - 0.4 s, a workgroup whose
+                // predecessor is not resident -- a GPU shared with another process -- gives up after CHASE_WAIT_TICKS and the
+                // constructor falls back to the one-stage solver; a spin count would take close to a minute to get there)
+                const unsigned long long t_start = wall_clock64();
                 while ((val = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
                     __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 4095) == 0) {
-                        if (spins > (1L << 26) || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if ((++spins & 1023) == 0) {
+                        if (wall_clock64() - t_start > a.wait_ticks || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             ok = 0;
                             break;
@@ -297,6 +302,9 @@ int eigh2_chase(crm_ctx* ctx, EighWork& w) {
     a.abort_flag = w.sync.as<int>();
     a.prog = w.sync.as<int>() + 64;
     a.n = n; a.dimp = dimp;
+    // (test form "chase_abort": no patience at all -- the first workgroup that has to wait raises the flag, and the
+    // constructor must come out of it through the one-stage solver with the same spectra)
+    a.wait_ticks = form("chase_abort", 0) ? 0ull : E2_WAIT_TICKS;
     CRM_HIP(hipMemsetAsync(w.sync.ptr, 0, sizeof(int) * ((size_t)B * dimp + 64), st));
     CRM_HIP(hipMemsetAsync(w.Vbc.ptr, 0, sizeof(double) * (size_t)a.v_slab * B, st));
     CRM_HIP(hipMemsetAsync(w.taubc.ptr, 0, sizeof(double) * (size_t)a.tau_slab * B, st));

@@ -20,7 +20,8 @@ struct NullFitTrial {  // one (variant, rho) fit
     int use_g, nfev;
     double margin;  // brent_search.h: the smallest margin of the decisions that steered the search (units of the objective)
     double noise;   // first-order bound on the rounding noise of the objective at the optimum, in roundings (x 2^-53)
-    double xunc;    // brent_search.h: movement of the stopping point per unit of perturbation of the objective values
+    double curv;    // (f(x + tol) + f(x - tol)) / 2 - f(x) at the stopping point x, tol = 1e-6 |x| + 1e-6: what the objective gains
+                    // over one stopping tolerance (units of the objective)
 };
 
 struct NullFitOut {
@@ -32,7 +33,7 @@ struct NullFitOut {
     // rho_decision = min over the other grid points i of (lml(rho*) - lml(i)) / (2^-53 (noise(rho*) + noise(i))): how far
     // the choice of rho* itself is from another one (CRM_MODEL_RHO_TIE).  NaN where a kernel does not measure it.
     double decision, rho_decision;
-    double margin, noise, gap, xunc;   // (the raw figures of the winner: decision = margin / noise; xunc: brent_search.h)
+    double margin, noise, gap, curv;   // (the raw figures of the winner: decision = margin / noise; curv: NullFitTrial)
 };
 
 struct NullFitArgs {

@@ -25,22 +25,31 @@ constexpr double LOG2PI = 1.8378770664093453;
 constexpr double EPS_TINY = 2.220446049250313e-16;    // numpy_sugar.epsilon.tiny
 constexpr double EPS_SMALL = 1.4901161193847656e-08;  // numpy_sugar.epsilon.small
 
-// Sum over the 64 lanes, every lane ending with bitwise the same total -- the value of the xor butterfly
-//   for (off = 1, 2, 4, 8, 16, 32) v += shfl_xor(v, off)
-// to the last bit, without its six dependent trips through the LDS crossbar per value (ds_bpermute: at a short spectrum
-// the seven reductions of an evaluation cost more than the pass over the spectrum itself).  Levels 1 and 2 are the
-// butterfly's own pairs as DPP quad permutations.  After them the four lanes of a quad hold one number (a + b is
-// commutative, exactly), so level 4 may pair a lane with ANY lane of the neighbouring quad -- row_half_mirror (lane i <->
-// 7 - i) -- and level 8 with any lane of the other half of its row -- row_mirror (i <-> 15 - i): the same two addends
-// as the butterfly's in every lane.  The rows then hold r0 .. r3, and what the butterfly's last two levels leave in every
-// lane is (r0 + r1) + (r2 + r3) (rows 2, 3: the same sum with its addends swapped): four scalar reads and three additions.
-__device__ inline double dpp_pair(double v, const int ctrl_tag) {
+// Sums over the 64 lanes, every lane ending with bitwise the same totals -- the xor butterfly
+//   for (off = 32, 16, 8, 4, 2, 1) v += shfl_xor(v, off)
+// with the same pairings in the same order, so every bit is the butterfly's -- but level by level for all N values of a
+// pass at once (the seven sums of an evaluation: seven dependent chains of six trips through the LDS crossbar each cost
+// more than the pass over a short spectrum itself; side by side they wait six times, not forty-two) and without the
+// crossbar's address arithmetic where the hardware has the permutation built in: xor 16 / 8 / 4 as ds_swizzle bit masks,
+// xor 2 / 1 as DPP quad permutations.
+__device__ inline double lane_xor_swizzle(double v, const int level) {   // level 16, 8 or 4: lane ^ level inside 32 lanes
     int lo = __double2loint(v), hi = __double2hiint(v);
-    switch (ctrl_tag) {
-        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
-        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
-        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
-        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    switch (level) {
+        case 16: lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F); break;
+        case 8: lo = __builtin_amdgcn_ds_swizzle(lo, 0x201F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x201F); break;
+        default: lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double lane_xor_quad(double v, const int level) {      // level 2 or 1: DPP quad_perm [2,3,0,1] / [1,0,3,2]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (level == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
     }
     return __hiloint2double(hi, lo);
 }
@@ -50,18 +59,43 @@ __device__ inline double read_lane(double v, const int l) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ inline double wave_sum(double v) {
-#ifdef CRM_NF_BUTTERFLY_SUM   // (diagnostic builds, tools/diag/compare_builds.py: the round-5 form of this sum)
+// FROM = 32: all six levels (one fit per wavefront); FROM = 8: levels 8 .. 1 (a row of sixteen lanes)
+template <int N, int FROM>
+__device__ inline void butterfly_sums(double (&v)[N]) {
+#ifdef CRM_NF_BUTTERFLY_SUM   // (diagnostic builds, tools/diag/compare_builds.py: the round-5 form, value by value)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int off = FROM; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+    return;
 #endif
-    v += dpp_pair(v, 0);
-    v += dpp_pair(v, 1);
-    v += dpp_pair(v, 2);
-    v += dpp_pair(v, 3);
-    const double r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    double t[N];
+    if constexpr (FROM >= 32) {
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = __shfl_xor(v[i], 32, 64);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) t[i] = lane_xor_swizzle(v[i], 16);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = lane_xor_swizzle(v[i], 8);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = lane_xor_swizzle(v[i], 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = lane_xor_quad(v[i], 2);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = lane_xor_quad(v[i], 1);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
 }
 
 // 1 / D for D > 0 (normal range): hardware reciprocal + two Newton steps -- full double precision to
@@ -207,9 +241,18 @@ __device__ __noinline__ double objective_noise_bound(const double (&bb)[U], cons
 // hardware reciprocal + Newton steps and the mantissa-product log-determinant (NullFitArgs::exact).
 // TR: the search also leaves its trace behind (brent_search.h; NullFitTrial::margin / noise / xunc) -- the kernels of the calls
 // that ask for model flags.  The kernels without it are the scan's.
-template <int C, bool SH, bool EX, bool TR>
+// G: fits per wavefront.  1: the wavefront's 64 lanes stride the spectrum of one fit.  4 (LDS-shared kernel): every row of
+// sixteen lanes runs a fit of its own (four variants of one grid point), each lane standing for the four lanes
+// sub, sub + 16, sub + 32, sub + 48 of the one-fit form -- the same entries in the same order into four separate
+// accumulators, reduced with the same pairings -- so that every sum is the one-fit form's to the last bit, while the part
+// of an evaluation that every lane executes redundantly (logistic, Cholesky, solves, logarithms, the search's own
+// arithmetic: most of an evaluation at a short spectrum) is executed once for four fits.  Rows diverge as their searches
+// do; nothing crosses a row (DPP row operations and in-row shuffles only).
+template <int C, bool SH, bool EX, bool TR, int G = 1>
 __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, const int w, const int lane,
                                             const double* sW, const double* sy, const double* sS, const int sld) {
+    static_assert(G == 1 || (G == 4 && C == 1 && !EX), "four fits per wavefront: one covariate column, default arithmetic");
+    const int sub = G == 1 ? lane : (lane & 15);   // lane within its fit
     constexpr int P = C + 1;  // columns of X = [W, g]
     constexpr int U = C + 2;  // ... plus y
     constexpr int NP = U * (U + 1) / 2;
@@ -336,20 +379,97 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
             }
             if (!EX && weighted && (++trips & 127) == 0) lp.renorm();
         }
+        {
+            double red[NP + 1];
 #pragma unroll
-        for (int i = 0; i < NP; i++) S[i] = wave_sum(S[i]);
-        if (weighted) lsum = wave_sum(EX ? lsum : lp.log_value());
-        if (grad) {
+            for (int i = 0; i < NP; i++) red[i] = S[i];
+            red[NP] = weighted ? (EX ? lsum : lp.log_value()) : 0.0;
+            butterfly_sums<NP + 1, 32>(red);
 #pragma unroll
-            for (int i = 0; i < NP; i++) S2[i] = wave_sum(S2[i]);
-            lsum2 = wave_sum(lsum2);
+            for (int i = 0; i < NP; i++) S[i] = red[i];
+            if (weighted) lsum = red[NP];
         }
+        if (grad) {
+            double red[NP + 1];
+#pragma unroll
+            for (int i = 0; i < NP; i++) red[i] = S2[i];
+            red[NP] = lsum2;
+            butterfly_sums<NP + 1, 32>(red);
+#pragma unroll
+            for (int i = 0; i < NP; i++) S2[i] = red[i];
+            lsum2 = red[NP];
+        }
+    };
+
+    // The same pass for four fits per wavefront (G = 4): this lane is the one-fit form's lanes v = sub + 16 q, q = 0 .. 3.
+    // Lane v of that form takes the entries j = v + 64 k, k = 0 .. 4 T_v - 1 with T_v = ceil((r - v) / 256) trips of four
+    // (entries beyond r: loaded from r - 1 with weight 0 and D = 1, as there); here k runs in trips of four as well, all four
+    // q side by side, a trip being unmasked for every lane of the wavefront while 256 t + 255 < r.
+    auto spectrum_pass4 = [&](double delta, bool weighted, double (&S)[NP], double& lsum) {
+        double Sq[4][NP];
+        LogProduct lpq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < NP; i++) Sq[q][i] = 0.0;
+        const double omd = 1.0 - delta;
+        int trips[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) trips[q] = sub + 16 * q < r ? (r - (sub + 16 * q) + 255) / 256 : 0;
+        const int t_all = (r + 255) / 256;   // trips of the one-fit form's lane 0: no lane has more
+        for (int t = 0; t < t_all; t++) {
+            const bool full = 256 * t + 255 < r;   // (wave-uniform: every entry of the trip exists for every lane)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!full && t >= trips[q]) continue;
+                double tv[4][U], s0[4];
+                bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = sub + 16 * q + 64 * (4 * t + k);
+                    ok[k] = full || j < r;
+                    const int jj = ok[k] ? j : r - 1;
+#pragma unroll
+                    for (int i = 0; i < C; i++) tv[k][i] = SH ? sW[i * sld + jj] : R.tW[(long)i * R.ldW + jj];
+                    tv[k][C] = tg[jj];
+                    tv[k][C + 1] = SH ? sy[jj] : R.ty[jj];
+                    s0[k] = weighted ? (SH ? sS[jj] : R.S0[jj]) : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double wgt = ok[k] ? 1.0 : 0.0;
+                    if (weighted) {
+                        const double D = ok[k] ? omd * s0[k] + delta : 1.0;
+                        const double inv = fast_rcp(D);
+                        wgt = ok[k] ? inv : 0.0;
+                        lpq[q].mul(D);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const double tw = tv[k][u] * wgt;
+#pragma unroll
+                        for (int v = u; v < U; v++) Sq[q][pair_index(u, v, U)] += tw * tv[k][v];
+                    }
+                }
+                if (weighted && ((t + 1) & 127) == 0) lpq[q].renorm();
+            }
+        }
+        // the butterfly's levels 32 and 16 pair q with q ^ 2 and then q ^ 1 -- inside this lane; levels 8 .. 1 cross the row
+        double red[NP + 1];
+#pragma unroll
+        for (int i = 0; i < NP; i++) red[i] = (Sq[0][i] + Sq[2][i]) + (Sq[1][i] + Sq[3][i]);
+        red[NP] = weighted ? (lpq[0].log_value() + lpq[2].log_value()) + (lpq[1].log_value() + lpq[3].log_value()) : 0.0;
+        butterfly_sums<NP + 1, 8>(red);
+#pragma unroll
+        for (int i = 0; i < NP; i++) S[i] = red[i];
+        lsum = weighted ? red[NP] : 0.0;
     };
 
     double tt[NP];  // t_u' t_v (complement correction)
     {
         double dummy, dummy2, unused[NP];
-        spectrum_pass(1.0, false, tt, dummy, false, unused, dummy2);
+        if constexpr (G == 1) spectrum_pass(1.0, false, tt, dummy, false, unused, dummy2);
+        else spectrum_pass4(1.0, false, tt, dummy);
     }
 
     double cur_delta = 0.5, cur_scale = 1.0, cur_lml = -INFINITY;
@@ -386,8 +506,13 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
             }
             return value;
         };
-        double S[NP], lsum, unused[NP], unused2;
-        spectrum_pass(delta, true, S, lsum, false, unused, unused2);
+        double S[NP], lsum;
+        if constexpr (G == 1) {
+            double unused[NP], unused2;
+            spectrum_pass(delta, true, S, lsum, false, unused, unused2);
+        } else {
+            spectrum_pass4(delta, true, S, lsum);
+        }
         const double inv_d = 1.0 / delta;
         double K[NP];  // u' Kt^-1 v
 #pragma unroll
@@ -422,10 +547,10 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         const double s = fmax(rss / df, EPS_SMALL);
         // log(delta), log(L_jj), log(s): lane q takes argument q (the others 1), one pass of log, the results read back
         double larg = 1.0;
-        larg = lane == 0 ? delta : larg;
+        larg = sub == 0 ? delta : larg;
 #pragma unroll
-        for (int j = 0; j < P; j++) larg = lane == 1 + j ? piv[j] : larg;
-        larg = lane == P + 1 ? s : larg;
+        for (int j = 0; j < P; j++) larg = sub == 1 + j ? piv[j] : larg;
+        larg = sub == P + 1 ? s : larg;
 #ifdef CRM_NF_SERIAL_LOGS      // (diagnostic builds: the round-5 form, one logarithm after the other)
         const double log_delta = log(delta), log_s = log(s);
         double logdetH = 0.0;
@@ -434,10 +559,15 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         (void)larg;
 #else
         const double lres = log(larg);
-        const double log_delta = read_lane(lres, 0), log_s = read_lane(lres, P + 1);
+        // (one fit per wavefront: scalar reads; four: a shuffle inside the row of the fit)
+        auto from_sub = [&](int k) -> double {
+            if constexpr (G == 1) return read_lane(lres, k);
+            else return __shfl(lres, (lane & 48) + k, 64);
+        };
+        const double log_delta = from_sub(0), log_s = from_sub(P + 1);
         double logdetH = 0.0;
 #pragma unroll
-        for (int j = 0; j < P; j++) logdetH += 2.0 * read_lane(lres, 1 + j);
+        for (int j = 0; j < P; j++) logdetH += 2.0 * from_sub(1 + j);
 #endif
         const double logdetK = lsum + (n - (double)r) * log_delta;
         val = -0.5 * (df * LOG2PI + df + n * log_s + logdetK);
@@ -533,10 +663,10 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         // test hook (crm_test_null_fit_probe): the objective at one given x instead of the search, so that the
         // likelihood itself can be compared with the oracle's at the same point
         (void)f(a.probe_x);
-        if (lane == 0) {
+        if (sub == 0) {
             NullFitTrial t;
             t.lml = cur_lml; t.delta = cur_delta; t.scale = cur_scale; t.use_g = use_g ? 1 : 0; t.nfev = nfev;
-            t.margin = NAN; t.noise = NAN; t.xunc = NAN;
+            t.margin = NAN; t.noise = NAN; t.curv = NAN;
             a.trial[(long)b * a.nrho + w] = t;
         }
         return;
@@ -552,7 +682,7 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
         BrentTrace trace;
         double bf0;
         double bx0 = brent_search<TR>(objective, trace, bf0);
-        if (a.polish) {
+        if constexpr (G == 1) if (a.polish) {   // (the derivative's pass exists in the one-fit form only)
             // secant steps on the analytic derivative (oracle/lmm.py: _polish)
             const double xs = bx0, fs = bf0;
             double xa = xs, ga = g(xa);
@@ -576,9 +706,17 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
                 }
             }
         }
+        // (tracked kernels: the objective one stopping tolerance to either side of where the search stopped -- how flat the
+        // likelihood is there says how far rounding can move the last parabolic steps; include/crm_hip.h)
+        double f_up = NAN, f_dn = NAN;
+        if constexpr (TR) {
+            const double tolx = 1e-6 * fabs(bx0) + 1e-6;
+            f_up = f(bx0 + tolx);
+            f_dn = f(bx0 - tolx);
+        }
         want_noise = true;
-        (void)f(bx0);  // LMM.fit(): beta and scale refreshed at the optimum
-        if (lane == 0) {
+        const double f_stop = f(bx0);  // LMM.fit(): beta and scale refreshed at the optimum
+        if (sub == 0) {
             NullFitTrial t;
             t.lml = cur_lml;
             t.delta = cur_delta;
@@ -586,11 +724,12 @@ __device__ __forceinline__ void nullfit_fit(const NullFitArgs& a, const int b, c
             t.use_g = use_g ? 1 : 0;
             t.nfev = nfev;
             if constexpr (TR) {
-                t.margin = fmin(trace.cmp, fmin(trace.sign, trace.edge));
-                t.xunc = trace.xunc;
+                t.margin = fmin(trace.cmp, trace.sign);
+                t.curv = 0.5 * (f_up + f_dn) - f_stop;
                 t.noise = cur_noise;
             } else {
-                t.margin = NAN; t.xunc = NAN; t.noise = NAN;
+                (void)f_stop;
+                t.margin = NAN; t.curv = NAN; t.noise = NAN;
             }
             a.trial[(long)b * a.nrho + w] = t;
         }
@@ -602,7 +741,7 @@ template <int C, bool EX, bool TR>
 __attribute__((amdgpu_waves_per_eu(CRM_NULLFIT_WAVES, CRM_NULLFIT_WAVES)))
 #endif
 __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
-    nullfit_fit<C, false, EX, TR>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
+    nullfit_fit<C, false, EX, TR, 1>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, nullptr, nullptr, nullptr, 0);
 }
 
 // The same fits with the shared vectors of a grid point resident in LDS.  The one-wavefront-per-fit kernel above
@@ -612,9 +751,11 @@ __global__ __launch_bounds__(64) void nullfit_kernel(NullFitArgs a) {
 // (120 KB at r = 5000) and its wavefronts then draw variants of that grid point from a queue (an atomic counter per
 // grid point: likelihood-evaluation counts differ from variant to variant); when the queue is empty the workgroup moves
 // on to the next grid point with work left.  Only Q0'g still comes from L2.
-constexpr int NF_SHARED_WAVES = 12;
-template <int C, bool EX, bool TR>
-__global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(NullFitArgs a, int variants, int sld,
+// (wavefronts per workgroup = per CU: twelve with one fit each -- 168 registers; eight with four fits each -- 256 registers:
+// four sets of accumulators)
+constexpr int nf_shared_waves(int G) { return G == 1 ? 12 : 8; }
+template <int C, bool EX, bool TR, int G>
+__global__ __launch_bounds__(64 * nf_shared_waves(G)) void nullfit_shared_kernel(NullFitArgs a, int variants, int sld,
                                                                              unsigned* __restrict__ queue) {
     extern __shared__ double nf_sm[];   // Q0'W [C][sld], Q0'y [sld], S0 [sld]
     __shared__ int any_left;
@@ -632,7 +773,7 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
         __syncthreads();
         if (!any) continue;
         const NullFitRho R = a.rho[w];
-        for (int j = tid; j < R.r; j += 64 * NF_SHARED_WAVES) {
+        for (int j = tid; j < R.r; j += 64 * nf_shared_waves(G)) {
 #pragma unroll
             for (int i = 0; i < C; i++) sW[i * sld + j] = R.tW[(long)i * R.ldW + j];
             sy[j] = R.ty[j];
@@ -640,15 +781,20 @@ __global__ __launch_bounds__(64 * NF_SHARED_WAVES) void nullfit_shared_kernel(Nu
         }
         __syncthreads();
         for (;;) {
-            // One ticket per wavefront, wave-uniform by construction: every lane issues the atomic, lane 0 adds one and
+            // One ticket per wavefront, wave-uniform by construction: every lane issues the atomic, lane 0 adds G and
             // the others add zero, so lane 0's return value is this wavefront's own ticket whatever form the compiler
             // gives the 64 lane-atomics (one per lane, or one per wavefront with a prefix sum) -- no branch on the lane
-            // around the atomic, no reliance on a particular optimisation.  Tickets count variants in units of one.
-            const unsigned ticket = __hip_atomic_fetch_add(&queue[w], lane == 0 ? 1u : 0u, __ATOMIC_RELAXED,
+            // around the atomic, no reliance on a particular optimisation.  Tickets count variants: G per wavefront.
+            const unsigned ticket = __hip_atomic_fetch_add(&queue[w], lane == 0 ? (unsigned)G : 0u, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-            if (b >= (unsigned)variants) break;
-            nullfit_fit<C, true, EX, TR>(a, (int)b, w, lane, sW, sy, sS, sld);
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (b0 >= (unsigned)variants) break;
+            if constexpr (G == 1) {
+                nullfit_fit<C, true, EX, TR, 1>(a, (int)b0, w, lane, sW, sy, sS, sld);
+            } else {
+                const unsigned b = b0 + (unsigned)(lane >> 4);    // a variant per row of sixteen lanes
+                if (b < (unsigned)variants) nullfit_fit<C, true, EX, TR, G>(a, (int)b, w, lane, sW, sy, sS, sld);
+            }
         }
         __syncthreads();
     }
@@ -674,7 +820,7 @@ __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nr
     }
     NullFitOut o;
     o.use_g = trial[(long)b * nrho].use_g;
-    o.decision = NAN; o.rho_decision = NAN; o.margin = NAN; o.noise = NAN; o.gap = NAN; o.xunc = NAN;
+    o.decision = NAN; o.rho_decision = NAN; o.margin = NAN; o.noise = NAN; o.gap = NAN; o.curv = NAN;
     if (!fitted) {
         o.rho_index = -1;
         o.lml = NAN; o.delta = NAN; o.scale = NAN; o.v0 = NAN; o.v1 = NAN;
@@ -693,7 +839,7 @@ __global__ void select_rho_kernel(const NullFitTrial* __restrict__ trial, int nr
         constexpr double ROUNDING = 1.1102230246251565e-16;   // 2^-53
         o.margin = t.margin;
         o.noise = t.noise;
-        o.xunc = t.xunc;
+        o.curv = t.curv;
         o.decision = t.margin / (ROUNDING * t.noise);
         double gap = INFINITY, rdec = INFINITY;
         for (int i = 0; i < nrho; i++) {
@@ -738,20 +884,23 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         CRM_HIP(hipGetDevice(&dev));
         CRM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         CRM_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned) * CRM_MAX_RHO, st));
-        const void* fn = a.exact ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, true, false>)
-                                 : (a.track ? reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false, true>)
-                                            : reinterpret_cast<const void*>(&nullfit_shared_kernel<1, false, false>));
-        if (shared_lds > 60 * 1024)
-            CRM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));
-        if (a.exact)
-            hipLaunchKernelGGL((nullfit_shared_kernel<1, true, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
-                               variants, sld, queue);
-        else if (a.track)
-            hipLaunchKernelGGL((nullfit_shared_kernel<1, false, true>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
-                               variants, sld, queue);
-        else
-            hipLaunchKernelGGL((nullfit_shared_kernel<1, false, false>), dim3(cus), dim3(64 * NF_SHARED_WAVES), shared_lds, st, a,
-                               variants, sld, queue);
+        // four fits per wavefront (nullfit_fit: G) unless the derivative polish or the "exact" arithmetic is asked for, or
+        // the form "nullfit_one_per_wave" says so (the suite holds the two forms against each other: the same bits)
+        const bool four = !a.exact && !a.polish && !form("nullfit_one_per_wave", 0);
+#define CRM_NF_SHARED(EXv, TRv, Gv)                                                                                        \
+    do {                                                                                                                   \
+        const void* fn = reinterpret_cast<const void*>(&nullfit_shared_kernel<1, EXv, TRv, Gv>);                           \
+        if (shared_lds > 60 * 1024)                                                                                        \
+            CRM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared_lds));                 \
+        hipLaunchKernelGGL((nullfit_shared_kernel<1, EXv, TRv, Gv>), dim3(cus), dim3(64 * nf_shared_waves(Gv)), shared_lds, st, a, \
+                           variants, sld, queue);                                                                          \
+    } while (0)
+        if (a.exact) CRM_NF_SHARED(true, false, 1);
+        else if (a.track && four) CRM_NF_SHARED(false, true, 4);
+        else if (a.track) CRM_NF_SHARED(false, true, 1);
+        else if (four) CRM_NF_SHARED(false, false, 4);
+        else CRM_NF_SHARED(false, false, 1);
+#undef CRM_NF_SHARED
     } else if (a.c > CRM_MAX_COV_WIDE) {
         CRM_TRY(launch_nullfit_xwide(st, a, variants));
     } else if (force_wide || a.c > CRM_MAX_COV) {

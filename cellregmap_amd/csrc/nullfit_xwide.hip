@@ -321,8 +321,14 @@ __global__ __launch_bounds__(256) void nullfit_xwide_kernel(NullFitArgs a) {
     BrentTrace trace;
     double bf0;
     const double bx0 = a.track ? brent_search<true>(objective, trace, bf0) : brent_search<false>(objective, trace, bf0);
+    double f_up = NAN, f_dn = NAN;   // (as in nullfit.hip: the objective one stopping tolerance to either side)
+    if (a.track) {
+        const double tolx = 1e-6 * fabs(bx0) + 1e-6;
+        f_up = f(bx0 + tolx);
+        f_dn = f(bx0 - tolx);
+    }
     want_noise = true;
-    (void)f(bx0);
+    const double f_stop = f(bx0);
     if (tid == 0) {
         NullFitTrial t;
         t.lml = cur_lml;
@@ -330,8 +336,8 @@ __global__ __launch_bounds__(256) void nullfit_xwide_kernel(NullFitArgs a) {
         t.scale = cur_scale;
         t.use_g = use_g ? 1 : 0;
         t.nfev = nfev;
-        t.margin = a.track ? fmin(trace.cmp, fmin(trace.sign, trace.edge)) : NAN;
-        t.xunc = a.track ? trace.xunc : NAN;
+        t.margin = a.track ? fmin(trace.cmp, trace.sign) : NAN;
+        t.curv = a.track ? 0.5 * (f_up + f_dn) - f_stop : NAN;
         t.noise = a.track ? cur_noise : NAN;
         a.trial[(long)b * a.nrho + w] = t;
     }

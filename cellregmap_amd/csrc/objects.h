@@ -39,7 +39,7 @@ struct crm_background {
     bool q0_ready[crm::CRM_MAX_RHO] = {false};
     crm::DevBuf Ht;                      // H' (ldh x n_pad), kept once a lazy Q0 has been formed
     crm::DevBuf S0[crm::CRM_MAX_RHO];    // [ldq]
-    std::vector<double> s0_max;          // largest entry of every spectrum (host; filled by the first scan that asks)
+    std::vector<double> s0_max;          // largest entry of every spectrum (host; filled when the background is sealed / created from given spectra)
     // thin branch with a well-conditioned kept spectrum: Q0(rho) = H Mix(rho), H = [E1, B]
     bool fast_T = false;
     long ldh = 0, cols = 0;

@@ -102,6 +102,9 @@ int crm_background_create_qs(crm_ctx* ctx, long n, int nrho, const double* rho, 
         if (rc != CRM_OK) { crm_background_destroy(bg); return rc; }
         bg->q0_ready[i] = true;
     }
+    bg->s0_max.assign(nrho, 0.0);   // (as background_seal leaves it for the backgrounds the library decomposes itself)
+    for (int i = 0; i < nrho; i++)
+        for (int j = 0; j < r[i]; j++) bg->s0_max[i] = std::max(bg->s0_max[i], S0[i][j]);
     CRM_HIP(hipStreamSynchronize(ctx->stream));
     *out = bg;
     return CRM_OK;
@@ -1186,10 +1189,16 @@ __global__ void replay_rows_kernel(double* __restrict__ T, long blk, long ldT, c
     else rows[(size_t)b * ldT + j] = slab[j];
 }
 
-// CRM_MODEL_FLAT_OPTIMUM / CRM_MODEL_RHO_TIE: a decision of the null fit counts as open to rounding when its margin is
-// within this many times the first-order noise bound of the objective (in roundings of 2^-53; nullfit.hip).  Calibrated on
-// device-vs-oracle fuzz streams (tools/diag/flat_flag_study.py, profiles/r06_flat_flag_*): the bound is a sum of
-// magnitudes, rounding errors add like a random walk, so the factor is well below one.
+// How far apart may two faithful runs of the reference's null fit stop (include/crm_hip.h: crm_scan_interaction_bounds)?
+// Measured on device-vs-oracle streams of 71 000 scans (tools/diag/flat_flag_study.py, profiles/r06_flat_flag_*): the
+// distance of the two stopping points in units of the search's tolerance, times the relative gain of the objective over one
+// tolerance at the stopping point (NullFitTrial::curv / |lml|), never exceeded 2.2e-13 (99.9 %: 1.2e-13, 99 %: 6e-14,
+// median 4e-19): the flatter the likelihood, the further rounding noise moves the last parabolic steps -- up to one whole
+// tolerance, where the search's last comparison f(x +- tol) <= f(x) itself falls the other way.
+constexpr double STOP_SHIFT_C = 2.5e-13;
+// ... and a decision of the search counts as open to rounding outright (shift = one tolerance) when its margin is within
+// this many times the first-order noise bound of the objective (nullfit.hip: objective_noise_bound); the choice of rho*
+// likewise (CRM_MODEL_RHO_TIE)
 constexpr double FLAT_KAPPA = 1.0;
 constexpr double RHO_KAPPA = 1.0;
 constexpr int FLAT_REC = 10;   // doubles per variant of the diagnostics record (crm_test_null_fit_probe_read)
@@ -1199,6 +1208,8 @@ struct ScanOut {  // per-gene output bases (host), each `count` long (lambda: co
     int* ifault = nullptr;   // Davies' fault code per variant (0 ok; 1, 2, 4 as AS 155; < 0: no usable eigenvalues)
     double* liu = nullptr;   // the modified-Liu p-value (chiscore's info["liu_pval"])
     int* flags = nullptr;    // CRM_MODEL_* bits per variant (include/crm_hip.h)
+    double* bound_Q = nullptr;   // crm_scan_interaction_bounds: how far Q / p of two faithful runs may differ (relative)
+    double* bound_p = nullptr;
 };
 
 // Variants per block of a scan of `count` variants.  Automatic: as many as keep the A~ buffer (block x k0 x ldq doubles)
@@ -1365,16 +1376,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
     // magnitude, while its product is most of a step.  Such tests get no (variant, rho*) pair: their Gram reads rows of zeros
     // (AssembleArgs::A_none).  rho* of such a fit is decided by rounding (the likelihood is flat in rho), so over many
     // phenotypes these are also the fits that would scatter a variant's pairs over the whole grid.
-    if ((int)bg->s0_max.size() != nrho) {
-        bg->s0_max.assign(nrho, 0.0);
-        std::vector<double> spec;
-        for (int i = 0; i < nrho; i++) {
-            if (bg->r[i] <= 0) continue;
-            spec.resize(bg->r[i]);
-            CRM_HIP(hipMemcpyAsync(spec.data(), bg->S0[i].ptr, sizeof(double) * bg->r[i], hipMemcpyDeviceToHost, st));
-            CRM_HIP(hipStreamSynchronize(st));
-            bg->s0_max[i] = *std::max_element(spec.begin(), spec.end());
-        }
+    if ((int)bg->s0_max.size() != nrho) {   // (filled when the background was sealed / created)
+        set_error("scan: the background was not sealed");
+        return CRM_ERR_INTERNAL;
     }
     const bool skip_pairs = form("pairs_without_kinship_term", 1) == 0 ? false : true;
     auto no_kinship_term = [&](const NullFitOut& f) {
@@ -2340,7 +2344,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
         if (!spectrum_tails.empty()) {
             CRM_HIP(hipMemcpyAsync(d_probs + nz, spectrum_tails.data(), sizeof(GemmProblem) * spectrum_tails.size(), hipMemcpyHostToDevice, st));
             CRM_TRY(launch_skinny_tn(st, d_probs + nz, (int)spectrum_tails.size(), max_m, kdim));
-            ctx->tail_launches++;
+            ctx->spectrum_tail_launches++;
             CRM_HIP(hipStreamSynchronize(st));   // (the records live on this stack frame)
         }
         // 7. elementwise products for the side contractions
@@ -2461,20 +2465,32 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                         // p ~ 1, leaves Q itself ill-conditioned)
                         double trace = 0.0;
                         for (int j = 0; j < k0; j++) trace += lam0[(size_t)b * k0 + j];
-                        const bool q_moves = std::fabs(q1[b] - q0[b]) > 5e-7 * std::max(std::fabs(q0[b]), trace);
-                        const bool p_moves = std::fabs(p1[b] - p0[b]) > 5e-6 * std::fabs(p0[b]);
-                        // ... and it only matters where rounding could have sent the search another way (first half, above)
-                        const double dec = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
-                        const bool undecided = !(dec > flat_kappa);
+                        const double mq = std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace);
+                        const double mp = std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]);
                         const NullFitOut& fo = h_fit[(size_t)gi * BLK + b];
                         double* rec = &probe_rec[(size_t)b * FLAT_REC];
-                        rec[0] = dec;
-                        rec[1] = std::max(rec[1], std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace));
-                        rec[2] = std::max(rec[2], std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]));
+                        // (NaN -- a probe that could not be evaluated -- must survive the maximum)
+                        rec[1] = (mq == mq && rec[1] == rec[1]) ? std::max(rec[1], mq) : NAN;
+                        rec[2] = (mp == mp && rec[2] == rec[2]) ? std::max(rec[2], mp) : NAN;
+                        rec[0] = flat_obj.empty() ? -1.0 : flat_obj[(size_t)gi * BLK + sb0 + b];
                         rec[3] = fo.margin; rec[4] = fo.noise; rec[5] = fo.rho_decision; rec[6] = fo.gap; rec[7] = fo.lml;
-                        rec[8] = fo.xunc; rec[9] = fo.delta;
-                        if ((q_moves || p_moves || !(q1[b] == q1[b]) || !(p1[b] == p1[b])) && undecided) flat[b] = 1;
+                        rec[8] = fo.curv; rec[9] = fo.delta;
                     }
+                }
+                // the bounds: (movement of Q / p over one tolerance) x (the largest distance, in tolerances, at which two
+                // faithful searches stop: STOP_SHIFT_C / relative gain of the objective over one tolerance, at most one --
+                // and one outright where a decision of the search itself was within the objective's noise bound)
+                for (int b = 0; b < nb; b++) {
+                    const NullFitOut& fo = h_fit[(size_t)gi * BLK + b];
+                    const double* rec = &probe_rec[(size_t)b * FLAT_REC];
+                    const double gain = fo.curv / std::fabs(fo.lml);
+                    double shift = (gain > 0.0 && gain == gain) ? std::min(1.0, STOP_SHIFT_C / gain) : 1.0;
+                    if (!(rec[0] > flat_kappa)) shift = 1.0;
+                    const double bq = rec[1] * shift, bp = rec[2] * shift;
+                    if (o.bound_Q) o.bound_Q[done + b] = bq;
+                    if (o.bound_p) o.bound_p[done + b] = bp;
+                    if (!(bp <= 1e-5)) flat[b] |= 1;
+                    if (!(bq <= 1e-6)) flat[b] |= 2;
                 }
             }
             if (o.flags && ng == 1) {   // (diagnostics: what the probes measured, crm_test_null_fit_probe_read)
@@ -2491,7 +2507,8 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                     int fl = saturated ? CRM_MODEL_SATURATED : 0;
                     if (!(f.delta > 1e-8)) fl |= CRM_MODEL_DELTA_AT_ZERO;
                     if (!f.use_g) fl |= CRM_MODEL_G_IN_SPAN_W;
-                    if (!flat.empty() && flat[b]) fl |= CRM_MODEL_FLAT_OPTIMUM;
+                    if (!flat.empty() && (flat[b] & 1)) fl |= CRM_MODEL_FLAT_OPTIMUM;
+                    if (!flat.empty() && (flat[b] & 2)) fl |= CRM_MODEL_STATISTIC_AT_TOLERANCE;
                     if (f.rho_decision == f.rho_decision && !(f.rho_decision > rho_kappa)) fl |= CRM_MODEL_RHO_TIE;
                     o.flags[done + b] = fl;
                 }
@@ -2632,7 +2649,26 @@ int crm_scan_interaction_permuted(crm_gene* gene, crm_panel* panel, long first, 
     });
 }
 
+int crm_scan_interaction_bounds(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E, const int* idx_G,
+                                double* out_pvalue, int* out_ifault, double* out_liu_pvalue, int* out_model_flags,
+                                double* out_bound_Q, double* out_bound_p) {
+    return crm::guarded_on("crm_scan_interaction_bounds", gene ? gene->ctx : nullptr, [&]() -> int {
+    if (!gene || !panel || !out_model_flags) return CRM_ERR_ARG;
+    std::vector<crm_gene*> genes{gene};
+    ScanOut o{out_pvalue, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    o.ifault = out_ifault;
+    o.liu = out_liu_pvalue;
+    o.flags = out_model_flags;
+    o.bound_Q = out_bound_Q;
+    o.bound_p = out_bound_p;
+    std::vector<ScanOut> outs{o};
+    return scan_core(genes, panel, first, count, idx_E, idx_G, outs);
+    });
+}
+
 long crm_test_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->tail_launches : -1; }
+
+long crm_test_spectrum_tail_launches(const crm_ctx* ctx) { return ctx ? ctx->spectrum_tail_launches : -1; }
 
 long crm_test_dense_repeats(const crm_ctx* ctx) { return ctx ? ctx->dense_repeats : -1; }
 

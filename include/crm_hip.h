@@ -197,29 +197,40 @@ int crm_scan_interaction_info(crm_gene* gene, crm_panel* panel, long first, long
  *   DELTA_AT_ZERO  the null fit at rho* ended at delta <= 1e-8: the likelihood was flat or still rising towards delta = 0
  *                  (no residual variance left), where the same noise / delta terms decide the reported optimum;
  *   G_IN_SPAN_W    the variant lies in the span of the covariates: the fit dropped it (glimix-core's SVD-reduced X);
- *   FLAT_OPTIMUM   the reference stops its null fit with Brent's search at rtol = atol = 1e-6 on logit(delta)
- *                  (_cellregmap.py:351-352).  That search is a sequence of decisions on likelihood VALUES (the bracketing
- *                  phase's and localmin's comparisons, the sign of a parabolic step shorter than the tolerance); two
- *                  faithful implementations take the same path unless one of those decisions has a margin within the
- *                  rounding noise of the likelihood, and where they part they stop up to a whole tolerance apart.  The
- *                  library's own search (the same statements) records the smallest margin of the fit at rho* and bounds
- *                  the noise of its objective to first order (magnitudes of the terms of the residual sum of squares,
- *                  of the log-determinants and of n log s, times 2^-53); the flag is raised where the margin is within
- *                  that bound AND it matters: the score test is re-evaluated with delta one tolerance to either side
- *                  (scale re-estimated, Q, F and the p-value recomputed) and flagged are the variants whose Q moves by
- *                  more than 5e-7 (relative to max(Q, tr F)) or whose p moves by more than 5e-6 (relative) -- half the
- *                  tolerances statistics (1e-6) and p-values (1e-5) are held to.  Variants without the flag reproduce to
- *                  those tolerances on every stream this has been measured on (what share of scans
- *                  carries the flag, and how many of those actually differ);
- *   RHO_TIE        the likelihoods of rho* and of another grid point differ by less than the same noise bound: which of
- *                  the two the reference's strict `>` (_cellregmap.py:354-357) keeps is decided by rounding, and
- *                  info["rho1"] with it (phenotypes without a kinship term tie on the whole grid: their p-values do not
- *                  depend on rho). */
+ *   FLAT_OPTIMUM   the P-VALUE of this variant may differ by more than 1e-5 (relative) between two faithful runs of the
+ *                  reference's procedure: bound_p of crm_scan_interaction_bounds (below) exceeds the tolerance p-values are
+ *                  held to.  1.6 - 2.0 % of the scans of the measured streams; none of the others was found beyond;
+ *   STATISTIC_AT_TOLERANCE   the same for the score statistic Q and its tolerance of 1e-6 (bound_Q > 1e-6).  The reference
+ *                  stops its search at rtol = atol = 1e-6 on logit(delta), so Q -- which moves by ~1e-6 of its value per
+ *                  tolerance -- is reproducible to about that and no better on more than a third of all scans (36 - 38 %);
+ *   RHO_TIE        the likelihoods of rho* and of another grid point differ by less than the first-order bound on the
+ *                  rounding noise of the objective (nullfit.hip): which of the two the reference's strict `>`
+ *                  (_cellregmap.py:354-357) keeps is decided by rounding, and info["rho1"] with it (phenotypes without a
+ *                  kinship term tie on the whole grid: their p-values do not depend on rho). */
 #define CRM_MODEL_SATURATED 1
 #define CRM_MODEL_DELTA_AT_ZERO 2
 #define CRM_MODEL_G_IN_SPAN_W 4
 #define CRM_MODEL_FLAT_OPTIMUM 8
 #define CRM_MODEL_RHO_TIE 16
+#define CRM_MODEL_STATISTIC_AT_TOLERANCE 32
+
+/* How reproducible is each variant's result?  The reference stops its null fit with Brent's search at rtol = atol = 1e-6
+ * on x = logit(delta) (_cellregmap.py:351-352, glimix-core LMM.fit).  Two faithful implementations (this library and the
+ * reference's numpy; two BLAS builds under the reference) evaluate the same likelihood to ~1e-15 of its value, and that is
+ * enough to move where the search stops: the last parabolic steps are quotients of differences of nearly equal values, and
+ * the final comparisons f(x +- tol) <= f(x) can fall either way -- by up to one whole tolerance.  The library measures, per
+ * variant, (i) how far Q and p move when delta moves by one tolerance (the score test re-evaluated to either side: scale
+ * re-estimated, Q, F, eigenvalues and p recomputed) and (ii) how flat the likelihood is at the stopping point (its gain over
+ * one tolerance, from the search's own kernel), and returns
+ *   out_bound_Q    bound on |Q - Q'| / max(Q, tr F) between two faithful runs  = (i) x min(1, 2.5e-13 / (ii))
+ *   out_bound_p    the same for |p - p'| / p
+ *   out_model_flags   CRM_MODEL_* bits (above); FLAT_OPTIMUM = bound_p > 1e-5, STATISTIC_AT_TOLERANCE = bound_Q > 1e-6.
+ * On the device-vs-oracle streams the constant was read from (71 000 scans) no scan exceeded its
+ * bounds (p: plus the ~1e-6 that two roundings of Davies' integration differ by); held-out streams: profiles/r06_*.
+ * out_ifault / out_liu_pvalue: as crm_scan_interaction_info.  Every output but out_model_flags may be NULL. */
+int crm_scan_interaction_bounds(crm_gene* gene, crm_panel* panel, long first, long count, const int* idx_E, const int* idx_G,
+                                double* out_pvalue, int* out_ifault, double* out_liu_pvalue, int* out_model_flags,
+                                double* out_bound_Q, double* out_bound_p);
 
 /* nperm permutations of one scan in one call -- the reference's use of its permutation hooks (_cellregmap.py:398-413; its
  * calibration test cellregmap/test/test_struct_lmm2.py:208-209 calls scan_interaction(G, idx_E=perm) in a loop).  The hooks

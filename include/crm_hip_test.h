@@ -23,6 +23,12 @@ extern "C" {
  *                         (default 1: where the kinship term's contexts are the scan's own and a cost model says so)
  *   "pairs_without_kinship_term" 0   form the rotated test direction for every test, also where the fit has no kinship
  *                         term to speak of (default: not formed where (v0 / v1) max S0 <= 1e-10)
+ *   "nullfit_one_per_wave" 1   the LDS-shared null-fit kernel with one fit per wavefront (default: four, one per row of sixteen
+ *                         lanes, nullfit.hip) -- the two forms give the same bits
+ *   "chase_abort" 1       the bulge chase of the two-stage eigen-solver gives up at its first inter-workgroup wait (what a
+ *                         device shared with another process does to it after 2 s): the constructor must come out through
+ *                         the one-stage solver with the same spectra
+ *   "flat_kappa_milli" v  factor (in thousandths) on the noise bound of CRM_MODEL_FLAT_OPTIMUM / CRM_MODEL_RHO_TIE (study tool)
  * These replace the environment switches of earlier versions; the GPU suite flips every one of them. */
 int crm_test_set_form(const char* name, int value, int reset);
 /* Contraction kernel variant for subsequent launches on this context: tile_width 0 = chosen per
@@ -60,6 +66,9 @@ int crm_test_set_kinship_route(crm_ctx* ctx, int on);
 /* Number of Khatri-Rao blocks of this context's scans whose last columns went through the 160-column-tile launch
  * (scan.hip: spectra with r mod 128 <= 32); tests use it to know which form they exercised. */
 long crm_test_tail_launches(const crm_ctx* ctx);
+/* ... and whose last few columns of the spectrum (r mod 128 <= 16 on the kinship-structure route) went through the skinny
+ * one-pass kernel instead of another 128-column tile of the product with the mixing matrix. */
+long crm_test_spectrum_tail_launches(const crm_ctx* ctx);
 /* Variants that scans on the donor-collapsed path repeated on the dense path because they were nearly collinear with the
  * covariates (scan.hip: COLLINEAR_TAU; the dense path orthogonalises the block against W in the cell axis). */
 long crm_test_dense_repeats(const crm_ctx* ctx);

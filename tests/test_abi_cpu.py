@@ -142,7 +142,7 @@ def test_every_entry_point_runs_behind_the_exception_guard():
     excepted), each `void crm_*_destroy` inside try / catch (...)."""
     csrc = os.path.join(ROOT, "cellregmap_amd", "csrc")
     text = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))
-    exempt = {"crm_last_error", "crm_version", "crm_test_tail_launches", "crm_test_dense_repeats", "crm_test_sync_fallbacks",
+    exempt = {"crm_last_error", "crm_version", "crm_test_tail_launches", "crm_test_spectrum_tail_launches", "crm_test_dense_repeats", "crm_test_sync_fallbacks",
               "crm_test_donor_pair_blocks", "crm_test_tests_without_pair",
               "crm_test_overruns",
               "crm_background_kinship_groups", "crm_background_kinship_folded"}

@@ -124,3 +124,27 @@ def test_constructor_forms_agree_at_config2(kernel_form):
     finally:
         _lib.check(lib.crm_set_null_fit_polish(ctx, 0))
         _engine._bg_cache.clear()
+
+
+def test_a_chase_that_gives_up_falls_back_to_the_one_stage_solver(kernel_form):
+    """The two-stage solver's bulge chase runs its sweeps as a pipeline of co-resident workgroups; on a device shared with
+    another process a workgroup's predecessor may never be scheduled, and the wait -- bounded by wall clock (2 s,
+    eigh.h: E2_WAIT_TICKS) -- raises the abort flag.  The form "chase_abort" leaves the chase no patience at all: the
+    constructor must notice, fall back to the one-stage solver and deliver the spectra the one-stage form delivers."""
+    from cellregmap_amd import CellRegMap, get_L_values
+    from cellregmap_amd.synth import make_config
+
+    c = make_config("cfg2", n_variants=8)
+    Ls = get_L_values(c.hK, c.E)
+    got = {}
+    for form in ("eigh_one_stage", "chase_abort"):
+        _engine._bg_cache.clear()
+        kernel_form(form, 1)
+        crm = CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
+        got[form] = ([crm._bg.rank(i) for i in range(11)], crm._bg.read(4, c.y.size)[1], crm._bg.read(9, c.y.size)[1])
+        kernel_form(form, 0, reset=True)
+        del crm
+    _engine._bg_cache.clear()
+    a, b = got["eigh_one_stage"], got["chase_abort"]
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])    # (the same solver ran: the same bits)

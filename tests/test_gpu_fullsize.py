@@ -9,6 +9,9 @@ from numpy.testing import assert_allclose
 pytestmark = pytest.mark.gpu
 
 P_RTOL, P_ATOL = 1e-5, 1e-13
+# delta itself is only defined to the search's tolerance: tol = 1e-6 (|x| + 1) on x = logit(delta), d(delta) / delta = (1 - delta) dx;
+# two tolerances at |x| <= 9
+DELTA_RTOL = 2 * 1e-6 * (9 + 1)
 
 
 def _oracle_on_device_decomposition(crm, y, E, W, Ls, only=None):
@@ -59,22 +62,29 @@ def _oracle_scan_allowing_ties(o, G, rho_device):
     return opv, oinfo
 
 
-def _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, k0, q_rtol=1e-6, delta_rtol=2e-5, p_rtol=P_RTOL):
+def _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, k0, q_rtol=1e-6, delta_rtol=DELTA_RTOL, p_rtol=P_RTOL, bounds=None):
     """rho*, delta, lml, Q, F, the eigenvalues of F and p on the picked variants (north-star tolerances: statistics
-    1e-6, p-values 1e-5)."""
+    1e-6, p-values 1e-5).  ``bounds = (bound_Q, bound_p)`` of the device's ``scan_interaction_info`` at the picked variants:
+    a variant whose own bound is wider than a tolerance is held to the bound (tests/parity_bounds.py)."""
+    n_pick = len(pick)
+    bq = np.zeros(n_pick) if bounds is None else np.asarray(bounds[0])
+    bp = np.zeros(n_pick) if bounds is None else np.asarray(bounds[1])
+    q_allow = np.maximum(q_rtol, 1.001 * bq)
+    p_allow = np.maximum(p_rtol, 1.001 * bp + (2e-6 if bounds is not None else 0.0))
     assert_allclose(info["rho1"][pick], oinfo["rho1"], atol=1e-12)
     assert_allclose(st["lml"][pick], ost["lml"], rtol=1e-10)
     assert_allclose(st["delta"][pick], ost["delta"], rtol=delta_rtol)
-    assert_allclose(st["Q"][pick], ost["Q"], rtol=q_rtol)
+    trF = np.array([np.trace(F) for F in ost["F"]])
+    assert np.all(np.abs(st["Q"][pick] - ost["Q"]) <= q_allow * np.maximum(np.abs(ost["Q"]), trF)), np.c_[st["Q"][pick], ost["Q"], q_allow]
     total = oinfo["e2"] + oinfo["g2"] + oinfo["eps2"]
     for k in ("e2", "g2", "eps2"):
-        assert np.all(np.abs(info[k][pick] - oinfo[k]) <= 1e-5 * oinfo[k] + 1e-6 * total), k
+        assert np.all(np.abs(info[k][pick] - oinfo[k]) <= np.maximum(1e-5, q_allow) * oinfo[k] + 1e-6 * total), k
     for row, j in enumerate(pick):
         F = ost["F"][row]
-        assert np.abs(st["F"][j] - F).max() <= q_rtol * np.abs(F).max(), j
+        assert np.abs(st["F"][j] - F).max() <= q_allow[row] * np.abs(F).max(), j
         lam = np.linalg.eigvalsh(F)
-        assert np.abs(st["lambda"][j] - lam).max() <= q_rtol * np.abs(lam).max(), j
-    assert np.all(np.abs(pv[pick] - opv) <= p_rtol * opv + P_ATOL), np.c_[pv[pick], opv]
+        assert np.abs(st["lambda"][j] - lam).max() <= q_allow[row] * np.abs(lam).max(), j
+    assert np.all(np.abs(pv[pick] - opv) <= p_allow * opv + P_ATOL), np.c_[pv[pick], opv, p_allow]
 
 
 ROUTES = ["kinship", "direct"]
@@ -138,10 +148,14 @@ def test_config2_against_the_oracles_own_decompositions(cfg2):
     o = OracleCellRegMap(c.y, c.E, W=c.W, Ls=khatri_rao_halves(c.hK, c.E))
     pick = sorted(set(np.random.default_rng(2).choice(384, size=16, replace=False).tolist()) | {10, 11})
     # the reference's procedure verbatim on both sides.  The two sides' likelihoods differ by the rounding of two
-    # different eigenbases (~1e-13 relative), which Brent's 1e-6 search on logit(delta) turns into up to ~1e-5 on Q
-    # (tests/test_oracle_spread.py measures that on the oracle alone): Q and p at that envelope
+    # different eigenbases (~1e-13 relative), and Brent's 1e-6 search on logit(delta) can stop up to one tolerance apart
+    # on them: every variant at the north-star tolerances or, where the device says so itself, at its own bounds
+    import parity_bounds
+
     opv, oinfo, ost = o.scan_interaction(c.G[:, pick], return_stats=True)
-    _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, c.E.shape[1], q_rtol=2e-5, delta_rtol=1e-4, p_rtol=5e-5)
+    bq, bp, _ = parity_bounds.bounds(crm, dense, pick)
+    parity_bounds.assert_bounds_are_informative(bq, bp)
+    _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, c.E.shape[1], bounds=(bq, bp))
     # and with the optimum pinned on both sides (polish): the algebra itself, 1e-8 (p: Davies integrates to 1e-6)
     lib, ctx = _lib.load(), _engine._context(0)
     _lib.check(lib.crm_set_null_fit_polish(ctx, 1))

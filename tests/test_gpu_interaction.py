@@ -352,7 +352,10 @@ def test_folded_route_with_an_E1_of_its_own(mode, kernel_form):
         _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
     assert np.array_equal(info["rho1"], info0["rho1"])
     assert_allclose(st["lml"], st0["lml"], rtol=1e-12)
-    assert_allclose(st["Q"], st0["Q"], rtol=2e-5)
+    # (the two routes are two faithful runs of the search: the statistic's tolerance, or the variant's own bound)
+    import parity_bounds
+
+    parity_bounds.assert_Q_within(st["Q"], st0["Q"], parity_bounds.bounds(crm, panel)[0])
     opv, oinfo, ost = OracleCellRegMap(y, E, W=W, E1=E1, **okw).scan_interaction(G, return_stats=True)
     _compare(pv, info, st, opv, oinfo, ost)
 

@@ -39,7 +39,9 @@ def test_permutations_in_one_call_equal_separate_calls_and_the_oracle(mode, hook
         pv, info, Q = obj.scan_interaction_permutations(panel, return_Q=True, **lists)
         assert pv.shape == (B, c.G.shape[1]) and Q.shape == pv.shape
         for b in range(B):
-            one = {"E": dict(idx_E=perms[b]), "G": dict(idx_G=perms[b]), "both": dict(idx_E=perms[b], idx_G=perms2[b])}[hook]
+            # (a None inside a list stands for the identity: the call with the identity spelled out)
+            pb = np.arange(n) if perms[b] is None else perms[b]
+            one = {"E": dict(idx_E=pb), "G": dict(idx_G=pb), "both": dict(idx_E=pb, idx_G=perms2[b])}[hook]
             pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True, **one)
             assert np.array_equal(pv[b], pv1), (groups, b, np.abs(pv[b] / pv1 - 1).max())
             assert np.array_equal(Q[b], st1["Q"])
@@ -47,7 +49,7 @@ def test_permutations_in_one_call_equal_separate_calls_and_the_oracle(mode, hook
                 assert np.array_equal(info[k], info1[k]), k
     # the oracle on two of the permutations (north-star tolerances)
     o = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, **okw)
-    for b in (0, B - 1):
+    for b in (0, 2, B - 1):
         one = {"E": dict(idx_E=perms[b]), "G": dict(idx_G=perms[b]), "both": dict(idx_E=perms[b], idx_G=perms2[b])}[hook]
         opv, oinfo = o.scan_interaction(c.G, **one)
         assert np.array_equal(info["rho1"], oinfo["rho1"])
@@ -56,9 +58,9 @@ def test_permutations_in_one_call_equal_separate_calls_and_the_oracle(mode, hook
 
 def test_permuted_contexts_are_calibrated_like_the_reference_test_asks():
     """cellregmap/test/test_struct_lmm2.py:190-211: a phenotype WITH GxE effects scanned against row-permuted contexts
-    looks null -- median p > 0.3 and min p > 0.04 over its 20 variants (one permutation there; sixteen here, in one call:
-    the median bound on every one of them, the bound on the smallest p-value in the share a uniform sample gives --
-    P(min of 20 > 0.04) = 0.44)."""
+    looks null -- median p > 0.3 and min p > 0.04 over its 20 variants (one seeded permutation there; sixteen here, in one
+    call: both bounds in the shares a uniform sample gives -- the median of 20 uniform p-values is below 0.3 four times in a
+    hundred, P(min of 20 > 0.04) = 0.44 -- and the pooled median near one half)."""
     import cellregmap_amd as crm
 
     c = make_cohort(50, 10, 3, 20, seed=2)      # 500 cells, 20 variants, causal GxE variants inside (synth.py)
@@ -69,7 +71,8 @@ def test_permuted_contexts_are_calibrated_like_the_reference_test_asks():
     plain, _ = obj.scan_interaction(c.G)
     assert plain.min() < 1e-3                    # (the unpermuted scan does see the GxE variants)
     med = np.median(pv, axis=1)
-    assert np.all(med > 0.3), med
+    assert np.mean(med > 0.3) >= 0.8, med
+    assert 0.35 < np.median(pv) < 0.65, np.median(pv)
     assert np.mean(pv.min(axis=1) > 0.04) >= 0.2, pv.min(axis=1)
     assert pv.min() > 1e-4
 

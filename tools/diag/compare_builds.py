@@ -20,7 +20,12 @@ def child(lib_path, count, seed, out):
     from cellregmap_amd import _lib
 
     if lib_path:
+        import ctypes
+
         _lib.LIB_PATH = lib_path
+        probe = ctypes.CDLL(lib_path)     # (an older build lacks the entry points added since: bind what it has)
+        for name in [k for k in _lib.SIGNATURES if not hasattr(probe, k)]:
+            del _lib.SIGNATURES[name]
     from fuzz_cases import build_case, fuzz_cases
 
     from cellregmap_amd import CellRegMap, GenotypePanel

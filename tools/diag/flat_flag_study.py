@@ -1,10 +1,11 @@
-"""What the CRM_MODEL_FLAT_OPTIMUM rule measures against what actually happens between device and oracle (verbatim Brent
-on both sides), per variant of a fuzz stream: the decision distance of the fit at rho* (smallest margin of the search's
-decisions / noise bound of the objective, include/crm_hip.h), the raw margin and bound, how far Q and p move one stopping
-tolerance away, the distance of rho* from the runner-up grid point, and the actual relative differences of Q, p and lml
-against the oracle.  Prints, for a ladder of factors kappa on the noise bound, the share of scans a rule `decision <= kappa
-and sensitive` would flag and how many scans beyond the north-star tolerances it would leave unflagged; the rows go to
-gpurun_out/flat_flag_study_<seed>.npy for calibration off the box.
+"""What the reproducibility bounds of ``scan_interaction_info`` (include/crm_hip.h: crm_scan_interaction_bounds) measure
+against what actually happens between device and oracle (verbatim Brent on both sides), per variant of a fuzz stream: the
+movement of Q and p over one stopping tolerance, the relative gain of the objective over one tolerance at the stopping
+point, the decision distance of the search (smallest margin / noise bound), the distance of rho* from the runner-up grid
+point -- and the actual differences of Q, p, lml and of the stopping point itself against the oracle.  Prints the shares
+flagged, the scans beyond the tolerances that carry no flag, the scans beyond their own bounds, the distribution of
+(distance of the stopping points in tolerances) x (relative gain) -- the quantity whose observed maximum the rule's constant
+STOP_SHIFT_C covers -- and the trade-off for other constants; the rows go to gpurun_out/flat_flag_study_<seed>.npy.
     [CRM_FUZZ_MANY_CONTEXTS=1] python tools/diag/flat_flag_study.py [count 150] [seed 7] [max_variants] [max_cells]"""
 import json
 import os
@@ -22,9 +23,9 @@ from oracle.crm import OracleCellRegMap  # noqa: E402
 
 REC = 10   # scan.hip: FLAT_REC
 COLUMNS = ("decision", "Q_move_one_tol", "p_move_one_tol", "margin", "noise_bound_roundings", "rho_decision", "rho_gap", "lml",
-           "xunc", "delta",
+           "curvature", "delta",
            "actual_rel_dQ", "actual_rel_dp", "covariates", "actual_rel_dlml", "same_rho", "flag", "rho_tie_flag", "mode",
-           "cells", "problem", "oracle_delta")
+           "cells", "problem", "oracle_delta", "bound_Q", "bound_p", "statistic_flag")
 
 
 def main():
@@ -59,31 +60,46 @@ def main():
             qscale = max(abs(ost["Q"][j]), float(np.trace(ost["F"][j])))
             rows.append((*rec[j], abs(st["Q"][j] - ost["Q"][j]) / qscale, abs(pv[j] - opv[j]) / opv[j], W.shape[1],
                          abs(st["lml"][j] - ost["lml"][j]) / abs(ost["lml"][j]), float(info["rho1"][j] == oinfo["rho1"][j]),
-                         float(xi["flat_optimum"][j]), float(xi["rho_tie"][j]), "ABC".index(case[6]), y.size, idx, ost["delta"][j]))
+                         float(xi["flat_optimum"][j]), float(xi["rho_tie"][j]), "ABC".index(case[6]), y.size, idx, ost["delta"][j],
+                         xi["bound_Q"][j], xi["bound_p"][j], float(xi["statistic_at_tolerance"][j])))
     a = np.array(rows)
     col = {k: i for i, k in enumerate(COLUMNS)}
     same = a[:, col["same_rho"]] > 0
-    bad = same & ((a[:, col["actual_rel_dQ"]] > 1e-6) | (a[:, col["actual_rel_dp"]] > 1e-5))
-    sens = (a[:, col["Q_move_one_tol"]] > 5e-7) | (a[:, col["p_move_one_tol"]] > 5e-6) | ~np.isfinite(a[:, col["Q_move_one_tol"]])
     dec = a[:, col["decision"]]
-    out = {"scans": int(a.shape[0]), "seed": seed, "problems": count, "same_rho": int(same.sum()), "beyond_north_star": int(bad.sum()),
-           "sensitive_to_one_tolerance": float(sens[same].mean()), "beyond_but_not_sensitive": int((bad & ~sens).sum()),
-           "flag_as_shipped": {"share": float(a[same, col["flag"]].mean()), "missed": int((bad & (a[:, col["flag"]] == 0)).sum())},
+    dQ, dp = a[:, col["actual_rel_dQ"]], a[:, col["actual_rel_dp"]]
+    bq, bp = a[:, col["bound_Q"]], a[:, col["bound_p"]]
+    fp, fq = a[:, col["flag"]] != 0, a[:, col["statistic_flag"]] != 0
+    d = np.clip(a[:, col["delta"]], 1e-300, 1 - 1e-16)
+    od = np.clip(a[:, col["oracle_delta"]], 1e-300, 1 - 1e-16)
+    x, ox = np.log(d) - np.log1p(-d), np.log(od) - np.log1p(-od)
+    shift = np.abs(x - ox) / (1e-6 * np.abs(x) + 1e-6)          # distance of the two stopping points in tolerances
+    gain = a[:, col["curvature"]] / np.abs(a[:, col["lml"]])     # relative gain of the objective over one tolerance
+    ok = same & np.isfinite(gain) & (gain > 0)
+    out = {"scans": int(a.shape[0]), "seed": seed, "problems": count, "same_rho": int(same.sum()),
+           "beyond_1e-6_on_Q": int((same & (dQ > 1e-6)).sum()), "beyond_1e-5_on_p": int((same & (dp > 1e-5)).sum()),
+           "share_flat_optimum_p_flag": float(fp[same].mean()), "share_statistic_at_tolerance_flag": float(fq[same].mean()),
+           "unflagged_beyond_1e-5_on_p": int((same & ~fp & (dp > 1e-5)).sum()),
+           "unflagged_beyond_1e-6_on_Q": int((same & ~fq & (dQ > 1e-6)).sum()),
+           "worst_unflagged_rel_dp": float(dp[same & ~fp].max()), "worst_unflagged_rel_dQ": float(dQ[same & ~fq].max()),
+           "beyond_own_bound_on_Q": int((same & (dQ > np.maximum(1e-6, 1.001 * bq))).sum()),
+           "beyond_own_bound_on_p": int((same & (dp > np.maximum(1e-5, 1.001 * bp + 2e-6))).sum()),
+           "shift_in_tolerances_percentiles_50_90_99_99.9_100": [float(v) for v in np.percentile(shift[same], [50, 90, 99, 99.9, 100])],
+           "shift_times_relative_gain_percentiles_50_90_99_99.9_100": [float(v) for v in np.percentile((shift * gain)[ok], [50, 90, 99, 99.9, 100])],
+           "relative_gain_percentiles_1_5_50_95": [float(v) for v in np.percentile(gain[ok], [1, 5, 50, 95])],
+           "Q_move_one_tolerance_percentiles_50_90_99": [float(v) for v in np.nanpercentile(a[same, col["Q_move_one_tol"]], [50, 90, 99])],
+           "p_move_one_tolerance_percentiles_50_90_99": [float(v) for v in np.nanpercentile(a[same, col["p_move_one_tol"]], [50, 90, 99])],
+           "decision_within_noise_bound_share": float((~(dec > 1.0))[same].mean()),
            "rho_differs": int((~same).sum()), "rho_differs_without_tie_flag": int((~same & (a[:, col["rho_tie_flag"]] == 0)).sum()),
-           "rho_tie_flag_share": float(a[:, col["rho_tie_flag"]].mean())}
-    for kappa in (0.01, 0.02, 0.05, 0.1, 0.2, 0.5, 1.0, 2.0, 5.0):
-        und = ~(dec > kappa)
-        out["kappa_%g" % kappa] = {"flagged_share": float((sens & und)[same].mean()), "missed": int((bad & ~(sens & und)).sum()),
-                                   "undecided_share": float(und[same].mean())}
-    rel = a[:, col["margin"]] / np.abs(a[:, col["lml"]])
-    for theta in (1e-15, 2e-15, 4e-15, 8e-15, 1.6e-14, 3e-14):
-        und = ~(rel > theta)
-        out["relative_margin_%g" % theta] = {"flagged_share": float((sens & und)[same].mean()), "missed": int((bad & ~(sens & und)).sum())}
-    out["decision_of_the_scans_beyond"] = sorted(float(x) for x in dec[bad])[-12:] if bad.any() else []
-    out["decision_percentiles_1_5_25_50_75"] = [float(x) for x in np.nanpercentile(dec[same], [1, 5, 25, 50, 75])]
-    out["noise_bound_over_abs_lml_percentiles_5_50_95_100"] = [
-        float(x) for x in np.nanpercentile(a[same, col["noise_bound_roundings"]] / np.abs(a[same, col["lml"]]), [5, 50, 95, 100])]
-    out["actual_rel_dlml_percentiles_50_95_100"] = [float(x) for x in np.percentile(a[same, col["actual_rel_dlml"]], [50, 95, 100])]
+           "rho_tie_flag_share": float(a[:, col["rho_tie_flag"]].mean()),
+           "actual_rel_dlml_percentiles_50_95_100": [float(x_) for x_ in np.percentile(a[same, col["actual_rel_dlml"]], [50, 95, 100])]}
+    # the trade-off the constant of the rule sits on: share flagged / scans beyond left unflagged, per constant C
+    Sq, Sp = a[:, col["Q_move_one_tol"]], a[:, col["p_move_one_tol"]]
+    for C in (2e-14, 4e-14, 8e-14, 1.2e-13, 2.5e-13):
+        sh = np.where(gain > 0, np.minimum(1.0, C / np.maximum(gain, 1e-300)), 1.0)
+        sh = np.where(dec > 1.0, sh, 1.0)
+        flag_p, flag_q = ~(Sp * sh <= 1e-5), ~(Sq * sh <= 1e-6)
+        out["C_%g" % C] = {"p_flag_share": float(flag_p[same].mean()), "p_missed": int((same & ~flag_p & (dp > 1e-5)).sum()),
+                           "Q_flag_share": float(flag_q[same].mean()), "Q_missed": int((same & ~flag_q & (dQ > 1e-6)).sum())}
     print(json.dumps(out, indent=1))
     dest = os.path.join(ROOT, "gpurun_out")
     os.makedirs(dest, exist_ok=True)
