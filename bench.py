@@ -128,7 +128,7 @@ def roofline_record(lib, ctx, crm, config, kr_ms, kr_n, kr_fl, elapsed):
     form = {"contraction_sync": not lib.crm_test_sync_fallbacks(ctx), "tail_launch": True, "library": lib.crm_version().decode(),
             "kinship_route": bool(kin_groups), "tile_band": 8}
     roofline["kernel_form"] = form
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary_direct_route.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary_direct_route.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             shape = pmc["launch_shape"]

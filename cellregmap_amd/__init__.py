@@ -19,6 +19,7 @@ from ._engine import (
     run_interaction,
     run_interaction_many,
     scan_interaction_many,
+    scan_interaction_resumable,
 )
 
 
@@ -29,7 +30,7 @@ class Term(Enum):
     RANDOM = 2
 
 
-__version__ = "0.5.0"
+__version__ = "0.6.0"
 
 __all__ = [
     "__version__",
@@ -42,6 +43,7 @@ __all__ = [
     "run_interaction",
     "run_interaction_many",
     "scan_interaction_many",
+    "scan_interaction_resumable",
     "compute_maf",
     "estimate_betas",
     "get_L_values",

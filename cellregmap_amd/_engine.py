@@ -1374,6 +1374,71 @@ def scan_interaction_many(crms, G, idx_E=None, idx_G=None, cis_index=None, progr
     return out["pv"], {k: out[k] for k in ("rho1", "e2", "g2", "eps2")}
 
 
+def scan_interaction_resumable(crm, G, checkpoint, idx_E=None, idx_G=None, chunk=8192, scan=None):
+    """``crm.scan_interaction(G, idx_E, idx_G)`` over column chunks of the host matrix ``G`` with the finished chunks kept in
+    ``checkpoint`` (an ``.npz`` file, rewritten atomically after every chunk): a job that is killed -- a pre-empted node, a
+    wall-clock limit -- and started again with the same arguments scans only what is missing.  The reference has no such
+    hook (SURVEY.md section 5 lists checkpoint / resume among the optional ones); its per-variant loop
+    (cellregmap/_cellregmap.py:340) is what makes it safe: variants are independent, so any split into chunks gives the
+    scan's own results (chunks that are multiples of the scan's block of 4096 variants: bit for bit).
+
+    The file carries a fingerprint of the problem (phenotype, contexts, covariates, permutation hooks, the shape of ``G``
+    and a digest of its first, middle and last columns); a checkpoint of another problem is refused, not overwritten.
+    ``scan`` overrides the per-chunk call (tests inject the CPU oracle).  Returns ``(pvalues, info)`` like
+    ``scan_interaction``."""
+    import os
+    import tempfile
+
+    G = np.asarray(G)
+    n, p = G.shape
+    chunk = max(1, int(chunk))
+    keys = ("pv", "rho1", "e2", "g2", "eps2")
+    cols = sorted({0, p // 2, p - 1}) if p else []
+    h = hashlib.blake2b(digest_size=16)      # (not _digest: the file must mean the same on a host without xxhash)
+    for a in (crm._y, crm._E0, crm._W, [n, p, chunk], -1.0 if idx_E is None else idx_E, -1.0 if idx_G is None else idx_G,
+              G[:, cols]):
+        a = np.ascontiguousarray(a, dtype=float)
+        h.update(str(a.shape).encode())
+        h.update(a.view(np.uint8).data)
+    finger = np.frombuffer(h.digest(), dtype=np.uint8)
+    nchunks = (p + chunk - 1) // chunk
+    out = {k: np.full(p, np.nan) for k in keys}
+    done = np.zeros(nchunks, bool)
+    if os.path.exists(checkpoint):
+        with np.load(checkpoint) as old:
+            if "fingerprint" not in old or not np.array_equal(old["fingerprint"], finger):
+                raise ValueError(f"{checkpoint}: holds the checkpoint of another problem (other inputs, hooks or chunk size)")
+            done = old["done"].copy()
+            for k in keys:
+                out[k] = old[k].copy()
+    fn = scan if scan is not None else crm.scan_interaction
+
+    def save():
+        d = os.path.dirname(os.path.abspath(checkpoint))
+        fd, tmp = tempfile.mkstemp(dir=d, suffix=".npz")
+        os.close(fd)
+        try:
+            np.savez(tmp, fingerprint=finger, done=done, **out)
+            os.replace(tmp, checkpoint)       # (atomic on POSIX: a reader never sees half a file)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+
+    for ci in range(nchunks):
+        if done[ci]:
+            continue
+        j0, j1 = ci * chunk, min(p, (ci + 1) * chunk)
+        pv, info = fn(np.ascontiguousarray(G[:, j0:j1], dtype=float), idx_E, idx_G)
+        out["pv"][j0:j1] = pv
+        for k in keys[1:]:
+            out[k][j0:j1] = info[k]
+        done[ci] = True
+        save()
+    if nchunks == 0:
+        save()
+    return out["pv"], {k: out[k] for k in keys[1:]}
+
+
 def run_interaction_many(Y, E, G, W=None, E1=None, E2=None, hK=None, *, cis_index=None, device=0):
     """``run_interaction`` for the columns of ``Y`` (n x genes) with one background decomposition,
     one genotype upload and shared per-variant work.  Returns arrays of shape (genes, p); with

@@ -186,7 +186,7 @@ using namespace crm;
 extern "C" {
 
 const char* crm_last_error(void) { return last_error_text(); }
-const char* crm_version(void) { return "0.5.0"; }
+const char* crm_version(void) { return "0.6.0"; }
 
 int crm_ctx_create(int device, crm_ctx** out) {
     return crm::guarded("crm_ctx_create", [&]() -> int {

@@ -886,7 +886,11 @@ int launch_nullfit(hipStream_t st, const NullFitArgs& a, int variants, bool forc
         CRM_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned) * CRM_MAX_RHO, st));
         // four fits per wavefront (nullfit_fit: G) unless the derivative polish or the "exact" arithmetic is asked for, or
         // the form "nullfit_one_per_wave" says so (the suite holds the two forms against each other: the same bits)
-        const bool four = !a.exact && !a.polish && !form("nullfit_one_per_wave", 0);
+        // ... and only for spectra up to 2 048 entries: the rows of a wavefront search on their own -- different phases, other
+        // numbers of evaluations -- so the pass over the spectrum, which the four fits do not share, pays for the divergence
+        // what the shared scalar part saves.  Measured per 4096 x 11 fits: r = 1 020 (BASELINE config 2) 1.62 -> 1.15 ms,
+        // r = 5 000 (config 3) 4.34 -> 5.50 ms; the two lines cross near r = 2 200.
+        const bool four = !a.exact && !a.polish && rmax <= 2048 && !form("nullfit_one_per_wave", 0);
 #define CRM_NF_SHARED(EXv, TRv, Gv)                                                                                        \
     do {                                                                                                                   \
         const void* fn = reinterpret_cast<const void*>(&nullfit_shared_kernel<1, EXv, TRv, Gv>);                           \

@@ -2465,8 +2465,9 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                         // p ~ 1, leaves Q itself ill-conditioned)
                         double trace = 0.0;
                         for (int j = 0; j < k0; j++) trace += lam0[(size_t)b * k0 + j];
-                        const double mq = std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace);
-                        const double mp = std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]);
+                        // (equal values -- a p-value that underflows to zero on both sides included -- have not moved)
+                        const double mq = q1[b] == q0[b] ? 0.0 : std::fabs(q1[b] - q0[b]) / std::max(std::fabs(q0[b]), trace);
+                        const double mp = p1[b] == p0[b] ? 0.0 : std::fabs(p1[b] - p0[b]) / std::fabs(p0[b]);
                         const NullFitOut& fo = h_fit[(size_t)gi * BLK + b];
                         double* rec = &probe_rec[(size_t)b * FLAT_REC];
                         // (NaN -- a probe that could not be evaluated -- must survive the maximum)

@@ -160,7 +160,7 @@ def test_every_entry_point_runs_behind_the_exception_guard():
 
 
 def test_the_committed_traffic_profile_is_of_this_library():
-    """bench.py quotes `roofline.traffic` from profiles/r05_pmc_summary.json only when the profile's kernel form (library
+    """bench.py quotes `roofline.traffic` from profiles/r06_pmc_summary.json only when the profile's kernel form (library
     version, route, tile walk) is the running one; a version bump without new counter passes would silently turn the figure
     into null in the driver's bench line -- fail here instead."""
     import json
@@ -170,7 +170,7 @@ def test_the_committed_traffic_profile_is_of_this_library():
     from cellregmap_amd import _lib
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    form = json.load(open(os.path.join(root, "profiles", "r05_pmc_summary.json")))["kernel_form"]
+    form = json.load(open(os.path.join(root, "profiles", "r06_pmc_summary.json")))["kernel_form"]
     version = _lib.load().crm_version().decode()
     assert version == cellregmap_amd.__version__
     assert form == {"contraction_sync": True, "tail_launch": True, "library": version, "kinship_route": True, "tile_band": 8}

@@ -153,7 +153,7 @@ def test_nearly_collinear_variants_in_the_fixed_effects_own_basis(problem):
     lib, ctx = _lib.load(), _engine._context(0)
     before = lib.crm_test_dense_repeats(ctx)
     bq, bp, _ = parity_bounds.bounds(crm, GenotypePanel(G, groups=None), **hooks)
-    parity_bounds.assert_bounds_are_informative(bq, bp)
+    parity_bounds.assert_bounds_are_informative(bq, bp, opv)
     for groups in (None, "auto"):
         pv, info, st = crm.scan_interaction(GenotypePanel(G, groups=groups), return_stats=True, **hooks)
         assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
@@ -273,7 +273,7 @@ def test_interaction_scan_with_seventy_covariate_columns(genotypes):
     # verbatim procedure: every variant to the north-star tolerance or, where the library says two faithful runs may differ
     # by more (its null-fit kernel for 63 .. 128 columns leaves the same trace as the others), to its own bound
     bq, bp, _ = parity_bounds.bounds(crm, GenotypePanel(c.G, groups=None))
-    parity_bounds.assert_bounds_are_informative(bq, bp)
+    parity_bounds.assert_bounds_are_informative(bq, bp, opv)
     qscale = np.maximum(np.abs(ost["Q"]), [np.trace(F) for F in ost["F"]])
     parity_bounds.assert_Q_within(st["Q"], ost["Q"], bq, qscale)
     parity_bounds.assert_p_within(pv, opv, bp)
@@ -324,7 +324,7 @@ def test_interaction_scan_with_many_contexts(k0, c, mode, route, monkeypatch, ke
         _lib.check(lib.crm_test_set_kinship_route(ctx, 1))
     assert_allclose(info["rho1"], oinfo["rho1"], atol=1e-12)
     # (verbatim procedure: the north-star tolerances, or the variant's own bound where the library reports a wider one)
-    parity_bounds.assert_bounds_are_informative(bq, bp)
+    parity_bounds.assert_bounds_are_informative(bq, bp, opv)
     oF = np.asarray(ost["F"])
     qscale = np.maximum(np.abs(ost["Q"]), np.trace(oF, axis1=1, axis2=2))
     parity_bounds.assert_Q_within(st["Q"], ost["Q"], bq, qscale)
@@ -460,8 +460,11 @@ def test_davies_info_is_surfaced():
     pv, _ = crm.scan_interaction(c.G)
     pv2, info = crm.scan_interaction_info(c.G)
     assert np.array_equal(pv, pv2)
-    assert set(info) == {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate", "flat_optimum"} and info["ifault"].dtype == np.int32
-    assert not info["degenerate"].any() and not info["model_flags"].any()      # a well-posed problem
+    assert set(info) == {"liu_pval", "Is_Converged", "ifault", "model_flags", "degenerate", "flat_optimum", "statistic_at_tolerance",
+                         "rho_tie", "bound_Q", "bound_p"} and info["ifault"].dtype == np.int32
+    # a well-posed problem: nothing degenerate, no p-value at risk; the statistic may sit at the search's tolerance (bit 32)
+    assert not info["degenerate"].any() and not (info["model_flags"] & ~32).any()
+    assert np.all(info["bound_p"] <= 1e-5) and np.all(info["bound_Q"] >= 0) and np.all(np.isfinite(info["bound_Q"]))
     _, _, ost = OracleCellRegMap(c.y, c.E, W=c.W, hK=c.hK).scan_interaction(c.G, return_stats=True)
     for j in range(20):
         _, oinfo = davies_pvalue(ost["Q"][j], ost["F"][j], True)
@@ -543,22 +546,27 @@ def test_gram_kernel_forms_agree(shape, kernel_form):
 
 @pytest.mark.parametrize("route", [0, 2])
 def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(route, kernel_form):
-    """r = 2064 = 16 x 128 + 16.  Direct route (0): the last 144 columns of the Khatri-Rao contraction go through a launch of
-    160-column tiles; kinship-structure route (2): the last 16 columns of the mixing-matrix product through one pass over
-    the operand (gemm_tn.hip: skinny_tn_kernel).  The form "kr_no_tail" keeps the single launch over seventeen columns of
-    128-column tiles.  Both forms must give the same statistics to rounding, and the oracle's on a few variants."""
+    """r = 1032 = 8 x 128 + 8.  Direct route (0): the last 136 columns of the Khatri-Rao contraction go through a launch of
+    160-column tiles; kinship-structure route (2): the last 8 columns of the mixing-matrix product through one pass over
+    the operand (gemm_tn.hip: skinny_tn_kernel).  The form "kr_no_tail" keeps the single launch over nine columns of
+    128-column tiles.  Both forms must give the same statistics to rounding, and the oracle's on a few variants.
+    (Until round 6 this test ran on a cohort of 17 cells per donor against 16 contexts, whose spectrum is too ill-conditioned
+    for the library to keep its half factor: the kinship-structure route never ran, and one shared launch counter hid it.)"""
     import cellregmap_amd as crm
     from cellregmap_amd.synth import make_cohort
     from oracle import crm as ocrm
 
     from cellregmap_amd import _engine, _lib
 
-    c = make_cohort(129, 17, 16, 2048, seed=23)         # rank 16 * 129 = 2064 = 16 x 128 + 16 (cols 2080) < n = 2193
+    variants = 2048      # (the direct route's tail launch needs more than 1024 tiles in the main one)
+    c = make_cohort(129, 20, 8, variants, seed=23)      # rank 8 * 129 = 1032 (cols 1040) < n = 2580, twenty cells per donor
     rng = np.random.default_rng(1)
     G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes: the dense path
     Ls = crm.get_L_values(c.hK, c.E)
     obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
-    assert max(obj._bg.rank(i) for i in range(11)) == 2064
+    assert max(obj._bg.rank(i) for i in range(11)) == 1032
+    assert _lib.load().crm_background_kinship_groups(obj._bg.handle) == 129      # the structure is there to be used
+    pv0, _ = obj.scan_interaction(crm.GenotypePanel(G, groups=None))
     lib, ctx = _lib.load(), _engine._context(0)
     panel = crm.GenotypePanel(G, groups=None)
     _lib.check(lib.crm_test_set_kinship_route(ctx, route))
@@ -581,9 +589,9 @@ def test_spectrum_a_little_longer_than_a_multiple_of_the_tile(route, kernel_form
     assert np.all(np.abs(st["Q"] - st1["Q"]) <= 1e-11 * scale)
     assert np.all(np.abs(st["F"] - st1["F"]) <= 1e-11 * np.abs(st1["F"]).max(axis=(1, 2), keepdims=True))
     assert np.all(np.abs(pv - pv1) <= 1e-6 * pv1 + 1e-13)
-    pick = np.array([0, 5, 777, 1500, 2047])
+    pick = np.array([0, 5, 10, 777, 2047])
     opv, oinfo = ocrm.OracleCellRegMap(c.y, c.E, W=c.W, Ls=ocrm.khatri_rao_halves(c.hK, c.E)).scan_interaction(G[:, pick])
-    assert np.all(np.abs(pv[pick] - opv) <= 1e-5 * opv + 1e-13), np.c_[pv[pick], opv]
+    parity_bounds.assert_p_within(pv[pick], opv, parity_bounds.bounds(obj, panel, pick)[1])
 
 
 def test_null_fit_forms_are_bit_identical(kernel_form):
@@ -857,3 +865,60 @@ def test_fits_without_a_kinship_term_need_no_rotated_test_direction(kernel_form)
     both, _ = crm.scan_interaction_many([plain, flat], panel)
     pv_plain, _ = plain.scan_interaction(panel)
     assert np.array_equal(both[0], pv_plain) and np.array_equal(both[1], pv)
+
+
+@pytest.mark.parametrize("r_mod", ["short", "ragged", "long"])
+def test_four_null_fits_per_wavefront_give_the_bits_of_one(r_mod, kernel_form):
+    """The LDS-shared null-fit kernel runs four fits per wavefront, one per row of sixteen lanes (nullfit.hip: G = 4): every
+    lane stands for four lanes of the one-fit form -- the same spectrum entries in the same order into four accumulators,
+    the same pairings of the butterfly -- so delta, lml and the scale must be those of the one-fit form ("nullfit_one_per_wave")
+    to the last bit, whatever the length of the spectrum modulo the 256 entries of a trip: ~60 (shorter than a wavefront),
+    ~1 170 (a ragged last trip), ~2 064.  1 100 variants: the queue's last ticket holds fewer than four."""
+    import cellregmap_amd as crm
+    from cellregmap_amd.synth import make_cohort
+
+    donors, cells, k0 = {"short": (4, 300, 12), "ragged": (61, 30, 19), "long": (129, 17, 16)}[r_mod]
+    c = make_cohort(donors, cells, k0, 1100, seed=91)
+    rng = np.random.default_rng(4)
+    G = c.G + 0.05 * rng.normal(size=c.G.shape)
+    obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=crm.get_L_values(c.hK, c.E))
+    lo, hi = {"short": (40, 63), "ragged": (1100, 1178), "long": (2049, 2080)}[r_mod]
+    assert lo <= max(obj._bg.rank(i) for i in range(11)) <= hi
+    panel = crm.GenotypePanel(G, groups=None)
+    pv, info, st = obj.scan_interaction(panel, return_stats=True)
+    xi = obj.scan_interaction_info(panel)[1]
+    kernel_form("nullfit_one_per_wave", 1)
+    pv1, info1, st1 = obj.scan_interaction(panel, return_stats=True)
+    xi1 = obj.scan_interaction_info(panel)[1]
+    kernel_form("nullfit_one_per_wave", 0, reset=True)
+    for k in ("delta", "lml", "scale", "Q"):
+        assert np.array_equal(st[k], st1[k]), k
+    assert np.array_equal(pv, pv1) and np.array_equal(info["rho1"], info1["rho1"])
+    # ... and the tracked kernels of the two forms leave the same trace
+    for k in ("bound_Q", "bound_p", "model_flags"):
+        assert np.array_equal(xi[k], xi1[k]), k
+
+
+def test_resumable_scan_on_the_device(tmp_path):
+    """``scan_interaction_resumable`` with the device as the per-chunk scan: chunks that are multiples of the scan's block give
+    the one-panel scan bit for bit, and a second call on the finished checkpoint touches no GPU work at all."""
+    from cellregmap_amd import CellRegMap, _engine, _lib, scan_interaction_resumable
+    from cellregmap_amd.synth import make_cohort
+
+    c = make_cohort(6, 20, 3, 600, seed=8)
+    crm = CellRegMap(c.y, c.E, W=c.W, hK=c.hK)
+    lib, ctx = _lib.load(), _engine._context(0)
+    _lib.check(lib.crm_set_block_variants(ctx, 128))
+    try:
+        pv, info = crm.scan_interaction(c.G, groups=None)
+        path = str(tmp_path / "scan.npz")
+        rpv, rinfo = scan_interaction_resumable(crm, c.G, path, chunk=256, scan=lambda G, a, b: crm.scan_interaction(G, a, b, groups=None))
+    finally:
+        _lib.check(lib.crm_set_block_variants(ctx, 0))
+    assert np.array_equal(rpv, pv) and all(np.array_equal(rinfo[k], info[k]) for k in info)
+
+    def no_scan(*args):
+        raise AssertionError("a finished checkpoint must not scan")
+
+    again, _ = scan_interaction_resumable(crm, c.G, path, chunk=256, scan=no_scan)
+    assert np.array_equal(again, pv)

@@ -154,7 +154,7 @@ def test_config2_against_the_oracles_own_decompositions(cfg2):
 
     opv, oinfo, ost = o.scan_interaction(c.G[:, pick], return_stats=True)
     bq, bp, _ = parity_bounds.bounds(crm, dense, pick)
-    parity_bounds.assert_bounds_are_informative(bq, bp)
+    parity_bounds.assert_bounds_are_informative(bq, bp, pv[pick])
     _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, c.E.shape[1], bounds=(bq, bp))
     # and with the optimum pinned on both sides (polish): the algebra itself, 1e-8 (p: Davies integrates to 1e-6)
     lib, ctx = _lib.load(), _engine._context(0)
@@ -469,3 +469,64 @@ def _config5(route):
     assert second is not None, "no second phenotype with another modal rho* found"
     checked += check(*second, 4)
     assert checked >= 8
+
+
+def test_fold_of_a_dense_ragged_donor_level_factor_at_config2_size(kernel_form):
+    """The kinship factor as the reference's simulator forms it (_simulate.py:83-102, 477-479: hK = U sqrt(S) of the
+    donor-block K) is DENSE at donor level -- m x m, every donor against every component -- and real cohorts are ragged.
+    At BASELINE config 2's size (5 000 cells, 20 contexts; 48 donors of 40 .. 160 cells) the library must find the donor
+    structure, fold the dense donor-level block into its mixing matrices (MixK; with 20 contexts the fold is not the default
+    -- one launch over [us | E1] per donor measured faster at config 2 -- so the form "kin_fold" asks for it) and scan
+    general genotypes through the folded route to the oracle's numbers -- and to the direct route's (the contraction
+    against Q0(rho*) over all cells); the unfolded kinship-structure route, config 2's default, must agree as well."""
+    import parity_bounds
+    from cellregmap_amd import CellRegMap, GenotypePanel, _engine, _lib, get_L_values
+    from cellregmap_amd.synth import column_normalize
+    from oracle.crm import khatri_rao_halves
+
+    rng = np.random.default_rng(77)
+    donors, n, k0 = 48, 5000, 20
+    counts = rng.integers(40, 161, size=donors)
+    counts = np.maximum(20, (counts * (n / counts.sum())).astype(int))
+    counts[-1] += n - counts.sum()
+    donor = np.repeat(np.arange(donors), counts)
+    assert donor.size == n and counts.min() >= 20 and counts.max() > 2 * counts.min()
+    # U sqrt(S) of the donor-block K = Z Z' / mean diag + 1e-8 I restricted to its m leading directions: Z D R with R an
+    # orthogonal m x m matrix (cellregmap_amd/synth.py: kinship_factor "rotated") -- dense at donor level, ragged donors
+    R, _ = np.linalg.qr(rng.normal(size=(donors, donors)))
+    hKd = np.sqrt((counts + 1e-8) / counts)[:, None] * R
+    hK = hKd[donor]
+    E = column_normalize(rng.normal(size=(n, k0)))
+    W = np.ones((n, 1))
+    G = column_normalize(rng.normal(size=(n, 96)))                      # general (cell-level) genotypes
+    yk = sum(E[:, i] * (hK @ rng.normal(size=donors)) for i in range(k0))
+    y = 0.3 + 0.4 * G[:, 3] * (E @ rng.normal(size=k0)) + yk / yk.std() + E @ rng.normal(size=k0) * 0.3 + rng.normal(size=n)
+    Ls = get_L_values(hK, E)
+    lib, ctx = _lib.load(), _engine._context(0)
+    plain = CellRegMap(y, E, W=W, Ls=Ls)                               # the default at this size: structure used, not folded
+    assert lib.crm_background_kinship_groups(plain._bg.handle) == donors
+    assert lib.crm_background_kinship_folded(plain._bg.handle) == 0
+    panel = GenotypePanel(G, groups=None)
+    pv_plain, info_plain = plain.scan_interaction(panel)
+    del plain
+    _engine._bg_cache.clear()
+    kernel_form("kin_fold", 2)                                         # (read when the structure is announced)
+    crm = CellRegMap(y, E, W=W, Ls=Ls)
+    assert lib.crm_background_kinship_groups(crm._bg.handle) == donors
+    assert lib.crm_background_kinship_folded(crm._bg.handle) > 0
+    pv, info, st = crm.scan_interaction(panel, return_stats=True)
+    assert np.array_equal(info["rho1"], info_plain["rho1"])
+    with _route("direct"):
+        pv0, info0, st0 = crm.scan_interaction(panel, return_stats=True)
+    assert np.array_equal(info["rho1"], info0["rho1"])
+    bq, bp, _ = parity_bounds.bounds(crm, panel)
+    parity_bounds.assert_bounds_are_informative(bq, bp, pv)
+    assert_allclose(st["lml"], st0["lml"], rtol=1e-11)
+    parity_bounds.assert_Q_within(st["Q"], st0["Q"], bq, np.maximum(np.abs(st0["Q"]), np.trace(st0["F"], axis1=1, axis2=2)), "routes")
+    parity_bounds.assert_p_within(pv, pv0, bp, "routes")
+    parity_bounds.assert_p_within(pv_plain, pv0, bp, "unfolded")
+    o = _oracle_on_device_decomposition(crm, y, E, W, khatri_rao_halves(hK, E))
+    pick = sorted(set(np.random.default_rng(5).choice(96, size=10, replace=False).tolist()) | {3})
+    opv, oinfo, ost = o.scan_interaction(G[:, pick], return_stats=True)
+    _compare_with_oracle(pv, info, st, pick, opv, oinfo, ost, k0, bounds=(bq[pick], bp[pick]))
+    assert pv[3] < 1e-6                                                  # the planted GxE variant is found

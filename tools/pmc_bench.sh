@@ -3,9 +3,9 @@
 # passes (the TCC block cannot hold FETCH_SIZE and WRITE_SIZE together), restricted to the dominant kernel: the tagged
 # plain product of the kinship-structure route by default; CRM_PMC_KERNELS='gemm_tn_glds_(sync_)?kernel<true' with
 # CRM_KIN_ROUTE=0 for the direct Khatri-Rao contraction.
-#   gpurun -- 'bash tools/pmc_bench.sh'      -> gpurun_out/pmc_r05/
+#   gpurun -- 'bash tools/pmc_bench.sh'      -> gpurun_out/pmc_r06/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/pmc_r05
+out=gpurun_out/pmc_r06
 mkdir -p $out
 BENCH="bench.py --steps 2 --warmup 1 --cpu-variants 0 --full-panel 0 --genes 0 --collapsed 0 --direct-steps 0"
 python3 $BENCH > $out/bench_plain.json 2> $out/bench_plain.err

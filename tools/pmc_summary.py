@@ -1,11 +1,11 @@
-"""Turn the CSVs of tools/pmc_bench.sh into profiles/r05_pmc_summary.json.
+"""Turn the CSVs of tools/pmc_bench.sh into profiles/r06_pmc_summary.json.
 
 A block of 4096 variants is one large Khatri-Rao launch (gemm_tn_glds_sync_kernel) plus, when the spectrum is a little
 longer than a multiple of the 128-column tile, a second launch of 160-column tiles for the last columns; the counters of
 both are added per block.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 bytes; FETCH_SIZE is doubled for
 16-byte-per-lane streams (the gfx950 correction of MI355X_MICROARCH.md's HBM section).
 
-    python tools/pmc_summary.py gpurun_out/pmc_r05 > profiles/r05_pmc_summary.json"""
+    python tools/pmc_summary.py gpurun_out/pmc_r06 > profiles/r06_pmc_summary.json"""
 import csv
 import json
 import os
