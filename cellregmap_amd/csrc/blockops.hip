@@ -530,7 +530,7 @@ constexpr int DP_VARIANTS = 4, DP_MAX_SLOTS = 32;   // 4 * npair <= 256 * slots 
 template <int DP_SLOTS>     // entries of the four pair rows per thread (registers: as few as the context count needs)
 __global__ __launch_bounds__(256) void donor_pairs_expand_kernel(const double* __restrict__ P, long p_slab, long ldp, int donors,
                                                                   int variants, int k0, int k1, double* __restrict__ S, long lds,
-                                                                  double* __restrict__ Psum, long psum_slab) {
+                                                                  double* __restrict__ Psum, long psum_slab, long row_d, long row_j) {
     extern __shared__ double tile[];              // [DP_VARIANTS][npair]
     const int npair = k0 * (k0 + 1) / 2, total = DP_VARIANTS * npair;
     const int v0 = blockIdx.x * DP_VARIANTS, tid = threadIdx.x;
@@ -566,10 +566,12 @@ __global__ __launch_bounds__(256) void donor_pairs_expand_kernel(const double* _
         __syncthreads();
         if (d + 1 < d1) fetch(d + 1);      // (in flight while this donor's rows are written)
         if (writer) {
-            double* __restrict__ Sd = S + (size_t)(k1 + (long)d * k0) * lds + (long)v0 * k0 + tid;
+            // (row of (d, j): k1 + d row_d + j row_j -- the folded form's k1 + d k0 + j, or k1 + j m + d where the donors' index
+            // is a column of the kinship factor and the rows are those of the half factor itself)
+            double* __restrict__ Sd = S + (size_t)(k1 + (long)d * row_d) * lds + (long)v0 * k0 + tid;
             for (int j = 0; j < k0; j++) {
                 const int pidx = j <= iw ? j * k0 - j * (j - 1) / 2 + (iw - j) : base_i + j;
-                Sd[(long)j * lds] = mine[pidx];
+                Sd[(long)j * row_j * lds] = mine[pidx];
             }
         }
         __syncthreads();
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(256) void donor_pairs_expand_kernel(const double* _
 bool donor_pairs_serves(int k0) { return k0 >= 2 && DP_VARIANTS * (k0 * (k0 + 1) / 2) <= 256 * DP_MAX_SLOTS && DP_VARIANTS * k0 <= 256; }
 
 int launch_donor_pairs_expand(hipStream_t st, const double* P, long p_slab, long ldp, int donors, int variants, int k0, int k1,
-                              double* S, long lds, double* Psum, long psum_slab, int splits) {
+                              double* S, long lds, double* Psum, long psum_slab, int splits, long row_d, long row_j) {
+    if (row_d <= 0) { row_d = k0; row_j = 1; }
     if (variants <= 0 || donors <= 0) return CRM_OK;
     if (!donor_pairs_serves(k0) || splits < 1) {
         set_error("donor pairs: k0=%d outside the supported range", k0);
@@ -594,7 +597,7 @@ int launch_donor_pairs_expand(hipStream_t st, const double* P, long p_slab, long
     const int slots = (DP_VARIANTS * (k0 * (k0 + 1) / 2) + 255) / 256;
 #define CRM_DP_LAUNCH(SL)                                                                                                        \
     hipLaunchKernelGGL(donor_pairs_expand_kernel<SL>, grid, dim3(256), lds_bytes, st, P, p_slab, ldp, donors, variants, k0, k1, \
-                       S, lds, Psum, psum_slab)
+                       S, lds, Psum, psum_slab, row_d, row_j)
     if (slots <= 4) CRM_DP_LAUNCH(4);
     else if (slots <= 8) CRM_DP_LAUNCH(8);
     else if (slots <= 16) CRM_DP_LAUNCH(16);

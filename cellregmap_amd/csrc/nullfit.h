@@ -131,8 +131,9 @@ int launch_pair_rows(hipStream_t st, const double* C, long ldc, int variants, in
 int launch_same_columns(hipStream_t st, const double* H, long ldh, const double* Ep, long ld_ep, long cells, int k, int* flag);
 int launch_pair_rows_sym(hipStream_t st, const double* C, long ldc, int variants, int k0, double* S, long lds);
 bool donor_pairs_serves(int k0);
+// (row_d, row_j: row of (donor d, context j) = k1 + d row_d + j row_j; default (k0, 1): the folded form's layout)
 int launch_donor_pairs_expand(hipStream_t st, const double* P, long p_slab, long ldp, int donors, int variants, int k0, int k1,
-                              double* S, long lds, double* Psum, long psum_slab, int splits);
+                              double* S, long lds, double* Psum, long psum_slab, int splits, long row_d = 0, long row_j = 0);
 // dst[k, :cols] = src[k, :cols] * scale[k * ld_scale]
 int launch_scale_rows(hipStream_t st, const double* src, long ld_src, const double* scale, long ld_scale, long rows, int cols,
                       double* dst, long ld_dst);

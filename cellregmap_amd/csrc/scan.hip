@@ -1517,7 +1517,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                                       (e1_pairs ? (size_t)(std::max<long>(BLK, max_pairs) + 128) * ldP : (size_t)bg->kin_k1 * ld_ah)));
         } else {
             CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)bg->ldh * ld_ah));
-            CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
+            // (zeroed further down, once the form of the per-donor sums is known: all of it, or its padding rows alone)
         }
         if (ng > 1) CRM_TRY(ctx->ws_XG.ensure(sizeof(double) * (size_t)kdim * ld_xg));
     }
@@ -1661,6 +1661,53 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(ctx->ws_AH.ensure(sizeof(double) * (size_t)std::max<long>(donor_pair_splits, fold_split6) *
                                       (size_t)std::max<long>(pd_slab, (std::max<long>(BLK, max_pairs) + 128) * ldP)));
         }
+    }
+    // The same idea on the UNFOLDED kinship-structure route (few contexts: BASELINE config 2's 20): with E1 = E2 = E the
+    // per-donor blocks [us | E1]'(g o E0) are one symmetric matrix S_d = sum_c g_c e_c e_c' twice over -- one batched plain
+    // product per donor against E (x) E in donor order (P_d), the contraction over the donors with the kinship factor ON THE
+    // PAIR PRODUCTS (Z_c = sum_d hKd[d, c] P_d: 210 columns per variant instead of 400, and an extra column of ones in hKd
+    // gives the sum over the donors that the E1 rows are), then the rows of AH = H'(g o E0) written from Z in one pass --
+    // instead of the Khatri-Rao launch per donor (64-wide tiles a third full), the contraction over the donors on k0 x k0
+    // blocks and the E1 sums.  Config 2: 1.7 -> 0.7 ms of a 8.6 ms step.
+    bool pairs_unfolded = false;
+    if (kin_route && !kfold && d_EE && bg->kin_k1 == k0 && bg->kin_k2 == k0 && donor_pairs_serves(k0) && form("donor_pairs", 1) &&
+        bg->kin_cols + 1 <= bg->kin_ldh) {
+        const double cost_kr = 2.0 * bg->kin_rows * (double)KK * k0 + 2.0 * (double)bg->kin_groups_pad * bg->kin_cols * bg->kin_k2 * k0;
+        const double cost_pairs = 2.0 * bg->kin_rows * (double)npair + 2.0 * (double)(bg->kin_cols + 1) * bg->kin_groups_pad * (double)ldPd;
+        const bool fits = sizeof(double) * (double)bg->kin_groups_pad * (double)pd_slab <= 8.0 * (1ull << 30) &&
+                          sizeof(double) * (double)(bg->kin_cols + 1) * (double)pd_slab <= (double)s_bytes;
+        if (fits && (cost_pairs < 0.8 * cost_kr || form("donor_pairs", 1) >= 2)) {
+            int h_flag = 0;
+            int* d_flag = reinterpret_cast<int*>(d_near);
+            CRM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+            CRM_TRY(launch_same_columns(st, bg->H.as<double>(), bg->ldh, d_Ep, g0->ld_ep, n, k0, d_flag));
+            CRM_TRY(launch_same_columns(st, bg->kin_Y.as<double>(), bg->kin_ldy, g0->kinEp.as<double>(), g0->ld_ep, bg->kin_rows, k0, d_flag));
+            CRM_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            CRM_HIP(hipStreamSynchronize(st));
+            pairs_unfolded = h_flag == 0;
+        }
+        if (pairs_unfolded) {
+            CRM_TRY(g0->kinEE.ensure(sizeof(double) * (size_t)bg->kin_rows * g0->ld_ee));
+            CRM_TRY(launch_gather_rows(st, d_EE, g0->ld_ee, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ee, g0->kinEE.as<double>(),
+                                       g0->ld_ee));
+            // (slabs of the padding donors stay zero from the allocation: they meet zero rows of hKd)
+            CRM_TRY(ctx->ws_Pd.ensure(sizeof(double) * (size_t)bg->kin_groups_pad * pd_slab));
+            // the column of ones behind the kinship factor's m columns (kin_hKd: kin_groups_pad x kin_ldh, zero beyond m)
+            std::vector<double> ones((size_t)bg->kin_groups, 1.0);
+            CRM_HIP(hipMemcpy2DAsync(bg->kin_hKd.as<double>() + bg->kin_cols, sizeof(double) * bg->kin_ldh, ones.data(), sizeof(double),
+                                     sizeof(double), bg->kin_groups, hipMemcpyHostToDevice, st));
+            CRM_HIP(hipStreamSynchronize(st));   // (ones lives on this stack frame)
+        }
+    }
+    if (bg->fast_T && ctx->fast_T && (ng > 1 || kin_route) && !collapsed && !kfold) {
+        // AH = H'(g o E0), the operand of the products with the mixing matrices: its rows beyond the half factor's columns meet
+        // zero rows of Mix and must be finite -- zero.  The pair-feature form writes every row below them for every column it
+        // is read at (columns beyond the block's only feed output rows that are never stored), so the padding rows are all
+        // there is to clear: 4 rows instead of 0.67 GB per call at config 2.
+        if (pairs_unfolded && bg->ldh > bg->cols)
+            CRM_HIP(hipMemsetAsync(ctx->ws_AH.as<double>() + (size_t)bg->cols * ld_ah, 0, sizeof(double) * (size_t)(bg->ldh - bg->cols) * ld_ah, st));
+        else if (!pairs_unfolded)
+            CRM_HIP(hipMemsetAsync(ctx->ws_AH.ptr, 0, sizeof(double) * (size_t)bg->ldh * ld_ah, st));
     }
     const long xrows = collapsed ? mp : np;  // length of the contraction axis in this mode
     std::vector<NullFitOut> h_fit((size_t)BLK * ng);
@@ -2268,6 +2315,43 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(launch_gather_rows(st, Gsrc, ldg_k, bg->kin_map.as<int>(), bg->kin_rows, in_pair_order ? (int)ldg_k : blk_cols, Gk, ldg_k));
             std::vector<GemmProblem> kp((size_t)groups + k2);
             long maxlen = GEMM_BK;
+            if (pairs_unfolded) {
+                // P_d = G_d'(E (x) E)_d per donor; Z = [hKd | 1]' P over the donors (in ws_S: the per-donor blocks are not formed);
+                // rows k1 + j m + c of AH from Z_c, rows [0, k1) from the sums over the donors Z_m
+                double* Pd = ctx->ws_Pd.as<double>();
+                double* Z = S;
+                for (long d = 0; d < groups; d++) {
+                    GemmProblem p{};
+                    p.X = Gk + bg->kin_row0[d] * ldg_k; p.ldx = ldg_k;
+                    p.Y = g0->kinEE.as<double>() + bg->kin_row0[d] * g0->ld_ee; p.ldy = g0->ld_ee;
+                    p.C = Pd + (size_t)d * pd_slab; p.ldc = ldPd;
+                    p.M = ncol; p.N = npair; p.cells = bg->kin_len[d];
+                    maxlen = std::max(maxlen, bg->kin_len[d]);
+                    kp[d] = p;
+                }
+                {
+                    GemmProblem p{};
+                    p.X = bg->kin_hKd.as<double>(); p.ldx = bg->kin_ldh;
+                    p.Y = Pd; p.ldy = pd_slab;
+                    p.C = Z; p.ldc = pd_slab;
+                    p.M = (int)mk + 1; p.N = (int)((long)ncol * ldPd);
+                    kp[groups] = p;
+                }
+                GemmProblem* d_kp = d_probs + 2 * CRM_MAX_RHO + 4;
+                CRM_HIP(hipMemcpyAsync(d_kp, kp.data(), sizeof(GemmProblem) * (size_t)(groups + 1), hipMemcpyHostToDevice, st));
+                CRM_TRY(launch_gemm_tn(ctx, d_kp, (int)groups, ncol, npair, maxlen, false, 0, 1, 0));
+                CRM_TRY(launch_gemm_tn(ctx, d_kp + groups, 1, (int)mk + 1, (int)((long)ncol * ldPd), bg->kin_groups_pad, false, 0, 1, 0));
+                CRM_TRY(launch_donor_pairs_expand(st, Z, pd_slab, ldPd, (int)mk, ncol, k0, k1, ctx->ws_AH.as<double>(), ld_ah, Pd, pd_slab, 1,
+                                                  1, mk));
+                CRM_TRY(launch_pair_rows_sym(st, Z + (size_t)mk * pd_slab, ldPd, ncol, k0, ctx->ws_AH.as<double>(), ld_ah));
+                ctx->donor_pair_blocks++;
+                if (!in_pair_order) {
+                    const int xg_cols = (int)std::min<long>(ld_xg, round_up((long)npairs * k0, 128) + 128);
+                    CRM_TRY(launch_gather_slabs(st, ctx->ws_AH.as<double>(), ld_ah, bg->ldh, d_ord, npairs, k0,
+                                                ctx->ws_XG.as<double>(), ld_xg, xg_cols));
+                }
+                CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+            } else {
             for (long d = 0; d < groups; d++) {
                 GemmProblem p{};
                 p.X = Gk + bg->kin_row0[d] * ldg_k; p.ldx = ldg_k;
@@ -2299,6 +2383,7 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
                                             ctx->ws_XG.as<double>(), ld_xg, xg_cols));
             }
             CRM_HIP(hipStreamSynchronize(st));   // (kp lives on this stack frame)
+            }   // (the Khatri-Rao form of the per-donor blocks)
         } else if (via_H) {
             GemmProblem p{};
             p.X = Gt; p.ldx = ldb; p.E = d_Ep; p.lde = g0->ld_ep; p.k0 = k0;

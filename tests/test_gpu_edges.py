@@ -782,13 +782,16 @@ def test_scans_from_several_threads_on_one_device_are_serialised_by_the_library(
         assert np.array_equal(pv, spv) and np.array_equal(info["rho1"], sinfo["rho1"])
 
 
+@pytest.mark.parametrize("fold", [2, 0], ids=["folded", "unfolded"])
 @pytest.mark.parametrize("donors,cells,k0,variants", [(6, 120, 7, 37), (12, 90, 20, 130), (5, 300, 50, 64)])
-def test_per_donor_sums_from_the_symmetric_pair_features(donors, cells, k0, variants, kernel_form):
-    """The kinship term's contexts are the scan's own (run_interaction's default E2 = E): the folded kinship-structure form
+def test_per_donor_sums_from_the_symmetric_pair_features(donors, cells, k0, variants, fold, kernel_form):
+    """The kinship term's contexts are the scan's own (run_interaction's default E2 = E): the kinship-structure route
     takes the per-donor sums S_d = sum_c g_c e_c e_c' from one batched product against E (x) E in donor order and the E1
     rows as their sum over the donors (scan.hip: donor pairs; blockops.hip: donor_pairs_expand_kernel) instead of the
-    Khatri-Rao launch per donor plus the E1 rows' own product.  Both forms must give the same statistics to rounding --
-    odd context counts, variant counts that are no multiple of the four a workgroup takes -- and the oracle's."""
+    Khatri-Rao launch per donor plus the E1 rows' own product -- in its folded form (the rows of S from the products) and,
+    round 6, in its unfolded one (the contraction over the donors with the kinship factor applied to the pair products,
+    the rows of H'(g o E0) from the result: BASELINE config 2's form).  Both forms must give the same statistics to
+    rounding -- odd context counts, variant counts that are no multiple of the four a workgroup takes -- and the oracle's."""
     import cellregmap_amd as crm
     from cellregmap_amd import _engine, _lib
     from cellregmap_amd.synth import make_cohort
@@ -797,12 +800,14 @@ def test_per_donor_sums_from_the_symmetric_pair_features(donors, cells, k0, vari
     c = make_cohort(donors, cells, k0, variants, seed=300 + k0)
     rng = np.random.default_rng(k0)
     G = c.G + 0.05 * rng.normal(size=c.G.shape)          # general genotypes: the dense path
-    kernel_form("kin_fold", 2)                            # (read when the structure is announced: folded with few contexts too)
+    kernel_form("kin_fold", fold)                         # (read when the structure is announced: folded with few contexts too / never)
+    _engine._bg_cache.clear()
     Ls = crm.get_L_values(c.hK, c.E)
     assert Ls.device_us is not Ls.us and np.array_equal(Ls.device_us, c.E)   # the device gets the contexts' own basis
     obj = crm.CellRegMap(c.y, c.E, W=c.W, Ls=Ls)
     lib, ctx = _lib.load(), _engine._context(0)
-    assert lib.crm_background_kinship_folded(obj._bg.handle) > 0
+    assert (lib.crm_background_kinship_folded(obj._bg.handle) > 0) == (fold == 2)
+    assert lib.crm_background_kinship_groups(obj._bg.handle) == donors
     panel = crm.GenotypePanel(G, groups=None)
     _lib.check(lib.crm_test_set_kinship_route(ctx, 2))
     try:
