@@ -1690,8 +1690,12 @@ static int scan_pass(const std::vector<crm_gene*>& genes, crm_panel* panel, long
             CRM_TRY(g0->kinEE.ensure(sizeof(double) * (size_t)bg->kin_rows * g0->ld_ee));
             CRM_TRY(launch_gather_rows(st, d_EE, g0->ld_ee, bg->kin_map.as<int>(), bg->kin_rows, (int)g0->ld_ee, g0->kinEE.as<double>(),
                                        g0->ld_ee));
-            // (slabs of the padding donors stay zero from the allocation: they meet zero rows of hKd)
+            // (the slabs of the padding donors meet zero rows of hKd in the contraction over the donors: they must be finite --
+            // cleared here, not left to whatever the allocation or an earlier call put there)
             CRM_TRY(ctx->ws_Pd.ensure(sizeof(double) * (size_t)bg->kin_groups_pad * pd_slab));
+            if (bg->kin_groups_pad > bg->kin_groups)
+                CRM_HIP(hipMemsetAsync(ctx->ws_Pd.as<double>() + (size_t)bg->kin_groups * pd_slab, 0,
+                                       sizeof(double) * (size_t)(bg->kin_groups_pad - bg->kin_groups) * pd_slab, st));
             // the column of ones behind the kinship factor's m columns (kin_hKd: kin_groups_pad x kin_ldh, zero beyond m)
             std::vector<double> ones((size_t)bg->kin_groups, 1.0);
             CRM_HIP(hipMemcpy2DAsync(bg->kin_hKd.as<double>() + bg->kin_cols, sizeof(double) * bg->kin_ldh, ones.data(), sizeof(double),
