@@ -5,7 +5,8 @@ cellregmap/_cellregmap.py:352).  Near the optimum Brent's parabolic steps are bu
 objective values of relative size ~1e-12, so rounding noise of a few ulp in the objective moves the
 accepted point by an amount of the order of the stopping tolerance, and Q and the p-value move with it.
 This CPU test measures that spread on the oracle alone -- the same code, the same inputs, only the
-objective rounded differently -- and so backs the two-tier criterion of tests/test_gpu_fuzz.py:
+objective rounded differently -- and so backs what tests/test_gpu_fuzz.py and tests/parity_bounds.py hold the device to
+under the verbatim procedure (the north-star tolerances, or a variant's own reproducibility bound where that is wider):
 
   * spectrum columns permuted (every sum over the spectrum in another order, ~1 ulp) or the cells permuted (every
     n-length inner product in another order): same Brent path on this sample, spread < 1e-7;
@@ -139,8 +140,8 @@ def test_another_order_of_the_cells_keeps_the_brent_path_on_this_sample(spreads)
 
 def test_a_few_ulp_in_the_objective_move_Q_by_the_stopping_tolerance(spreads):
     """Identical mathematics, objective rounded differently: the spread of Q grows with the size of the
-    rounding difference, reaches the stopping tolerance's 1e-6 class, and stays inside the envelope the
-    GPU fuzz test allows for the verbatim procedure (Q 2e-5, p 5e-5)."""
+    rounding difference, reaches the stopping tolerance's 1e-6 class, and stays within a few tolerances (Q 2e-5, p 5e-5:
+    the oracle-vs-oracle envelope; the device is held to per-variant bounds instead, tests/parity_bounds.py)."""
     med = [spreads[k]["median_rel_Q"] for k in ("permuted", "noise1e-15", "noise1e-14", "noise1e-13")]
     assert med[0] < med[1] < med[2] < med[3], med
     assert spreads["noise1e-14"]["worst_rel_Q"] > 2e-7, spreads["noise1e-14"]

@@ -21,5 +21,6 @@ if len(sys.argv) > 5:
 if os.environ.get("CRM_FUZZ_MANY_CONTEXTS"):   # the sizes of the slower kernel forms: up to 256 contexts, 288 Gram rows
     limits.update(max_contexts=256, max_rows=288, extra_covariates=(30, 70))
 share = bool(os.environ.get("CRM_FUZZ_SHARE_DECOMPOSITION"))   # the oracle on the device's (Q0, S0): isolates the scan
-for polish in ([True, False] if which == "both" else [which == "polished"]):
-    print(json.dumps({**_run(polish, count=count, seed=seed, share_decomposition=share, **limits)[0], **limits}, indent=1), flush=True)
+docs = [{**_run(polish, count=count, seed=seed, share_decomposition=share, **limits)[0], **limits}
+        for polish in ([True, False] if which == "both" else [which == "polished"])]
+print(json.dumps(docs[0] if len(docs) == 1 else {"procedures": docs}, indent=1), flush=True)     # (one JSON document)
