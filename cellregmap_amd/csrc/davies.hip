@@ -10,6 +10,7 @@
 //     every sum over the eigenvalues is lane-parallel + butterfly, and the trapezoid rule
 //     puts one abscissa per lane.
 #include "nullfit.h"
+#include "wave_ops.h"
 
 namespace crm {
 
@@ -20,11 +21,7 @@ constexpr double LN28 = 0.08664339756999316;  // log(2)/8
 constexpr int DAVIES_LIM = 10000;
 constexpr double DAVIES_ACC = 1e-6;
 
-__device__ inline double wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ inline double wsum(double v) { return wave_sum_butterfly(v); }
 __device__ inline int wsum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -221,22 +218,53 @@ __device__ void find_trunc_point(Qf& q, double& utx, double accx) {
     utx = ut;
 }
 
-// AS 155 integrate: one abscissa per lane
+// AS 155 integrate: one abscissa per lane.  At an abscissa u the integrand needs  sum_j atan(2 lb_j u)  and
+// sum_j log(1 + (2 lb_j u)^2) -- r arctangents and r logarithms, the bulk of the kernel's time at 50 weights.  Both are
+// one complex number: prod_j (1 + i x_j) has the argument sum_j atan(x_j) and the modulus exp(sum_j log(1 + x_j^2) / 2).
+// With positive weights (what SKAT's filter leaves: always, here) every factor turns the product anticlockwise by less than
+// a quarter turn, so the argument is unwrapped by counting the crossings of the negative real axis; the product is kept
+// within range by taking out powers of two.  r complex multiplications, one atan2 and one log per abscissa instead of r of
+// each; the sums agree with the term-by-term ones to ~r roundings (absolute), far inside acc = 1e-6.  Weights of mixed
+// sign (never produced by the score test) take the term-by-term loop.
 __device__ void integrate(Qf& q, int nterm, double interv, double tausq, bool mainx) {
     const double inpi = interv / PI;
     double a1 = 0.0, a2 = 0.0;
+    const bool positive = q.lmin == 0.0;
     for (int k = nterm - q.lane; k >= 0; k -= 64) {
         const double u = (k + 0.5) * interv;
         double sum1 = -2.0 * u * q.c;
         double sum2 = fabs(sum1);
         double sum3 = -0.5 * q.sigsq * u * u;
-        for (int j = q.r - 1; j >= 0; j--) {
-            const double x = 2.0 * q.lb[j] * u;
-            const double y = x * x;
-            sum3 -= 0.25 * log1p_variant(y, true);
-            const double z = atan(x);
-            sum1 += z;
-            sum2 += fabs(z);
+        if (positive) {
+            double re = 1.0, im = 0.0;
+            int turns = 0, expo = 0;
+            const double u2 = 2.0 * u;
+            for (int j = q.r - 1; j >= 0; j--) {
+                const double x = q.lb[j] * u2;
+                const double nre = fma(-im, x, re), nim = fma(re, x, im);
+                // anticlockwise by less than a quarter turn: the negative real axis is crossed where im goes from >= 0 to < 0
+                turns += (im >= 0.0 && nim < 0.0) ? 1 : 0;
+                re = nre; im = nim;
+                if ((j & 3) == 0) {   // keep the modulus near one: (1 + x^2)^(r/2) leaves the range of a double for large u
+                    const int e = __builtin_amdgcn_frexp_exp(fmax(fabs(re), fabs(im)));
+                    re = ldexp(re, -e); im = ldexp(im, -e);
+                    expo += e;
+                }
+            }
+            const double theta = atan2(im, re) + 2.0 * PI * (double)turns;        // sum_j atan(x_j)
+            const double logmod2 = log(re * re + im * im) + 2.0 * 0.6931471805599453 * (double)expo;   // sum_j log(1 + x_j^2)
+            sum1 += theta;
+            sum2 += theta;                // (every term is positive)
+            sum3 -= 0.25 * logmod2;
+        } else {
+            for (int j = q.r - 1; j >= 0; j--) {
+                const double x = 2.0 * q.lb[j] * u;
+                const double y = x * x;
+                sum3 -= 0.25 * log1p_variant(y, true);
+                const double z = atan(x);
+                sum1 += z;
+                sum2 += fabs(z);
+            }
         }
         double x = inpi * exp_guard(sum3) / u;
         if (!mainx) x *= (1.0 - exp_guard(-0.5 * tausq * u * u));
@@ -386,11 +414,214 @@ __device__ double liu_mod_sf(const double* lb, int r, double t, int lane) {
     return ncx2_sf(tfinal, dof_x, delta_x > 1e-9 ? delta_x : 1e-9);
 }
 
+// ---- eigenvalues -----------------------------------------------------------------------------
+__device__ inline double wave_min(double v) {
+    v = fmin(v, __shfl_xor(v, 32, 64));
+    v = fmin(v, lane_xor_swizzle(v, 16)); v = fmin(v, lane_xor_swizzle(v, 8)); v = fmin(v, lane_xor_swizzle(v, 4));
+    v = fmin(v, lane_xor_quad(v, 2)); v = fmin(v, lane_xor_quad(v, 1));
+    return v;
+}
+
+// Eigenvalues of the symmetric tridiagonal matrix (dd [k], ee [k - 1], both in LDS and overwritten) by Sturm bisection
+// from the Gershgorin interval, one eigenvalue index per lane (LAPACK dstebz's procedure and stopping rule), ascending
+// into ev.  The count of eigenvalues below a point is taken from the signs of the leading principal minors
+//     p_0 = 1,  p_1 = d_1 - x,  p_i = (d_i - x) p_(i-1) - e_(i-1)^2 p_(i-2)
+// rather than from their quotients q_i = p_i / p_(i-1) (dstebz's form, q_i = d_i - x - e^2 / q_(i-1)): the quotient form
+// is a chain of k dependent divisions per count, ~55 counts per eigenvalue -- it was half of this kernel's time at 50
+// contexts -- where the minors cost one dependent multiply-add each.  The two count the same sign changes; what the
+// quotient form buys, safety from over- and underflow, is supplied here by (1) scaling the matrix by a power of two to
+// |T| in [1/2, 1) (exact), so a pair of consecutive minors grows by at most 3^8 over eight steps, and taking out its
+// exponent every eight steps; (2) a floor of 2^-110 on the scaled e^2 (a perturbation of 2^-55 |T| of an off-diagonal
+// entry: an eighth of a rounding), so that a step shrinks the pair by no more than e^2 / 4 -- the step is the matrix
+// [[d - x, -e^2], [1, 0]], of determinant e^2 and norm below 4 -- eight steps by no more than 2^-896, and a minor that is
+// exactly zero is followed by one that is not.
+__device__ void sturm_bisection(double* dd, double* ee, double* ev, int k, int lane, bool bad) {
+    double gl = INFINITY, gu = -INFINITY;
+    for (int i = lane; i < k; i += 64) {
+        const double lo = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i < k - 1 ? fabs(ee[i]) : 0.0);
+        gl = fmin(gl, dd[i] - lo);
+        gu = fmax(gu, dd[i] + lo);
+    }
+    gl = wave_min(gl);
+    gu = -wave_min(-gu);
+    const double eps = 2.220446049250313e-16;
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    __syncthreads();
+    if (bad) return;
+    if (!(tnorm > 0.0) || !(tnorm < INFINITY)) {    // the zero matrix (or an overflow on the way here)
+        for (int i = lane; i < k; i += 64) ev[i] = tnorm == 0.0 ? 0.0 : NAN;
+        __syncthreads();
+        return;
+    }
+    const int E = __builtin_amdgcn_frexp_exp(tnorm);
+    for (int i = lane; i < k; i += 64) {
+        dd[i] = ldexp(dd[i], -E);
+        if (i < k - 1) {
+            const double e = ldexp(ee[i], -E);
+            ee[i] = fmax(e * e, 0x1p-110);
+        }
+    }
+    __syncthreads();
+    const double tn = ldexp(tnorm, -E);
+    const double slop = 2.1 * tn * eps * k;
+    const double lo0 = ldexp(gl, -E) - slop, hi0 = ldexp(gu, -E) + slop;
+    const double atol = 2.0 * eps * tn;
+    for (int idx = lane; idx < k; idx += 64) {
+        double lo = lo0, hi = hi0;
+        for (int it = 0; it < 200; it++) {
+            const double mid = 0.5 * (lo + hi);
+            if (hi - lo <= fmax(atol, 2.0 * eps * fmax(fabs(lo), fabs(hi))) || mid == lo || mid == hi) break;
+            // (the signs of the minors go through a shift register, one v_alignbit per step; the sign changes of eight
+            // steps are counted at once.  An exactly zero minor needs no rule of its own: p_i = 0 makes p_(i+1) =
+            // -e^2 p_(i-1), so whichever sign the zero is read with, the three of them show exactly one change.)
+            double p2 = 1.0, p1 = dd[0] - mid;
+            unsigned signs = __builtin_amdgcn_alignbit(0u, (unsigned)__double2hiint(p1), 31);   // [.. 0, sign(p_1)]
+            int cnt = (int)(signs & 1u);
+            auto step = [&](double d, double e2) {
+                const double t = e2 * p2;
+                const double pn = fma(d - mid, p1, -t);
+                signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(pn), 31);
+                p2 = p1;
+                p1 = pn;
+            };
+            int i = 1;
+            for (; i + 7 < k; i += 8) {
+                const double d0 = dd[i], d1 = dd[i + 1], d2 = dd[i + 2], d3 = dd[i + 3];
+                const double d4 = dd[i + 4], d5 = dd[i + 5], d6 = dd[i + 6], d7 = dd[i + 7];
+                const double e0 = ee[i - 1], e1 = ee[i], e2 = ee[i + 1], e3 = ee[i + 2];
+                const double e4 = ee[i + 3], e5 = ee[i + 4], e6 = ee[i + 5], e7 = ee[i + 6];
+                step(d0, e0); step(d1, e1); step(d2, e2); step(d3, e3);
+                step(d4, e4); step(d5, e5); step(d6, e6); step(d7, e7);
+                cnt += __popc((signs ^ (signs >> 1)) & 0xFFu);
+                const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(p1), fabs(p2)));
+                p1 = ldexp(p1, -ex);
+                p2 = ldexp(p2, -ex);
+            }
+            for (; i < k; i++) {
+                step(dd[i], ee[i - 1]);
+                cnt += (int)((signs ^ (signs >> 1)) & 1u);
+            }
+            if (cnt > idx) hi = mid; else lo = mid;
+        }
+        ev[idx] = ldexp(0.5 * (lo + hi), E);
+    }
+    __syncthreads();
+}
+
+// Householder tridiagonalisation of the full symmetric matrix A [k][ks] (LAPACK dsytd2, lower) for k <= 64: the rows of
+// the trailing block one per lane, the Householder vector v and the update vector w IN REGISTERS -- lane i holds v_i and
+// w_i; the inner products and the rank-two update read them with v_readlane (the index is wave-uniform) instead of from
+// LDS, which leaves one LDS access per multiply-add and no scratch beside the matrix -- 20.4 KB at 50 contexts, eight
+// wavefronts to a compute unit, a launch of 4096 variants in two rounds (with LDS scratch it was 22.4 KB: seven, three
+// rounds).  The diagonal and the sub-diagonal are left in place (A[i][i], A[i+1][i]).
+__device__ void tridiagonalise_narrow(double* A, int k, int ks, int lane) {
+    for (int j = 0; j < k - 2; j++) {
+        const int m = k - j - 1;
+        const bool in = lane < m;
+        double* row = A + (j + 1 + (in ? lane : 0)) * ks + (j + 1);   // (idle lanes: a valid row, nothing stored)
+        const double x = in ? row[-1] : 0.0;
+        const double sig = wsum(lane >= 1 ? x * x : 0.0);
+        const double alpha = read_lane(x, 0);
+        double tau = 0.0, beta = alpha, v = x;
+        if (sig != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + sig), alpha);
+            tau = (beta - alpha) / beta;
+            const double sc = 1.0 / (alpha - beta);
+            v = lane == 0 ? 1.0 : x * sc;
+        }
+        if (lane == 0) row[-1] = beta;
+        if (tau != 0.0) {
+            double p = 0.0;
+            int c = 0;
+            for (; c + 3 < m; c += 4) {     // (four loads in flight; the sum in the order of the plain loop)
+                const double r0 = row[c], r1 = row[c + 1], r2 = row[c + 2], r3 = row[c + 3];
+                p += r0 * read_lane(v, c);
+                p += r1 * read_lane(v, c + 1);
+                p += r2 * read_lane(v, c + 2);
+                p += r3 * read_lane(v, c + 3);
+            }
+            for (; c < m; c++) p += row[c] * read_lane(v, c);
+            p = in ? p * tau : 0.0;
+            const double a2 = -0.5 * tau * wsum(p * v);
+            const double w = p + a2 * v;
+            auto update = [&](int cc, double rv) { return rv - (v * read_lane(w, cc) + w * read_lane(v, cc)); };
+            for (c = 0; c + 3 < m; c += 4) {
+                const double r0 = update(c, row[c]), r1 = update(c + 1, row[c + 1]);
+                const double r2 = update(c + 2, row[c + 2]), r3 = update(c + 3, row[c + 3]);
+                if (in) { row[c] = r0; row[c + 1] = r1; row[c + 2] = r2; row[c + 3] = r3; }
+            }
+            for (; c < m; c++) {
+                const double r = update(c, row[c]);
+                if (in) row[c] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The same reduction for more than 64 contexts: lanes stride the rows, v and w in LDS (hv, hw); diagonal and sub-diagonal
+// into dd [k], ee [k - 1].
+__device__ void tridiagonalise_wide(double* A, int k, int ks, int lane, double* dd, double* ee, double* hv, double* hw) {
+    for (int j = 0; j < k - 2; j++) {
+        const int m = k - j - 1;
+        double sig = 0.0;
+        for (int i = lane; i < m; i += 64) {
+            const double x = A[(j + 1 + i) * ks + j];
+            hv[i] = x;
+            if (i >= 1) sig += x * x;
+        }
+        sig = wsum(sig);
+        __syncthreads();
+        const double alpha = hv[0];
+        double tau = 0.0, beta = alpha;
+        if (sig != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + sig), alpha);
+            tau = (beta - alpha) / beta;
+            const double sc = 1.0 / (alpha - beta);
+            __syncthreads();
+            for (int i = lane; i < m; i += 64) hv[i] = i == 0 ? 1.0 : hv[i] * sc;
+        }
+        if (lane == 0) {
+            dd[j] = A[j * ks + j];
+            ee[j] = beta;
+        }
+        __syncthreads();
+        if (tau != 0.0) {
+            double pv = 0.0;
+            for (int i = lane; i < m; i += 64) {
+                const double* row = A + (j + 1 + i) * ks + (j + 1);
+                double p = 0.0;
+                for (int cidx = 0; cidx < m; cidx++) p += row[cidx] * hv[cidx];
+                p *= tau;
+                hw[i] = p;
+                pv += p * hv[i];
+            }
+            pv = wsum(pv);
+            const double a2 = -0.5 * tau * pv;
+            __syncthreads();
+            for (int i = lane; i < m; i += 64) hw[i] += a2 * hv[i];
+            __syncthreads();
+            for (int i = lane; i < m; i += 64) {
+                double* row = A + (j + 1 + i) * ks + (j + 1);
+                const double vi = hv[i], wi = hw[i];
+                for (int cidx = 0; cidx < m; cidx++) row[cidx] -= vi * hw[cidx] + wi * hv[cidx];
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        dd[k - 2] = A[(k - 2) * ks + (k - 2)];
+        dd[k - 1] = A[(k - 1) * ks + (k - 1)];
+        ee[k - 2] = A[(k - 1) * ks + (k - 2)];
+    }
+    __syncthreads();
+}
+
 // ---- the kernel ------------------------------------------------------------------------------
-// LDS: A [k][ks] (ks = k | 1), ev [k], kept [k], tridiagonal + Householder scratch
-#ifdef CRM_DAVIES_WAVES
-__attribute__((amdgpu_waves_per_eu(CRM_DAVIES_WAVES, CRM_DAVIES_WAVES)))
-#endif
+// LDS, NARROW (k <= 64, and every launch without the eigenvalue step): A [k][ks] (ks = k | 1), over which -- the matrix is
+// dead once reduced -- ev [k], kept [k], the tridiagonal's dd [k], ee [k] are laid.  Otherwise (k > 64): A [k][ks] (in
+// global memory past 128 contexts), ev [k], kept [k] (doubles as dd), k + 2 doubles for ee, 2k for the Householder vectors.
+template <bool NARROW>
 __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict__ Fall,
                                                          const double* __restrict__ Qall, int k,
                                                          double* __restrict__ lambda_out,
@@ -402,17 +633,16 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int ks = k | 1;
-    // the working copy of F: in LDS, or -- more than 128 contexts, the slower form -- in global memory (one wavefront per
-    // matrix: the barriers below order its accesses)
-    const bool a_global = k > 128;                             // (the launcher's rule)
+    const bool a_global = !NARROW && k > 128;                  // (the launcher's rule)
     double* A = a_global ? scratch + (size_t)b * k * ks : sm;  // k * ks  (touched only with do_eig)
-    double* ev = a_global ? sm : sm + (long)k * ks;            // k
-    double* kept = ev + k;        // k
-    double* rc = kept + k;        // k/2+1 cos
-    double* rs = rc + (k / 2 + 1);  // k/2+1 sin
-    int* rp = reinterpret_cast<int*>(rs + (k / 2 + 1));  // start of the 2k-double Householder scratch
+    double* ev = (NARROW || a_global) ? sm : sm + (long)k * ks;   // k
+    double* kept = ev + k;                                     // k
 
     bool bad = false;
+#ifdef CRM_DAVIES_STAMPS   // (tools/diag/davies_phases.py: phase durations in 10 ns ticks, written over lambda_out[0..3])
+    const unsigned long long st0 = wall_clock64();
+    unsigned long long st1 = st0, st2 = st0, st3 = st0;
+#endif
     if (do_eig) {
         const double* __restrict__ F = Fall + (long)b * k * k;
         for (int e = lane; e < k * k; e += 64) {
@@ -423,115 +653,35 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
         }
         bad = __any(bad);
         __syncthreads();
-        double* dd = kept;      // diagonal of the tridiagonal form (kept[] is free until the filter)
-        double* ee = rc;        // sub-diagonal, k-1 entries (rc/rs are contiguous: 2*(k/2+1) >= k)
-        double* hv = reinterpret_cast<double*>(rp);  // Householder vector / w, 2k doubles (see launch)
-        double* hw = hv + k;
-        if (!bad && k > 2) {
-            // Householder tridiagonalisation of the full symmetric matrix (LAPACK dsytd2, lower),
-            // lanes over the rows of the trailing block
-            for (int j = 0; j < k - 2; j++) {
-                const int m = k - j - 1;
-                double sig = 0.0;
-                for (int i = lane; i < m; i += 64) {
-                    const double x = A[(j + 1 + i) * ks + j];
-                    hv[i] = x;
-                    if (i >= 1) sig += x * x;
-                }
-                sig = wsum(sig);
-                __syncthreads();
-                const double alpha = hv[0];
-                double tau = 0.0, beta = alpha;
-                if (sig != 0.0) {
-                    beta = -copysign(sqrt(alpha * alpha + sig), alpha);
-                    tau = (beta - alpha) / beta;
-                    const double sc = 1.0 / (alpha - beta);
-                    __syncthreads();
-                    for (int i = lane; i < m; i += 64) hv[i] = i == 0 ? 1.0 : hv[i] * sc;
-                }
-                if (lane == 0) {
-                    dd[j] = A[j * ks + j];
-                    ee[j] = beta;
-                }
-                __syncthreads();
-                if (tau != 0.0) {
-                    double pv = 0.0;
-                    for (int i = lane; i < m; i += 64) {
-                        const double* row = A + (j + 1 + i) * ks + (j + 1);
-                        double p = 0.0;
-                        for (int cidx = 0; cidx < m; cidx++) p += row[cidx] * hv[cidx];
-                        p *= tau;
-                        hw[i] = p;
-                        pv += p * hv[i];
-                    }
-                    pv = wsum(pv);
-                    const double a2 = -0.5 * tau * pv;
-                    __syncthreads();
-                    for (int i = lane; i < m; i += 64) hw[i] += a2 * hv[i];
-                    __syncthreads();
-                    for (int i = lane; i < m; i += 64) {
-                        double* row = A + (j + 1 + i) * ks + (j + 1);
-                        const double vi = hv[i], wi = hw[i];
-                        for (int cidx = 0; cidx < m; cidx++) row[cidx] -= vi * hw[cidx] + wi * hv[cidx];
-                    }
-                    __syncthreads();
-                }
+        if constexpr (NARROW) {
+            if (!bad) tridiagonalise_narrow(A, k, ks, lane);
+            double d = 0.0, e = 0.0;
+            if (lane < k) {
+                d = A[lane * ks + lane];
+                if (lane < k - 1) e = A[(lane + 1) * ks + lane];
             }
-        }
-        if (lane == 0) {
-            if (k == 1) {
-                dd[0] = A[0];
-            } else if (k == 2) {
-                dd[0] = A[0]; dd[1] = A[ks + 1]; ee[0] = A[ks];
-            } else {
-                dd[k - 2] = A[(k - 2) * ks + (k - 2)];
-                dd[k - 1] = A[(k - 1) * ks + (k - 1)];
-                ee[k - 2] = A[(k - 1) * ks + (k - 2)];
+            __syncthreads();
+            double* dd = sm + 2 * k;
+            double* ee = sm + 3 * k;
+            if (lane < k) {
+                dd[lane] = d;
+                ee[lane] = e;
             }
+            __syncthreads();
+#ifdef CRM_DAVIES_STAMPS
+            st1 = wall_clock64();
+#endif
+            sturm_bisection(dd, ee, ev, k, lane, bad);
+        } else {
+            double* dd = kept;               // (kept[] is free until the filter)
+            double* ee = kept + k;           // k + 2 doubles
+            double* hv = ee + 2 * (k / 2 + 1);
+            if (!bad) tridiagonalise_wide(A, k, ks, lane, dd, ee, hv, hv + k);
+#ifdef CRM_DAVIES_STAMPS
+            st1 = wall_clock64();
+#endif
+            sturm_bisection(dd, ee, ev, k, lane, bad);
         }
-        __syncthreads();
-        // eigenvalues of the tridiagonal matrix by Sturm bisection (LAPACK dstebz), one index per lane
-        double gl = INFINITY, gu = -INFINITY, emax = 0.0;
-        for (int i = lane; i < k; i += 64) {
-            const double lo = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i < k - 1 ? fabs(ee[i]) : 0.0);
-            gl = fmin(gl, dd[i] - lo);
-            gu = fmax(gu, dd[i] + lo);
-            if (i < k - 1) emax = fmax(emax, ee[i] * ee[i]);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            gl = fmin(gl, __shfl_xor(gl, off, 64));
-            gu = fmax(gu, __shfl_xor(gu, off, 64));
-            emax = fmax(emax, __shfl_xor(emax, off, 64));
-        }
-        const double eps = 2.220446049250313e-16, safemin = 2.2250738585072014e-308;
-        const double pivmin = safemin * fmax(1.0, emax);
-        const double tnorm = fmax(fabs(gl), fabs(gu));
-        gl -= 2.1 * tnorm * eps * k + 2.1 * pivmin;
-        gu += 2.1 * tnorm * eps * k + 2.1 * pivmin;
-        const double atol = 2.0 * eps * tnorm + 2.0 * pivmin;
-        if (!bad) {
-            for (int idx = lane; idx < k; idx += 64) {
-                double lo = gl, hi = gu;
-                for (int it = 0; it < 200; it++) {
-                    const double mid = 0.5 * (lo + hi);
-                    if (hi - lo <= fmax(atol, 2.0 * eps * fmax(fabs(lo), fabs(hi))) || mid == lo || mid == hi) break;
-                    // number of eigenvalues below mid
-                    int cnt = 0;
-                    double q = dd[0] - mid;
-                    if (fabs(q) < pivmin) q = -pivmin;
-                    cnt += q < 0.0;
-                    for (int i = 1; i < k; i++) {
-                        q = dd[i] - mid - ee[i - 1] * ee[i - 1] / q;
-                        if (fabs(q) < pivmin) q = -pivmin;
-                        cnt += q < 0.0;
-                    }
-                    if (cnt > idx) hi = mid; else lo = mid;
-                }
-                ev[idx] = 0.5 * (lo + hi);
-            }
-        }
-        __syncthreads();
         for (int i = lane; i < k; i += 64) lambda_out[(long)b * k + i] = bad ? NAN : ev[i];
     } else {
         for (int i = lane; i < k; i += 64) {
@@ -541,6 +691,9 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
         bad = __any(bad);
         __syncthreads();
     }
+#ifdef CRM_DAVIES_STAMPS
+    st2 = wall_clock64();
+#endif
     const double Q = Qall[b];
     if (bad || !(fabs(Q) < INFINITY)) {
         if (lane == 0) {
@@ -583,6 +736,15 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
         pv_out[b] = p;
         if (ifault_out) ifault_out[b] = ifault;
         if (liu_out) liu_out[b] = p_liu;
+#ifdef CRM_DAVIES_STAMPS
+        st3 = wall_clock64();
+        if (k >= 4) {
+            lambda_out[(long)b * k + 0] = (double)(st1 - st0);
+            lambda_out[(long)b * k + 1] = (double)(st2 - st1);
+            lambda_out[(long)b * k + 2] = (double)(st3 - st2);
+            lambda_out[(long)b * k + 3] = (double)st0;
+        }
+#endif
     }
 }
 
@@ -598,17 +760,26 @@ int launch_eig_davies(hipStream_t st, const double* F, const double* Q, int coun
         return CRM_ERR_UNSUPPORTED;
     }
     const int ks = k | 1;
-    // A [k x ks], ev [k], kept [k] (doubles as the tridiagonal's diagonal), rc/rs [2*(k/2+1)] (its
-    // sub-diagonal), then 2k doubles for the Householder vectors
-    const bool global_copy = k > 128;
-    if (global_copy && do_eig && !scratch) {
+    const bool narrow = !do_eig || k <= 64;
+    const bool global_copy = !narrow && k > 128;
+    if (global_copy && !scratch) {
         set_error("eigen/Davies: k0=%d needs the global-memory work space", k);
         return CRM_ERR_ARG;
     }
-    size_t lds = sizeof(double) * ((global_copy ? 0 : (size_t)k * ks) + 2 * k + 2 * (k / 2 + 1) + 2 * k);
-    lds = (lds + 15) / 16 * 16;
-    hipLaunchKernelGGL(eig_davies_kernel, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
-                       ifault, liu, do_eig ? 1 : 0, global_copy ? scratch : nullptr);
+    size_t lds;
+    if (narrow) {
+        lds = sizeof(double) * (do_eig ? (size_t)std::max(k * ks, 4 * k) : (size_t)2 * k);
+        lds = (lds + 15) / 16 * 16;
+        hipLaunchKernelGGL(eig_davies_kernel<true>, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
+                           ifault, liu, do_eig ? 1 : 0, nullptr);
+    } else {
+        // A [k x ks], ev [k], kept [k] (doubles as the tridiagonal's diagonal), k + 2 doubles (its sub-diagonal), then 2k
+        // doubles for the Householder vectors
+        lds = sizeof(double) * ((global_copy ? 0 : (size_t)k * ks) + 2 * k + 2 * (k / 2 + 1) + 2 * k);
+        lds = (lds + 15) / 16 * 16;
+        hipLaunchKernelGGL(eig_davies_kernel<false>, dim3(count), dim3(64), lds, st, F, Q, k, lambda, pvalue,
+                           ifault, liu, 1, global_copy ? scratch : nullptr);
+    }
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }

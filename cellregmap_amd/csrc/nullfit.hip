@@ -16,6 +16,7 @@
 #include "crm_internal.h"
 #include "nullfit.h"
 #include "brent_search.h"
+#include "wave_ops.h"
 #include <type_traits>
 
 namespace crm {
@@ -25,40 +26,6 @@ namespace {
 constexpr double LOG2PI = 1.8378770664093453;
 constexpr double EPS_TINY = 2.220446049250313e-16;    // numpy_sugar.epsilon.tiny
 constexpr double EPS_SMALL = 1.4901161193847656e-08;  // numpy_sugar.epsilon.small
-
-// Sums over the 64 lanes, every lane ending with bitwise the same totals -- the xor butterfly
-//   for (off = 32, 16, 8, 4, 2, 1) v += shfl_xor(v, off)
-// with the same pairings in the same order, so every bit is the butterfly's -- but level by level for all N values of a
-// pass at once (the seven sums of an evaluation: seven dependent chains of six trips through the LDS crossbar each cost
-// more than the pass over a short spectrum itself; side by side they wait six times, not forty-two) and without the
-// crossbar's address arithmetic where the hardware has the permutation built in: xor 16 / 8 / 4 as ds_swizzle bit masks,
-// xor 2 / 1 as DPP quad permutations.
-__device__ inline double lane_xor_swizzle(double v, const int level) {   // level 16, 8 or 4: lane ^ level inside 32 lanes
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    switch (level) {
-        case 16: lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F); break;
-        case 8: lo = __builtin_amdgcn_ds_swizzle(lo, 0x201F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x201F); break;
-        default: lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F); break;
-    }
-    return __hiloint2double(hi, lo);
-}
-
-__device__ inline double lane_xor_quad(double v, const int level) {      // level 2 or 1: DPP quad_perm [2,3,0,1] / [1,0,3,2]
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    if (level == 2) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
-    }
-    return __hiloint2double(hi, lo);
-}
-
-__device__ inline double read_lane(double v, const int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
 
 // FROM = 32: all six levels (one fit per wavefront); FROM = 8: levels 8 .. 1 (a row of sixteen lanes)
 template <int N, int FROM>
