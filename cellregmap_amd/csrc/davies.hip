@@ -21,12 +21,8 @@ constexpr double LN28 = 0.08664339756999316;  // log(2)/8
 constexpr int DAVIES_LIM = 10000;
 constexpr double DAVIES_ACC = 1e-6;
 
-__device__ inline double wsum(double v) { return wave_sum_butterfly(v); }
-__device__ inline int wsum_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ inline double wsum(double v) { return wave_total(v); }
+__device__ inline int wsum_i(int v) { return wave_total(v); }
 
 __device__ inline double exp_guard(double x) { return x < -50.0 ? 0.0 : exp(x); }
 
@@ -509,49 +505,106 @@ __device__ void sturm_bisection(double* dd, double* ee, double* ev, int k, int l
 }
 
 // Householder tridiagonalisation of the full symmetric matrix A [k][ks] (LAPACK dsytd2, lower) for k <= 64: the rows of
-// the trailing block one per lane, the Householder vector v and the update vector w IN REGISTERS -- lane i holds v_i and
-// w_i; the inner products and the rank-two update read them with v_readlane (the index is wave-uniform) instead of from
-// LDS, which leaves one LDS access per multiply-add and no scratch beside the matrix -- 20.4 KB at 50 contexts, eight
-// wavefronts to a compute unit, a launch of 4096 variants in two rounds (with LDS scratch it was 22.4 KB: seven, three
-// rounds).  The diagonal and the sub-diagonal are left in place (A[i][i], A[i+1][i]).
+// the trailing block one per lane, so lane i holds v_i and w_i of the Householder vector and the update vector in
+// registers.  What every lane needs of them -- v_c, w_c, the same for all lanes -- is kept in the part of the matrix that
+// step j leaves dead: v in row j right of the diagonal (contiguous), w in column j below the sub-diagonal (w_0 by
+// v_readlane: that slot holds the sub-diagonal entry), and read back as LDS broadcasts.  No scratch beside the matrix --
+// 20.4 KB at 50 contexts, eight wavefronts to a compute unit, a launch of 4096 variants in two rounds (with scratch it was
+// 22.4 KB: seven, three rounds).  The diagonal and the sub-diagonal are left in place (A[i][i], A[i+1][i]).
 __device__ void tridiagonalise_narrow(double* A, int k, int ks, int lane) {
     for (int j = 0; j < k - 2; j++) {
         const int m = k - j - 1;
         const bool in = lane < m;
         double* row = A + (j + 1 + (in ? lane : 0)) * ks + (j + 1);   // (idle lanes: a valid row, nothing stored)
+        double* V = A + j * ks + (j + 1);           // v_c at V[c]
+        double* W = A + (j + 1) * ks + j;           // w_c at W[c * ks], c >= 1
         const double x = in ? row[-1] : 0.0;
         const double sig = wsum(lane >= 1 ? x * x : 0.0);
         const double alpha = read_lane(x, 0);
         double tau = 0.0, beta = alpha, v = x;
         if (sig != 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + sig), alpha);
-            tau = (beta - alpha) / beta;
-            const double sc = 1.0 / (alpha - beta);
-            v = lane == 0 ? 1.0 : x * sc;
+            // beta = -sign(alpha) |x|, tau = (beta - alpha) / beta = 1 + |alpha| / |x|, 1 / (alpha - beta) = sign(alpha) /
+            // (|alpha| + |x|): one reciprocal square root and one reciprocal, Newton-refined from the hardware estimates
+            // (a square root and two divisions by the IEEE sequences are a fifth of a step's dependent chain)
+            const double n2 = alpha * alpha + sig, h = 0.5 * n2;
+            double rs = __builtin_amdgcn_rsq(n2);
+            rs *= fma(-h * rs, rs, 1.5);
+            rs *= fma(-h * rs, rs, 1.5);
+            const double nrm = n2 * rs;
+            beta = -copysign(nrm, alpha);
+            tau = fma(fabs(alpha), rs, 1.0);
+            const double den = fabs(alpha) + nrm;
+            double rc = __builtin_amdgcn_rcp(den);
+            rc = fma(fma(-den, rc, 1.0), rc, rc);
+            rc = fma(fma(-den, rc, 1.0), rc, rc);
+            v = lane == 0 ? 1.0 : x * copysign(rc, alpha);
         }
         if (lane == 0) row[-1] = beta;
         if (tau != 0.0) {
+            if (in) V[lane] = v;
+            __syncthreads();
+            // (the loops below are bound by the LDS round trip, not by their arithmetic: each batch's operands are
+            // requested one batch ahead)
             double p = 0.0;
             int c = 0;
-            for (; c + 3 < m; c += 4) {     // (four loads in flight; the sum in the order of the plain loop)
-                const double r0 = row[c], r1 = row[c + 1], r2 = row[c + 2], r3 = row[c + 3];
-                p += r0 * read_lane(v, c);
-                p += r1 * read_lane(v, c + 1);
-                p += r2 * read_lane(v, c + 2);
-                p += r3 * read_lane(v, c + 3);
+            if (m >= 8) {
+                double rr[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { rr[u] = row[u]; vv[u] = V[u]; }
+#pragma unroll 2
+                for (; c + 15 < m; c += 8) {
+                    double rn[8], vn[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { rn[u] = row[c + 8 + u]; vn[u] = V[c + 8 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p += rr[u] * vv[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { rr[u] = rn[u]; vv[u] = vn[u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) p += rr[u] * vv[u];
+                c += 8;
             }
-            for (; c < m; c++) p += row[c] * read_lane(v, c);
+            for (; c < m; c++) p += row[c] * V[c];
             p = in ? p * tau : 0.0;
             const double a2 = -0.5 * tau * wsum(p * v);
             const double w = p + a2 * v;
-            auto update = [&](int cc, double rv) { return rv - (v * read_lane(w, cc) + w * read_lane(v, cc)); };
-            for (c = 0; c + 3 < m; c += 4) {
-                const double r0 = update(c, row[c]), r1 = update(c + 1, row[c + 1]);
-                const double r2 = update(c + 2, row[c + 2]), r3 = update(c + 3, row[c + 3]);
-                if (in) { row[c] = r0; row[c + 1] = r1; row[c + 2] = r2; row[c + 3] = r3; }
+            if (in && lane >= 1) W[lane * ks] = w;
+            const double w0 = read_lane(w, 0);
+            __syncthreads();
+            // A <- A - v w' - w v'
+            auto update = [&](double rv, double vc, double wc) { return fma(-w, vc, fma(-v, wc, rv)); };
+            {
+                const double r = update(row[0], 1.0, w0);
+                if (in) row[0] = r;
+            }
+            c = 1;
+            if (m >= 5) {
+                double rr[4], vv[4], ww[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { rr[u] = row[1 + u]; vv[u] = V[1 + u]; ww[u] = W[(1 + u) * ks]; }
+#pragma unroll 2
+                for (; c + 7 < m; c += 4) {
+                    double rn[4], vn[4], wn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { rn[u] = row[c + 4 + u]; vn[u] = V[c + 4 + u]; wn[u] = W[(c + 4 + u) * ks]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double r = update(rr[u], vv[u], ww[u]);
+                        if (in) row[c + u] = r;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { rr[u] = rn[u]; vv[u] = vn[u]; ww[u] = wn[u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double r = update(rr[u], vv[u], ww[u]);
+                    if (in) row[c + u] = r;
+                }
+                c += 4;
             }
             for (; c < m; c++) {
-                const double r = update(c, row[c]);
+                const double r = update(row[c], V[c], W[c * ks]);
                 if (in) row[c] = r;
             }
         }
@@ -641,18 +694,27 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
     bool bad = false;
 #ifdef CRM_DAVIES_STAMPS   // (tools/diag/davies_phases.py: phase durations in 10 ns ticks, written over lambda_out[0..3])
     const unsigned long long st0 = wall_clock64();
-    unsigned long long st1 = st0, st2 = st0, st3 = st0;
+    unsigned long long st1 = st0, st2 = st0, st3 = st0, stl = st0;
 #endif
     if (do_eig) {
         const double* __restrict__ F = Fall + (long)b * k * k;
+        // (the lower triangle, as eigvalsh reads it, mirrored: the matrix is read in memory order -- its upper triangle read
+        // and dropped -- and e / k is a multiply-high: k * k <= 2^16)
+        const unsigned kinv = 0xFFFFFFFFu / (unsigned)k + 1u;
         for (int e = lane; e < k * k; e += 64) {
-            const int i = e / k, j = e - i * k;
-            const double v = i >= j ? F[(long)i * k + j] : F[(long)j * k + i];  // lower triangle
-            if (!(fabs(v) < INFINITY)) bad = true;
-            A[i * ks + j] = v;
+            const int i = (int)__umulhi((unsigned)e, kinv), j = e - i * k;
+            const double v = F[e];
+            if (i >= j) {
+                if (!(fabs(v) < INFINITY)) bad = true;
+                A[i * ks + j] = v;
+                A[j * ks + i] = v;
+            }
         }
         bad = __any(bad);
         __syncthreads();
+#ifdef CRM_DAVIES_STAMPS
+        stl = wall_clock64();
+#endif
         if constexpr (NARROW) {
             if (!bad) tridiagonalise_narrow(A, k, ks, lane);
             double d = 0.0, e = 0.0;
@@ -743,6 +805,7 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
             lambda_out[(long)b * k + 1] = (double)(st2 - st1);
             lambda_out[(long)b * k + 2] = (double)(st3 - st2);
             lambda_out[(long)b * k + 3] = (double)st0;
+            if (k >= 5) lambda_out[(long)b * k + 4] = (double)(stl - st0);
         }
 #endif
     }

@@ -49,4 +49,34 @@ __device__ inline double wave_sum_butterfly(double v) {
     return v;
 }
 
+// The total of one value over the 64 lanes, in every lane (wave-uniform: it comes back through v_readlane), by the DPP
+// row operations of the vector ALU alone -- an inclusive scan inside each row of sixteen (row_shr 1, 2, 4, 8), lane 15 of
+// rows 0 and 2 into rows 1 and 3 (row_bcast15), lane 31 into rows 2 and 3 (row_bcast31): the total stands in lane 63.
+// No trip through the LDS crossbar: about a third of the butterfly's latency.  NOT the butterfly's order of summation --
+// for sums whose bits nothing is pinned to (davies.hip).
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_fetch(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_total(double v) {
+    v += dpp_fetch<0x111, 0xF>(v);
+    v += dpp_fetch<0x112, 0xF>(v);
+    v += dpp_fetch<0x114, 0xF>(v);
+    v += dpp_fetch<0x118, 0xF>(v);
+    v += dpp_fetch<0x142, 0xA>(v);
+    v += dpp_fetch<0x143, 0xC>(v);
+    return read_lane(v, 63);
+}
+__device__ inline int wave_total(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 }  // namespace crm

@@ -27,6 +27,8 @@ for _ in range(3):
 if "--stamps" in sys.argv:
     t = lam[:, :3] * 0.01      # us
     start = (lam[:, 3] - lam[:, 3].min()) * 0.01
+    if k >= 5:
+        print("  of the reduction, loading the matrix: %.0f / %.0f us" % (np.median(lam[:, 4]) * 0.01, lam[:, 4].max() * 0.01))
     print("per wavefront, us (median / max): reduction %.0f / %.0f, bisection %.0f / %.0f, Davies %.0f / %.0f; start of the "
           "last wavefront %.0f us after the first" % (np.median(t[:, 0]), t[:, 0].max(), np.median(t[:, 1]), t[:, 1].max(),
                                                    np.median(t[:, 2]), t[:, 2].max(), start.max()))
