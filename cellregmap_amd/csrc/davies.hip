@@ -701,17 +701,31 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
         // (the lower triangle, as eigvalsh reads it, mirrored: the matrix is read in memory order -- its upper triangle read
         // and dropped -- and e / k is a multiply-high: k * k <= 2^16)
         const unsigned kinv = 0xFFFFFFFFu / (unsigned)k + 1u;
+        double amax = 0.0;
         for (int e = lane; e < k * k; e += 64) {
             const int i = (int)__umulhi((unsigned)e, kinv), j = e - i * k;
             const double v = F[e];
             if (i >= j) {
                 if (!(fabs(v) < INFINITY)) bad = true;
+                amax = fmax(amax, fabs(v));
                 A[i * ks + j] = v;
                 A[j * ks + i] = v;
             }
         }
         bad = __any(bad);
         __syncthreads();
+        // the reduction squares the entries: a matrix far from the middle of the double range is brought there by a power
+        // of two first (dsyev's scaling), and its eigenvalues taken back
+        int rescale = 0;
+        amax = -wave_min(-amax);
+        if (!bad && amax != 0.0 && (amax < 0x1p-400 || amax > 0x1p400)) {
+            rescale = __builtin_amdgcn_frexp_exp(amax);
+            for (int e = lane; e < k * k; e += 64) {
+                const int i = (int)__umulhi((unsigned)e, kinv), j = e - i * k;
+                A[i * ks + j] = ldexp(A[i * ks + j], -rescale);
+            }
+            __syncthreads();
+        }
 #ifdef CRM_DAVIES_STAMPS
         stl = wall_clock64();
 #endif
@@ -743,6 +757,10 @@ __global__ __launch_bounds__(64) void eig_davies_kernel(const double* __restrict
             st1 = wall_clock64();
 #endif
             sturm_bisection(dd, ee, ev, k, lane, bad);
+        }
+        if (rescale != 0) {
+            for (int i = lane; i < k; i += 64) ev[i] = ldexp(ev[i], rescale);
+            __syncthreads();
         }
         for (int i = lane; i < k; i += 64) lambda_out[(long)b * k + i] = bad ? NAN : ev[i];
     } else {

@@ -148,6 +148,50 @@ def test_eigvalsh_batched(ctx, k):
         assert_allclose(lam[i], ref, rtol=0, atol=1e-13 * max(1.0, abs(ref).max()))
 
 
+@pytest.mark.parametrize("k", [3, 8, 21, 50, 64, 70])
+def test_eigvalsh_on_structured_matrices(ctx, k):
+    """The cases the bisection's count -- signs of the leading minors, rescaled every eight steps (csrc/davies.hip:
+    sturm_bisection) -- has to survive without the quotient form's pivmin: the zero matrix, multiples of the identity,
+    diagonal matrices with zeros and repeats, decoupled blocks (exact zeros off the diagonal, a zero block), minors that
+    vanish exactly at a bisection point (antidiagonal pairs: eigenvalues +-1 around the midpoint 0), Wilkinson's close
+    pairs, rank one, negative definite, and entries near both ends of the double range."""
+    from cellregmap_amd import _lib
+
+    lib, h = ctx
+    rng = np.random.default_rng(100 + k)
+    mats = [np.zeros((k, k)), 3.5 * np.eye(k), -2.0 * np.eye(k)]
+    d = rng.normal(size=k); d[::3] = 0.0; d[1::4] = d[1]
+    mats.append(np.diag(d))
+    B = np.zeros((k, k)); h2 = k // 2
+    A = rng.normal(size=(h2, h2)); B[:h2, :h2] = A @ A.T            # a block and a zero block
+    mats.append(B)
+    C = np.zeros((k, k))
+    for i in range(0, k - 1, 2):
+        C[i, i + 1] = C[i + 1, i] = 1.0                             # 2 x 2 antidiagonal blocks: p_1(0) = 0 exactly
+    mats.append(C)
+    W = np.diag(np.abs(np.arange(k) - (k - 1) / 2.0)) + np.diag(np.ones(k - 1), 1) + np.diag(np.ones(k - 1), -1)
+    mats.append(W)                                                  # Wilkinson: pairs agreeing to ~1e-14
+    T = np.diag(rng.normal(size=k)) + np.diag(np.full(k - 1, 1e-200), 1) + np.diag(np.full(k - 1, 1e-200), -1)
+    mats.append(T)                                                  # couplings that underflow when squared
+    u = rng.normal(size=k)
+    mats.append(np.outer(u, u))                                     # rank one
+    A = rng.normal(size=(k, k))
+    mats.append(-(A @ A.T) - np.eye(k))                             # negative definite
+    S = A @ A.T
+    mats += [S * 1e-150, S * 1e150, S * 2.0 ** -1000, S + 1e8 * np.eye(k)]
+    P = np.eye(k)[rng.permutation(k)]
+    mats.append(P @ np.diag(np.r_[np.zeros(k - 2), 1.0, 1.0]) @ P.T)  # two ones and zeros, scrambled
+    F = np.ascontiguousarray(np.stack(mats))
+    lam = np.empty((len(mats), k))
+    _lib.check(lib.crm_test_eigvalsh(h, len(mats), k, _lib.ptr(F), _lib.ptr(lam)))
+    for i, M in enumerate(mats):
+        ref = np.linalg.eigvalsh(M)
+        scale = np.abs(ref).max()
+        assert np.all(np.isfinite(lam[i])), i
+        assert np.all(np.diff(lam[i]) >= 0), i
+        assert np.abs(lam[i] - ref).max() <= 4e-14 * scale + (0.0 if scale > 0 else 1e-300), (i, np.abs(lam[i] - ref).max(), scale)
+
+
 def test_davies_on_the_published_as155_case(ctx):
     """Q = 6 chi2_1 + 3 chi2_1 + chi2_1 (Imhof 1961 / Davies 1980, Table 1): P[Q < 7] = .4936,
     P[Q < 20] = .8760; at x = 1 the reference's settings (lim 10000, acc 1e-6) run out of terms and the
