@@ -10,6 +10,16 @@ namespace {
 
 constexpr int STAT_SPLITS = 64;
 
+// The row-by-row passes below launch one workgroup per (row, chunk of blockDim.x columns) with the CHUNK as the fast
+// index of a one-dimensional grid: workgroups dispatched together then stream neighbouring memory.  With the row as the fast
+// index (a dim3(rows, chunks) grid) neighbouring workgroups sit a whole row apart, and a 20 096 x 4096 block of doubles is
+// copied at 5.0 TB/s instead of 5.9 (tools/diag/micro/copy_shapes.hip).
+__device__ __forceinline__ void row_and_chunk(int chunks, long& row, int& chunk) {
+    row = blockIdx.x / (unsigned)chunks;
+    chunk = (int)(blockIdx.x - (unsigned)row * (unsigned)chunks);
+}
+inline dim3 row_chunk_grid(long rows, int chunks) { return dim3((unsigned)(rows * chunks)); }
+
 // partial[split][q][b]: q = 0 gg, 1 gy, 2.. gW_i.  y and W are columns of one row-major
 // matrix (leading dimension ldw).
 template <int C>
@@ -90,9 +100,11 @@ __global__ void variant_stats_finish(const double* __restrict__ partial, int var
 __global__ void gather_block_kernel(const double* __restrict__ src, long ld_src, long cells_pad,
                                     long cells, const int* __restrict__ row_index,
                                     const int* __restrict__ col_index, int variants,
-                                    double* __restrict__ dst, long ld_dst, int dst_cols) {
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
-    const long i = blockIdx.x;
+                                    double* __restrict__ dst, long ld_dst, int dst_cols, int chunks) {
+    long i;
+    int chunk;
+    row_and_chunk(chunks, i, chunk);
+    const int j = chunk * blockDim.x + threadIdx.x;
     if (j >= dst_cols) return;
     double v = 0.0;
     if (i < cells && j < variants) {
@@ -105,9 +117,11 @@ __global__ void gather_block_kernel(const double* __restrict__ src, long ld_src,
 
 __global__ void expand_block_kernel(const double* __restrict__ Gd, long ld_gd, const int* __restrict__ group,
                                     long cells, const int* __restrict__ row_index, int variants,
-                                    double* __restrict__ dst, long ld_dst, int dst_cols) {
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
-    const long i = blockIdx.x;
+                                    double* __restrict__ dst, long ld_dst, int dst_cols, int chunks) {
+    long i;
+    int chunk;
+    row_and_chunk(chunks, i, chunk);
+    const int j = chunk * blockDim.x + threadIdx.x;
     if (j >= dst_cols) return;
     double v = 0.0;
     if (i < cells && j < variants) {
@@ -143,9 +157,11 @@ __global__ void donor_stats_kernel(const double* __restrict__ Gam, long ld_gam, 
 
 __global__ void square_block_kernel(const double* __restrict__ Gt, const double* __restrict__ G,
                                     long ldg, long ldg_t, int cols, double* __restrict__ G2,
-                                    double* __restrict__ GG, long ld_out) {
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
-    const long i = blockIdx.x;
+                                    double* __restrict__ GG, long ld_out, int chunks) {
+    long i;
+    int chunk;
+    row_and_chunk(chunks, i, chunk);
+    const int j = chunk * blockDim.x + threadIdx.x;
     if (j >= cols) return;
     const double t = Gt[i * ldg_t + j];
     G2[i * ld_out + j] = t * t;
@@ -255,9 +271,11 @@ int launch_gather_slabs(hipStream_t st, const double* src, long ld_src, long row
 // ---- donor order of a background's kinship structure (objects.h: crm_background::kin*) ------------------------------
 // dst[k, j] = src[map[k], j] (map[k] < 0: a padding row of zeros), j < cols
 __global__ void gather_rows_kernel(const double* __restrict__ src, long ld_src, const int* __restrict__ map, int cols,
-                                   double* __restrict__ dst, long ld_dst) {
-    const long k = blockIdx.x;
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+                                   double* __restrict__ dst, long ld_dst, int chunks) {
+    long k;
+    int chunk;
+    row_and_chunk(chunks, k, chunk);
+    const int j = chunk * blockDim.x + threadIdx.x;
     if (j >= cols) return;
     const int c = map[k];
     dst[k * ld_dst + j] = c >= 0 ? src[(long)c * ld_src + j] : 0.0;
@@ -266,8 +284,9 @@ __global__ void gather_rows_kernel(const double* __restrict__ src, long ld_src, 
 int launch_gather_rows(hipStream_t st, const double* src, long ld_src, const int* map, long rows, int cols, double* dst,
                        long ld_dst) {
     if (rows <= 0 || cols <= 0) return CRM_OK;
-    dim3 grid((unsigned)rows, (unsigned)((cols + 255) / 256));
-    hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, st, src, ld_src, map, cols, dst, ld_dst);
+    const int chunks = (cols + 255) / 256;
+    hipLaunchKernelGGL(gather_rows_kernel, row_chunk_grid(rows, chunks), dim3(256), 0, st, src, ld_src, map, cols, dst, ld_dst,
+                       chunks);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }
@@ -397,9 +416,11 @@ __global__ void ortho_coef_kernel(const double* __restrict__ gW, long ld_gW, con
 __global__ __launch_bounds__(256) void ortho_apply_kernel(const double* __restrict__ G, long ldg,
                                                          const double* __restrict__ W, long ldw, int c,
                                                          const double* __restrict__ coef, long ld_coef, int cols,
-                                                         double* __restrict__ Gx, long ldx) {
-    const int b = blockIdx.y * blockDim.x + threadIdx.x;
-    const long i = blockIdx.x;
+                                                         double* __restrict__ Gx, long ldx, int chunks) {
+    long i;
+    int chunk;
+    row_and_chunk(chunks, i, chunk);
+    const int b = chunk * blockDim.x + threadIdx.x;
     if (b >= cols) return;
     double v = G[i * ldg + b];
     for (int j = 0; j < c; j++) v = fma(-W[i * ldw + j], coef[(long)j * ld_coef + b], v);
@@ -437,8 +458,9 @@ int launch_ortho_block(hipStream_t st, const double* G, long ldg, long cells_pad
     hipLaunchKernelGGL(ortho_coef_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, gW, ld_gW, proj, c, variants, cols,
                        coef, ld_coef, thr);
     CRM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ortho_apply_kernel, dim3((unsigned)cells_pad, (cols + 255) / 256), dim3(256), 0, st, G, ldg, W,
-                       ldw, c, coef, ld_coef, cols, Gx, ldx);
+    const int chunks = (cols + 255) / 256;
+    hipLaunchKernelGGL(ortho_apply_kernel, row_chunk_grid(cells_pad, chunks), dim3(256), 0, st, G, ldg, W,
+                       ldw, c, coef, ld_coef, cols, Gx, ldx, chunks);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }
@@ -646,9 +668,9 @@ int launch_pair_rows(hipStream_t st, const double* C, long ldc, int variants, in
 int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cells_pad, long cells,
                         const int* row_index, const int* col_index, int variants, double* dst,
                         long ld_dst, int dst_cols) {
-    dim3 grid((unsigned)cells_pad, (dst_cols + 255) / 256);
-    hipLaunchKernelGGL(gather_block_kernel, grid, dim3(256), 0, st, src, ld_src, cells_pad, cells,
-                       row_index, col_index, variants, dst, ld_dst, dst_cols);
+    const int chunks = (dst_cols + 255) / 256;
+    hipLaunchKernelGGL(gather_block_kernel, row_chunk_grid(cells_pad, chunks), dim3(256), 0, st, src, ld_src, cells_pad, cells,
+                       row_index, col_index, variants, dst, ld_dst, dst_cols, chunks);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }
@@ -656,9 +678,9 @@ int launch_gather_block(hipStream_t st, const double* src, long ld_src, long cel
 int launch_expand_block(hipStream_t st, const double* Gd, long ld_gd, const int* group, long cells_pad,
                         long cells, const int* row_index, int variants, double* dst, long ld_dst,
                         int dst_cols) {
-    dim3 grid((unsigned)cells_pad, (dst_cols + 255) / 256);
-    hipLaunchKernelGGL(expand_block_kernel, grid, dim3(256), 0, st, Gd, ld_gd, group, cells, row_index, variants,
-                       dst, ld_dst, dst_cols);
+    const int chunks = (dst_cols + 255) / 256;
+    hipLaunchKernelGGL(expand_block_kernel, row_chunk_grid(cells_pad, chunks), dim3(256), 0, st, Gd, ld_gd, group, cells,
+                       row_index, variants, dst, ld_dst, dst_cols, chunks);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }
@@ -682,9 +704,9 @@ int launch_donor_stats(hipStream_t st, const double* Gam, long ld_gam, int m, in
 
 int launch_square_block(hipStream_t st, const double* Gt, const double* G, long ldg, long ldg_t,
                         long cells_pad, int cols, double* G2, double* GG, long ld_out) {
-    dim3 grid((unsigned)cells_pad, (cols + 255) / 256);
-    hipLaunchKernelGGL(square_block_kernel, grid, dim3(256), 0, st, Gt, G, ldg, ldg_t, cols, G2, GG,
-                       ld_out);
+    const int chunks = (cols + 255) / 256;
+    hipLaunchKernelGGL(square_block_kernel, row_chunk_grid(cells_pad, chunks), dim3(256), 0, st, Gt, G, ldg, ldg_t, cols, G2, GG,
+                       ld_out, chunks);
     CRM_HIP(hipGetLastError());
     return CRM_OK;
 }
