@@ -5,10 +5,10 @@
 // (chi2comb, lim = 10000, acc = 1e-6), modified-Liu fall-back.  Same procedure as
 // oracle/davies.py + oracle/qfc.c, re-organised for 64 lanes:
 //   * eigenvalues: Householder tridiagonalisation in LDS (lanes over the rows of the trailing
-//     block) followed by Sturm-sequence bisection, one eigenvalue index per lane;
+//     block) followed by Sturm-sequence bisection, one eigenvalue index per lane (DESIGN.md 5b);
 //   * qfc: the scalar search logic (truncation point, cut-offs, step) runs wave-uniform;
-//     every sum over the eigenvalues is lane-parallel + butterfly, and the trapezoid rule
-//     puts one abscissa per lane.
+//     every sum over the eigenvalues is lane-parallel + a wave total (wave_ops.h), and the
+//     trapezoid rule puts one abscissa per lane.
 #include "nullfit.h"
 #include "wave_ops.h"
 
